@@ -1,0 +1,316 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference under the
+shims of _refshim.py) on seeded inputs, asserting the oracle agrees, and saving inputs + expected
+outputs.  Runs only in the build container:  python tests/golden/make_golden.py
+
+Fixtures are data (inputs, seeds, expected outputs); no reference source is stored.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+from fixture_init import seeded_state  # noqa: E402
+from oracle import anchors as OA, boxes as OB, coders as OC, geometry as OG, nets as ON, rpn as OR  # noqa: E402
+
+# reference modules
+from model import anchor as R_anchor, utils as R_utils, rpn as R_rpn  # noqa: E402
+from model.coder import AABBCoder, MidpointOffsetCoder  # noqa: E402
+from model.coder import misc as R_misc  # noqa: E402
+from model.feature_extractor import VGG_FPN  # noqa: E402
+from model.nerf_rpn import NeRFRegionProposalNetwork  # noqa: E402
+from model.rotated_iou import oriented_iou_loss as R_iou, box_intersection_2d as R_b2d  # noqa: E402
+import run_rpn as R_run  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def close(a, b, tol, what):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= tol, f"oracle != reference for {what}: max err {err}"
+    return err
+
+
+def rand_obb(n, g, lo=4.0, hi=60.0, smin=2.0, smax=24.0):
+    c = torch.rand(n, 3, generator=g) * (hi - lo) + lo
+    s = torch.rand(n, 3, generator=g) * (smax - smin) + smin
+    t = (torch.rand(n, 1, generator=g) - 0.5) * math.pi
+    return torch.cat([c, s, t], dim=1)
+
+
+def rand_aabb(n, g, lo=0.0, hi=60.0, smin=2.0, smax=24.0):
+    c = torch.rand(n, 3, generator=g) * (hi - lo) + lo
+    s = torch.rand(n, 3, generator=g) * (smax - smin) + smin
+    return torch.cat([c - s / 2, c + s / 2], dim=1)
+
+
+# --------------------------------------------------------------------------------------------
+def gen_geometry():
+    print("geometry")
+    g = torch.Generator().manual_seed(11)
+    K = 600
+    b1 = rand_obb(K, g, 10, 30, 2, 20)
+    b2 = rand_obb(K, g, 10, 30, 2, 20)
+    b2[:150, :3] = b1[:150, :3] + (torch.rand(150, 3, generator=g) - 0.5) * 4      # heavy overlaps
+    special1 = torch.tensor([[0, 0, 0, 3, 3, 3, 0.], [1, 1, 1, 2, 2, 2, 0.], [0, 0, 0, 3, 3, 3, 0.],
+                             [5, 5, 5, 4, 2, 3, 0.3], [5, 5, 5, 4, 2, 3, 0.3], [0, 0, 0, 2, 2, 2, 0.],
+                             [0, 0, 0, 4, 4, 4, 0.], [0, 0, 0, 4, 2, 2, 0.], [0, 0, 0, 2, 2, 2, 0.]])
+    special2 = torch.tensor([[0, 0, 0, 3, 3, 3, 0.], [2, 1, 1, 2, 2, 2, 0.], [1, 1, 1, 2, 2, 2, math.pi / 3],
+                             [5, 5, 5, 4, 2, 3, 0.3], [5, 5, 5, 2, 4, 3, 0.3 - math.pi / 2], [10, 10, 10, 2, 2, 2, 0.],
+                             [0, 0, 0, 1, 1, 1, 0.7], [0, 0, 0, 2, 4, 2, math.pi / 2], [2, 0, 0, 2, 2, 2, 0.]])
+    b1 = torch.cat([special1, b1]).unsqueeze(0)
+    b2 = torch.cat([special2, b2]).unsqueeze(0)
+    iou = R_iou.cal_iou_3d(b1, b2)
+    gl, gi, _ = R_iou.cal_giou_3d(b1, b2)
+    dl, _ = R_iou.cal_diou_3d(b1, b2)
+    # the sort op's own I/O, captured inside the reference stack
+    c1 = R_iou.box2corners_th(b1[..., [0, 1, 3, 4, 6]])
+    c2 = R_iou.box2corners_th(b2[..., [0, 1, 3, 4, 6]])
+    inters, mi = R_b2d.box_intersection_th(c1, c2)
+    c12, c21 = R_b2d.box_in_box_th(c1, c2)
+    verts, mask = R_b2d.build_vertices(c1, c2, c12, c21, inters, mi)
+    nv = mask.int().sum(2).int()
+    mean = (verts * mask.float().unsqueeze(-1)).sum(2, keepdim=True) / nv[..., None, None]
+    vn = (verts - mean).float()
+    order = R_b2d.sort_indices(verts, mask)
+    e = [close(OG.iou_3d(b1, b2), iou, 1e-6, "iou3d"), close(OG.giou_3d(b1, b2)[0], gl, 1e-5, "giou"),
+         close(OG.diou_3d(b1, b2)[0], dl, 1e-5, "diou")]
+    print("   max err", e, " iou known answers:", iou[0, :3].tolist())
+    assert abs(iou[0, 0] - 1) < 1e-6 and abs(iou[0, 1] - 1 / 3) < 1e-6 and abs(iou[0, 2] - 0.1138) < 1e-4
+    a = rand_aabb(40, g)
+    b = rand_aabb(300, g)
+    m = R_utils.box_iou_3d(a, b)
+    close(OB.aabb_iou_matrix(a, b), m, 0, "aabb iou")
+    om = R_utils.box_iou_3d(b1[0, :40], b2[0, :50])
+    close(OB.iou_matrix(b1[0, :40], b2[0, :50]), om, 1e-6, "obb matrix")
+    save("geometry", b1=b1, b2=b2, iou3d=iou, giou_loss=gl, diou_loss=dl,
+         sort_vertices=vn, sort_mask=mask, sort_num_valid=nv, sort_order=order.int(),
+         aabb_a=a, aabb_b=b, aabb_iou=m, obb_matrix=om)
+
+
+def ref_anchor_gen():
+    return R_anchor.AnchorGenerator3D(R_run.anchor_sizes, R_run.aspect_ratios, is_normalized=False)
+
+
+def gen_anchors():
+    print("anchors")
+    ag = ref_anchor_gen()
+    mesh = torch.zeros(2, 4, 40, 36, 28)
+    grids = [(10, 9, 7), (5, 5, 4), (3, 3, 2), (2, 2, 1)]
+    feats = [torch.zeros(2, 8, *gr) for gr in grids]
+    anchors, _ = ag(mesh, feats)
+    ratio_order = []
+    for r in R_run.aspect_ratios[0]:
+        import itertools
+        ratio_order += list(set(itertools.permutations(r)))
+    assert tuple(ratio_order) == OA.RATIO_ORDER, ratio_order
+    mine = torch.cat(OA.all_anchors((40, 36, 28), grids))
+    close(mine, anchors[0], 0, "anchors")
+    ori = [(40, 36, 28), (33, 20, 28)]
+    masks = ag.get_padding_masks(mesh, feats, ori)
+    flat = torch.cat([R_rpn.permute_and_flatten(m, *m.shape[:2], 1, *m.shape[2:]) for m in masks], dim=1).squeeze(-1)
+    assert torch.equal(flat, OA.padding_masks((40, 36, 28), grids, ori))
+    save("anchors", mesh_size=[40, 36, 28], grids=grids, anchors=anchors[0], ratio_order=ratio_order,
+         ori_sizes=ori, padding_mask=flat)
+
+
+def gen_coders():
+    print("coders")
+    g = torch.Generator().manual_seed(5)
+    M = 500
+    anc = rand_aabb(M, g, 0, 60, 4, 40)
+    gt6 = rand_aabb(M, g, 0, 60, 4, 40)
+    gt7 = rand_obb(M, g, 0, 60, 4, 40)
+    d6 = torch.randn(M, 6, generator=g) * 0.5
+    d6[:5, 3:] = 9.0  # exercise the log(2000) clamp
+    d8 = torch.randn(M, 8, generator=g) * 0.6
+    d8[:5, 3:6] = 6.0
+    d8[5:10, 3:6] = -6.0
+    ca, cm = AABBCoder(), MidpointOffsetCoder()
+    e6, x6 = ca.encode_single(gt6, anc), ca.decode_single(d6, anc)
+    e8, x7 = cm.encode_single(gt7, anc), cm.decode_single(d8, anc)
+    hbb = R_misc.obb2hbb_3d(gt7)
+    close(OC.aabb_encode(gt6, anc), e6, 1e-6, "aabb enc"); close(OC.aabb_decode(d6, anc), x6, 1e-3, "aabb dec")
+    close(OC.midpoint_encode(gt7, anc), e8, 1e-5, "mid enc"); close(OC.midpoint_decode(d8, anc), x7, 2e-4, "mid dec")
+    close(OC.obb3d_to_hbb(gt7), hbb, 1e-6, "hbb3d")
+    save("coders", anchors=anc, gt6=gt6, gt7=gt7, d6=d6, d8=d8, enc6=e6, dec6=x6, enc8=e8, dec7=x7, hbb=hbb)
+
+
+def gen_matcher():
+    print("matcher")
+    g = torch.Generator().manual_seed(9)
+    grids = [(10, 9, 7), (5, 5, 4), (3, 3, 2), (2, 2, 1)]
+    anc = torch.cat(OA.all_anchors((40, 36, 28), grids))
+    gt = rand_obb(6, g, 6, 30, 6, 20)
+    gt[0, 3:6] = torch.tensor([8., 8., 8.]); gt[0, 6] = 0.0; gt[0, :3] = torch.tensor([16., 16., 12.])  # exact anchor hit -> ties
+    q = R_utils.batched_box_iou(R_misc.obb2hbb_3d(gt), anc, 4)
+    m = R_utils.Matcher(0.35, 0.2, allow_low_quality_matches=True)
+    idx = m(q.clone())
+    close(OB.iou_matrix_chunked(OC.obb3d_to_hbb(gt), anc, 4), q, 0, "match quality")
+    assert torch.equal(OB.match(q.clone(), 0.35, 0.2), idx)
+    save("matcher", anchors=anc, gt=gt, quality=q, matched=idx, fg=0.35, bg=0.2)
+
+
+def gen_nms():
+    print("nms")
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    for tag, n, maker in (("aabb", 400, rand_aabb), ("obb", 160, rand_obb)):
+        base = maker(n // 8, g, 8, 40, 4, 14)
+        bx = base.repeat_interleave(8, dim=0)
+        bx[:, :3] += torch.randn(n, 3, generator=g) * 1.5
+        if tag == "aabb":
+            bx[:, 3:] = bx[:, :3] + (base.repeat_interleave(8, 0)[:, 3:] - base.repeat_interleave(8, 0)[:, :3]) \
+                * (1 + 0.2 * torch.rand(n, 3, generator=g))
+        else:
+            bx[:, 6] += torch.randn(n, generator=g) * 0.2
+        sc = torch.rand(n, generator=g)
+        lv = torch.randint(0, 4, (n,), generator=g)
+        k1 = R_utils.nms(bx, sc, 0.3)
+        k2 = R_utils.batched_nms(bx, sc, lv, 0.3)
+        assert torch.equal(OB.greedy_nms(bx, sc, 0.3), k1) and torch.equal(OB.nms_per_level(bx, sc, lv, 0.3), k2)
+        out.update({f"{tag}_boxes": bx, f"{tag}_scores": sc, f"{tag}_levels": lv, f"{tag}_keep": k1, f"{tag}_keep_batched": k2})
+    two = torch.tensor([[0, 0, 0, 4, 4, 4.], [1, 1, 1, 5, 5, 5.]])
+    out["two_keep"] = R_utils.nms(two, torch.tensor([0.2, 0.9]), 0.3)  # quirk B4 edge
+    save("nms", thr=0.3, **out)
+
+
+def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
+    bb = VGG_FPN("EF", 4, True, resolution)
+    hd = R_anchor.RPNHead(256, 13, 4, rotate=rotated)
+    seeded_state(bb, 1); seeded_state(hd, 2)
+    return NeRFRegionProposalNetwork(bb, ref_anchor_gen(), hd, rpn_pre_nms_top_n_train=2500, rpn_pre_nms_top_n_test=kw.get("pre", 2500),
+                                     rpn_post_nms_top_n_train=2500, rpn_post_nms_top_n_test=kw.get("post", 2500), rpn_nms_thresh=0.3,
+                                     rpn_fg_iou_thresh=0.35, rpn_bg_iou_thresh=0.2, rpn_batch_size_per_mesh=256,
+                                     rpn_positive_fraction=0.5, rpn_score_thresh=0.0, rotated_bbox=rotated, reg_loss_type=reg_loss)
+
+
+def build_oracle(rotated, resolution, reg_loss="smooth_l1", **kw):
+    bb = ON.VGGFPN("EF", 4, resolution)
+    hd = ON.RPNHead(256, 13, 4, rotated)
+    seeded_state(bb, 1); seeded_state(hd, 2)
+    return OR.Detector(bb, OR.RPN(hd, rotated=rotated, reg_loss_type=reg_loss, pre_nms_top_n=kw.get("pre", 2500),
+                                  post_nms_top_n=kw.get("post", 2500)))
+
+
+def scene(shape, seed):
+    return torch.rand(4, *shape, generator=torch.Generator().manual_seed(seed))
+
+
+def subsample(t, n=4096):
+    f = t.reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return idx, f[idx]
+
+
+def gen_eval():
+    print("end-to-end eval")
+    cases = [("eval_aabb_s2", False, 160, [(48, 48, 48)], {}),
+             ("eval_obb_s2", True, 160, [(48, 40, 32)], {}),
+             ("eval_obb_s1_cfg0", True, 64, [(16, 16, 16)], {"pre": 600}),       # BASELINE config[0] at 16^3
+             ("eval_aabb_batch2", False, 160, [(48, 48, 32), (40, 32, 32)], {})]
+    for name, rot, res, shapes, kw in cases:
+        ref = build_ref(rot, res, **kw).eval()
+        orc = build_oracle(rot, res, **kw)
+        orc.backbone.eval()
+        xs = [scene(s, 100 + i) for i, s in enumerate(shapes)]
+        with torch.no_grad():
+            (feats, props, lvls), _, scores = ref([x.clone() for x in xs])
+            (ofeats, oprops, olvls), _, oscores, aux = orc([x.clone() for x in xs])
+        arrs = {"shapes": shapes, "rotated": rot, "resolution": res, "pre": kw.get("pre", 2500)}
+        for i, (f, of) in enumerate(zip(feats, ofeats)):
+            close(of, f, 5e-4, f"{name} feat{i}")
+            idx, val = subsample(f)
+            arrs[f"feat{i}_shape"], arrs[f"feat{i}_idx"], arrs[f"feat{i}_val"] = list(f.shape), idx, val
+        for i in range(len(xs)):
+            assert props[i].shape == oprops[i].shape, (name, props[i].shape, oprops[i].shape)
+            close(oprops[i], props[i], 2e-3, f"{name} proposals"); close(oscores[i], scores[i], 1e-5, f"{name} scores")
+            arrs[f"proposals{i}"], arrs[f"scores{i}"], arrs[f"levels{i}"] = props[i], scores[i], lvls[i]
+            print(f"   {name}[{i}]: {props[i].shape[0]} proposals, score range {scores[i].min():.4f}..{scores[i].max():.4f}")
+        save(name, **arrs)
+
+
+def gen_train():
+    print("end-to-end train")
+    cases = [("train_aabb", False, "smooth_l1", [(48, 48, 48)]),
+             ("train_obb", True, "smooth_l1", [(48, 40, 32)]),
+             ("train_obb_iou", True, "iou", [(48, 40, 32)]),
+             ("train_obb_giou", True, "giou", [(48, 40, 32)]),
+             ("train_obb_diou", True, "diou", [(48, 40, 32)]),
+             ("train_aabb_batch2", False, "smooth_l1", [(48, 48, 32), (40, 32, 32)])]
+    for name, rot, loss, shapes in cases:
+        ref = build_ref(rot, 160, loss).train()
+        orc = build_oracle(rot, 160, loss)
+        orc.backbone.train(); orc.rpn.head.train()
+        xs = [scene(s, 200 + i) for i, s in enumerate(shapes)]
+        g = torch.Generator().manual_seed(77)
+        gts = []
+        for s in shapes:
+            if rot:
+                gt = rand_obb(5, g, 8, min(s) - 8, 6, 20)
+            else:
+                gt = rand_aabb(5, g, 8, min(s) - 8, 6, 20)
+            gts.append(gt)
+        torch.manual_seed(1234)
+        _, losses, _ = ref([x.clone() for x in xs], [t.clone() for t in gts])
+        total = losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"] + 0.0 * losses["loss_rpn_box_reg_2d"]
+        total.backward()
+        torch.manual_seed(1234)
+        _, olosses, _, aux = orc([x.clone() for x in xs], [t.clone() for t in gts], training=True)
+        ototal = olosses["loss_objectness"] + 5.0 * olosses["loss_rpn_box_reg"] + 0.0 * olosses["loss_rpn_box_reg_2d"]
+        ototal.backward()
+        arrs = {"shapes": shapes, "rotated": rot, "reg_loss_type": loss, "seed": 1234}
+        for k in losses:
+            e = close(olosses[k], losses[k], 2e-5 * max(1.0, abs(losses[k].item())), f"{name} {k}")
+            arrs[k] = losses[k]
+        arrs["pos_idx"], arrs["neg_idx"] = aux["sampled"]["pos"], aux["sampled"]["neg"]
+        arrs["labels"] = torch.cat(aux["labels"]).to(torch.int8)
+        rp = dict(ref.backbone.named_parameters()); rp.update({"head." + k: v for k, v in ref.rpn.head.named_parameters()})
+        op = dict(orc.backbone.named_parameters()); op.update({"head." + k: v for k, v in orc.rpn.head.named_parameters()})
+        worst = 0.0
+        for k, p in rp.items():
+            gr, go = p.grad, op[k].grad
+            # conv biases feeding a train-mode BatchNorm have a mathematically-zero gradient (pure
+            # rounding noise ~1e-6 in both implementations), hence the absolute floor.
+            rel = max(0.0, (gr - go).abs().max().item() - 5e-6) / (gr.abs().max().item() + 1e-12)
+            worst = max(worst, rel)
+            arrs["gnorm/" + k] = gr.norm()
+            if gr.numel() <= 512:
+                arrs["grad/" + k] = gr
+            else:
+                idx, val = subsample(gr, 256)
+                arrs["gidx/" + k], arrs["gval/" + k] = idx, val
+        assert worst < 2e-3, (name, worst)
+        for i, t in enumerate(gts):
+            arrs[f"gt{i}"] = t
+        print(f"   {name}: losses", {k: round(v.item(), 6) for k, v in losses.items()}, "pos", len(arrs["pos_idx"]),
+              "worst rel grad err oracle-vs-ref", f"{worst:.2e}")
+        save(name, **arrs)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "eval", "train"]
+    for w in which:
+        globals()["gen_" + w]()
