@@ -1,0 +1,248 @@
+/*
+ * nerfrpn.h -- C ABI of libnerfrpn_hip.so: the MI355X (gfx950) kernels of the 3D RPN-over-NeRF hot path.
+ *
+ * Contract (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch/ATen types.  Every pointer is a DEVICE pointer
+ *     unless the parameter name starts with `h_` (host).  `stream` is a hipStream_t passed as void*.
+ *   - Returns 0 on success, a negative nrpn_status otherwise; the message is available from
+ *     nrpn_last_error() (thread-local).  Never aborts the process, never allocates device memory:
+ *     outputs and workspaces are supplied by the caller (sizes from the *_workspace_bytes queries).
+ *   - Asynchronous: kernels are enqueued on `stream`; no host synchronisation inside.
+ *   - Activations are channels-last  [N][X][Y][Z][C]  (the reference's (W,L,H,C) on-disk order,
+ *     reference datasets.py:55-56); C is the fastest dimension.  dtype codes: NRPN_F32, NRPN_BF16.
+ *
+ * Each group cites the reference interface it replaces (paths relative to /root/reference/nerf_rpn).
+ * The reference has exactly one native op on this path (sort_vertices); everything else replaces
+ * chains of torch ops / Python loops (SURVEY.md section 8a rows in brackets).
+ */
+#ifndef NERFRPN_H
+#define NERFRPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *nrpn_stream_t;
+
+enum nrpn_status {
+  NRPN_OK = 0,
+  NRPN_ERR_ARG = -1,     /* bad shape / null pointer / unsupported combination */
+  NRPN_ERR_LAUNCH = -2,  /* hipLaunch / hipGetLastError reported a failure     */
+  NRPN_ERR_DEVICE = -3   /* wrong architecture / no device                      */
+};
+
+enum nrpn_dtype { NRPN_F32 = 0, NRPN_BF16 = 1 };
+
+const char *nrpn_last_error(void);
+int nrpn_abi_version(void);
+/* 0 if device `ordinal` is a gfx950 part, NRPN_ERR_DEVICE otherwise. */
+int nrpn_check_device(int ordinal);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotated-IoU family.  [a16, a17, a15]
+ * nrpn_sort_vertices_f32 is the drop-in for the reference's pybind op
+ *   sort_vertices.sort_vertices_forward(vertices f32[B,N,M,2], mask bool[B,N,M], num_valid i32[B,N]) -> i32[B,N,9]
+ *   (model/rotated_iou/cuda_op/sort_vert.cpp:6-33, kernel sort_vert_kernel.cu:42-134); bn = B*N, m = M (24).
+ * The *_iou3d_* entry points fuse corners -> edge intersections -> containment -> sort -> shoelace -> z-overlap
+ *   (model/rotated_iou/oriented_iou_loss.py:6-107, box_intersection_2d.py:11-176) in registers, one lane per pair.
+ * ---------------------------------------------------------------------------------------------- */
+int nrpn_sort_vertices_f32(const float *vertices, const uint8_t *mask, const int32_t *num_valid,
+                           int32_t *idx, int64_t bn, int m, nrpn_stream_t stream);
+/* paired: b1,b2 [n,7] (x,y,z,w,h,d,theta) -> iou [n]            (cal_iou_3d, oriented_iou_loss.py:82-107) */
+int nrpn_iou3d_obb_pair_f32(const float *b1, const float *b2, float *iou, int64_t n, nrpn_stream_t stream);
+/* all pairs: a [n,w], b [m,w] -> iou [n,m]; w = 6 (AABB x1..z2) or 7 (OBB)   (box_iou_3d, model/utils.py:387-458) */
+int nrpn_iou3d_matrix_f32(const float *a, const float *b, float *iou, int64_t n, int64_t m, int box_dim,
+                          nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Greedy 3D NMS, per-level ("batched").  [a14]   (nms / batched_nms, model/utils.py:215-265)
+ *   boxes [n,box_dim] must already be ordered score-descending inside each level run; `levels` (int32 [n],
+ *   non-decreasing) restricts suppression to equal levels (nullptr = one level).  A box j is suppressed by an
+ *   earlier kept box i of the same level iff !(IoU(i,j) <= thr).  `d_count` (int32 device scalar, may be
+ *   nullptr => n_max) gives the live prefix length so no host sync is needed; entries >= *d_count get keep=0.
+ *   keep: uint8 [n_max].  workspace: nrpn_nms3d_workspace_bytes(n_max) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t nrpn_nms3d_workspace_bytes(int64_t n_max);
+int nrpn_nms3d(const float *boxes, const int32_t *levels, const int32_t *d_count, int64_t n_max, int box_dim,
+               float thr, uint8_t *keep, void *workspace, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmented top-k / sort of fp32 scores, order = (score descending, index ascending).  [a13]
+ *   (RegionProposalNetwork._get_top_n_idx, model/rpn.py:292-301; argsort in nms, utils.py:217)
+ *   For each of nseg segments [h_offsets[s], h_offsets[s+1]) writes min(k, len) winners to
+ *   out_idx[s*k ..] (int32, index relative to the start of `scores`) and out_val[s*k ..]; unused
+ *   tail slots get idx = -1, val = -inf.  k <= 16384.
+ * ---------------------------------------------------------------------------------------------- */
+int nrpn_segmented_topk_f32(const float *scores, const int64_t *h_offsets, int nseg, int k,
+                            int32_t *out_idx, float *out_val, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Anchors and box coders.  [a8, a10, a11, a12]
+ * Anchor table (device, int32 words) describes the pyramid so anchors are computed from their flat
+ * index, never stored (AnchorGenerator3D, model/anchor.py:98-174; order (x,y,z,a), stride = mesh//grid):
+ *   tab[0]=L levels, tab[1]=A anchors/cell, then per level l (8 words at 2+8l): gx,gy,gz, sx,sy,sz, first_lo, first_hi
+ *   (first = int64 flat index of the level's first anchor); base anchors (float [L][A][6], already rounded)
+ *   follow at word 2+8L, bit-cast.  nrpn_anchor_table_words(L,A) gives the word count.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t nrpn_anchor_table_words(int levels, int anchors_per_cell);
+/* anchors [count,6] for flat indices sel[0..count) (int64; nullptr => 0..count-1). */
+int nrpn_anchors_f32(const int32_t *table, const int64_t *sel, int64_t count, float *anchors, nrpn_stream_t stream);
+/* decode: deltas rows are gathered with the same index as the anchors.  coder 0 = AABB (6 deltas -> 6,
+ * AABB_coder.py:86-137), 1 = midpoint-offset (8 deltas -> 7, midpoint_offset_coder.py:160-222).
+ * deltas [T, 6|8] row-major in (x,y,z,a) anchor order; sel int64 [count] or nullptr; out [count, 6|7]. */
+int nrpn_decode_boxes_f32(const int32_t *table, const float *deltas, const int64_t *sel, int64_t count,
+                          int coder, float *boxes, nrpn_stream_t stream);
+/* encode (regression targets) for gathered pairs: gt [count, 6|7], anchors from sel -> deltas [count, 6|8]
+ * (AABB_coder.py:7-56, midpoint_offset_coder.py:106-158). */
+int nrpn_encode_boxes_f32(const int32_t *table, const float *gt, const int64_t *sel, int64_t count,
+                          int coder, float *deltas, nrpn_stream_t stream);
+
+/* the same coders on explicit (row, anchor) pairs: in [count, 6|7|8], anchors [count,6] -> out; encode != 0 selects
+ * gt -> deltas, else deltas -> boxes (BaseBBoxCoder.encode_single / decode_single). */
+int nrpn_coder_pairs_f32(const float *in, const float *anchors, int64_t count, int coder, int encode, float *out,
+                         nrpn_stream_t stream);
+/* RPN head rows [cells][ld] fp32 (columns [0,A) = logits, [A, A+A*dw) = deltas, rest padding) <-> the reference's
+ * flattened (x,y,z,a) order: logits [cells*A], deltas [cells*A, dw]  (permute_and_flatten, model/rpn.py:20-27).
+ * unflatten is the backward: d_head (f32|bf16 [cells][ld], padding zeroed) = scale2[0]*g_logits , scale2[1]*g_deltas. */
+int nrpn_head_flatten_f32(const float *head, int64_t cells, int ld, int anchors_per_cell, int dw, float *logits,
+                          float *deltas, nrpn_stream_t stream);
+int nrpn_head_unflatten(const float *g_logits, const float *g_deltas, int64_t cells, int ld, int anchors_per_cell, int dw,
+                        const float *scale2, void *d_head, int dtype, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Proposal filter (eval).  [a13]   (filter_proposals, model/rpn.py:303-370; utils.py:268-367)
+ *   In: candidates in per-level score-descending order: boxes [n, box_dim], logits [n], levels int32 [n],
+ *   cand_valid uint8 [n] (0 for empty top-k slots).  Applies sigmoid, clip-to-grid (AABB clamp / OBB
+ *   centre test that DROPS BOXES ONLY -- reference quirk B3, reproduced unless fix_obb_clip != 0),
+ *   remove_small_boxes(min_size), score >= score_thresh, and stably compacts survivors to the front of
+ *   out_boxes / out_scores / out_levels; *d_count = survivors.  All outputs sized n (n <= 16384).
+ *   workspace: nrpn_filter_workspace_bytes(n, box_dim).
+ * ---------------------------------------------------------------------------------------------- */
+size_t nrpn_filter_workspace_bytes(int64_t n, int box_dim);
+int nrpn_filter_candidates_f32(const float *boxes, const float *logits, const int32_t *levels,
+                               const uint8_t *cand_valid, int64_t n, int box_dim, const float *h_grid_size3,
+                               float min_size, float score_thresh, int fix_obb_clip, float *out_boxes,
+                               float *out_scores, int32_t *out_levels, int32_t *d_count, void *workspace,
+                               nrpn_stream_t stream);
+/* Final gather: among the first *d_count entries with keep!=0, order by (score desc, index asc), keep at most
+ * post_top_n: out_boxes [post_top_n, box_dim], out_scores, out_levels (float, as the reference returns),
+ * *d_out_count.  n <= 16384.  (batched_nms tail, utils.py:264-265; rpn.py:362-364) */
+int nrpn_select_kept_f32(const float *boxes, const float *scores, const int32_t *levels, const uint8_t *keep,
+                         const int32_t *d_count, int64_t n, int box_dim, int post_top_n, float *out_boxes,
+                         float *out_scores, float *out_levels, int32_t *d_out_count, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Target assignment (train).  [a18]   (assign_targets_to_anchors, rpn.py:240-290; Matcher, utils.py:98-211)
+ *   gt_aabb [G,6] (OBB ground truth already rectified with obb2hbb_3d, misc.py:85-93), anchors from the table
+ *   (T = total anchors).  h_ori_size3 (host, 3 floats) or nullptr: anchors whose cell starts at or beyond
+ *   ceil(ori/stride) (zero-padded region) get quality -1 and label -1 (anchor.py:124-152).
+ *   Outputs: labels f32 [T] in {1, 0, -1}; matched int32 [T] = clamp(match index, 0).
+ *   workspace: G floats (per-GT maxima), zero-initialised by the call.
+ * ---------------------------------------------------------------------------------------------- */
+int nrpn_match_anchors_f32(const int32_t *table, int64_t total_anchors, const float *gt_aabb, int num_gt,
+                           float fg_thresh, float bg_thresh, const float *h_ori_size3, float *labels,
+                           int32_t *matched, float *workspace, nrpn_stream_t stream);
+/* obb2hbb_3d: [n,7] -> [n,6] */
+int nrpn_obb_to_aabb_f32(const float *obb, float *aabb, int64_t n, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampled RPN losses with fused backward.  [a20]  (compute_loss, rpn.py:372-419)
+ *   logits [T], deltas [T,dw], targets [npos,dw] (already encoded for the sampled positives), pos/neg int64 index
+ *   lists.  loss[0] = BCE-with-logits mean over pos+neg (labels 1/0); loss[1] = smooth-L1(beta, sum over pos) /
+ *   (npos+nneg).  Writes d(loss0)/d(logits) into g_logits and d(loss1)/d(deltas) into g_deltas at the sampled rows
+ *   (caller zero-fills the rest).
+ * ---------------------------------------------------------------------------------------------- */
+int nrpn_rpn_sampled_loss_f32(const float *logits, const float *deltas, int dw, const float *targets,
+                              const int64_t *pos, int64_t npos, const int64_t *neg, int64_t nneg, float beta,
+                              float *loss2, float *g_logits, float *g_deltas, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv3d family, channels-last, implicit GEMM on MFMA.  [a3, a4, a7, a21]
+ *   (torch.nn.Conv3d inside VGG_FPN feature_extractor.py:331-358, FPN fpn.py:109-110, RPNHead anchor.py:190-198)
+ *   x [N,X,Y,Z,Cin], y [N,X,Y,Z,Cout] (k3: stride 1, pad 1; k1: stride 1, pad 0), dtype f32 or bf16 (fp32 accumulate).
+ *   Packed weights (nrpn_pack_conv_weight, from the reference layout [Cout][Cin][kx][ky][kz] fp32):
+ *     forward form  wp_fwd  [taps][rows_total][Cin]          tap = (kx*3+ky)*3+kz
+ *     dgrad form    wp_dgrad[taps][Cin][rows_total]          taps reversed, so dgrad IS nrpn_conv3d_fwd on dy with
+ *                                                            (cin, cout, wrows) := (rows_total, Cin, Cin)
+ *   rows_total >= Cout lets several reference convs share one GEMM (cls_logits + bbox_pred -> 128 rows, the
+ *   remaining rows zero); `row_offset` places this weight's rows.  `wrows` below = rows_total of the packed buffer.
+ *   flags: NRPN_CONV_BIAS (bias f32 [Cout]), NRPN_CONV_RELU, NRPN_CONV_OUT_F32 (bf16 inputs, fp32 output rows).
+ *   Cin*elemsize must be a multiple of 64 bytes.
+ * ---------------------------------------------------------------------------------------------- */
+enum { NRPN_CONV_BIAS = 1, NRPN_CONV_RELU = 2, NRPN_CONV_OUT_F32 = 4 };
+int nrpn_pack_conv_weight(const float *w_ref, int cout, int cin, int taps, int dtype, void *wp_fwd, void *wp_dgrad,
+                          int rows_total, int row_offset, nrpn_stream_t stream);
+/* packed fp32 weight gradient [taps][rows_total][Cin] -> reference layout (optionally accumulating into gw_ref) */
+int nrpn_unpack_conv_wgrad(const float *gw_packed, int cout, int cin, int taps, int rows_total, int row_offset,
+                           float *gw_ref, int accumulate, nrpn_stream_t stream);
+int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
+                    int cout, int wrows, int ksize, int dtype, int flags, nrpn_stream_t stream);
+/* wgrad: gw_packed f32 [taps][wrows][Cin] (zero-filled by the call, split-K partials are atomically added);
+ * optional gbias f32 [Cout] = column sums of dy. */
+int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
+                      int cin, int cout, int wrows, int ksize, int dtype, nrpn_stream_t stream);
+int nrpn_colsum(const void *dy, long long rows, int c, int dtype, float *out, nrpn_stream_t stream);
+/* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
+int nrpn_set_wgrad_transpose_read(int on);
+/* Stem: Conv3d(4 -> Cout, k7, pad 3, stride 1|2) on [N,X,Y,Z,4] (feature_extractor.py:336,341) as an im2col GEMM
+ * whose A operand is gathered tap by tap.  Packed stem weights: [Cout][Kpad], k = tap*4 + c, Kpad = nrpn_stem_kpad(dtype).
+ * Output grid: (X - 1)/stride + 1 per axis. */
+int nrpn_stem_kpad(int dtype);
+int nrpn_pack_stem_weight(const float *w_ref, int cout, int dtype, void *wp, nrpn_stream_t stream);
+int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *gw_ref, int accumulate, nrpn_stream_t stream);
+int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz,
+                         int cout, int stride, int dtype, int flags, nrpn_stream_t stream);
+int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
+                           int cout, int stride, int dtype, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm3d / ReLU / MaxPool3d / nearest-upsample-add, channels-last.  [a3, a4, a21]
+ *   (feature_extractor.py:337-358, fpn.py:150-155)
+ * ---------------------------------------------------------------------------------------------- */
+/* per-channel batch statistics over rows = N*X*Y*Z: mean, biased var (f32 [C]); updates running stats
+ * (momentum m, unbiased var) when running_mean != nullptr.  workspace: nrpn_bn_workspace_bytes(rows, c). */
+size_t nrpn_bn_workspace_bytes(int64_t rows, int c);
+int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, float *mean, float *var, float *running_mean,
+                  float *running_var, float momentum, void *workspace, nrpn_stream_t stream);
+/* y = relu?((x - mean) * rsqrt(var + eps) * gamma + beta) */
+int nrpn_bn_apply(const void *x, void *y, int64_t rows, int c, int dtype, const float *mean, const float *var,
+                  const float *gamma, const float *beta, float eps, int relu, nrpn_stream_t stream);
+/* backward of bn_apply(+relu) in train mode: given x (conv output), y (post-activation, for the ReLU mask) and dy,
+ * writes dx and accumulates dgamma/dbeta (f32 [C], overwritten). */
+int nrpn_bn_backward(const void *x, const void *y, const void *dy, void *dx, int64_t rows, int c, int dtype,
+                     const float *mean, const float *var, const float *gamma, float eps, int relu, float *dgamma,
+                     float *dbeta, void *workspace, nrpn_stream_t stream);
+int nrpn_relu_backward(const void *y, const void *dy, void *dx, int64_t count, int dtype, nrpn_stream_t stream);
+/* MaxPool3d(k, stride s, pad p, ceil_mode) forward writes int8 argmax offsets (window-local) for the backward. */
+int nrpn_pool_out_size(int in, int k, int s, int p, int ceil_mode);
+int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n, int gx, int gy, int gz, int c, int k, int s,
+                       int p, int ceil_mode, int dtype, nrpn_stream_t stream);
+int nrpn_maxpool3d_bwd(const void *dy, const int8_t *argmax, void *dx, int n, int gx, int gy, int gz, int c, int k,
+                       int s, int p, int ceil_mode, int dtype, nrpn_stream_t stream);
+/* fine += nearest_upsample(coarse) (legacy floor(dst*in/out) index rule, fpn.py:153-155); backward reduces. */
+int nrpn_upsample_add_fwd(void *fine, const void *coarse, int n, int fx, int fy, int fz, int cx, int cy, int cz, int c,
+                          int dtype, nrpn_stream_t stream);
+int nrpn_upsample_add_bwd(const void *dfine, void *dcoarse, int n, int fx, int fy, int fz, int cx, int cy, int cz,
+                          int c, int dtype, int accumulate, nrpn_stream_t stream);
+/* layout / dtype conversion between the reference's [N,C,X,Y,Z] f32 and channels-last f32|bf16 */
+int nrpn_ncdhw_to_ndhwc(const float *src, void *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
+int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
+int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtype, int dst_dtype, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser step on a flat fp32 arena.  [a21]  (clip_grad_norm_ + AdamW, run_rpn.py:345-349,390-395)
+ *   sumsq: f32 device scalar (zeroed by nrpn_grad_sumsq); step applies g *= min(1, max_norm/(sqrt(sumsq)+1e-6)),
+ *   then decoupled-weight-decay Adam with bias correction (torch.optim.AdamW semantics).
+ * ---------------------------------------------------------------------------------------------- */
+int nrpn_grad_sumsq(const float *grad, int64_t count, float *sumsq, nrpn_stream_t stream);
+int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count,
+                    const float *sumsq, float max_norm, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, nrpn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFRPN_H */

@@ -1,0 +1,51 @@
+// Shared host-side plumbing of libnerfrpn_hip.so (error reporting, launch checks, dtype helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/nerfrpn.h"
+
+int nrpn_fail(int code, const char *fmt, ...);
+
+#define NRPN_REQUIRE(cond, ...)                                 \
+  do {                                                          \
+    if (!(cond)) return nrpn_fail(NRPN_ERR_ARG, __VA_ARGS__);   \
+  } while (0)
+
+#define NRPN_HIP(call)                                                                          \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) return nrpn_fail(NRPN_ERR_LAUNCH, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define NRPN_LAUNCH_CHECK(name)                                                                  \
+  do {                                                                                           \
+    hipError_t e_ = hipGetLastError();                                                           \
+    if (e_ != hipSuccess) return nrpn_fail(NRPN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline hipStream_t as_stream(nrpn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// bf16 <-> f32 on raw 16-bit storage (round-to-nearest-even), usable in device code.
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+  static __device__ __forceinline__ float ld(const float *p) { return *p; }
+  static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct elem<unsigned short> {
+  static __device__ __forceinline__ float ld(const unsigned short *p) { return bf16_bits_to_f32(*p); }
+  static __device__ __forceinline__ void st(unsigned short *p, float v) { *p = f32_to_bf16_bits(v); }
+};

@@ -1,0 +1,578 @@
+// HBM-bound companions of the conv kernels (gfx950): BatchNorm3d statistics / apply / backward, ReLU backward,
+// MaxPool3d, nearest-upsample-add (FPN top-down), layout + dtype conversion, and the flat-arena AdamW step.
+// All tensors channels-last [rows = N*X*Y*Z][C]; each lane handles 4 consecutive channels (16-byte fp32 / 8-byte bf16
+// accesses, fully coalesced along C); per-channel reductions are block partials in fp32 finished in fp64.
+//
+// Replaces BatchNorm3d / ReLU / MaxPool3d / F.interpolate+add in reference feature_extractor.py:337-358, fpn.py:150-155
+// and clip_grad_norm_ + AdamW of run_rpn.py:345-349,390-395.
+#include "common.h"
+
+typedef unsigned short bf16s;
+typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+
+template <typename T> struct vec4;
+template <> struct vec4<float> {
+  static __device__ __forceinline__ f4 ld(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+  static __device__ __forceinline__ void st(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+};
+template <> struct vec4<bf16s> {
+  static __device__ __forceinline__ f4 ld(const bf16s *p) {
+    const us4 u = *reinterpret_cast<const us4 *>(p);
+    f4 v = {bf16_bits_to_f32(u[0]), bf16_bits_to_f32(u[1]), bf16_bits_to_f32(u[2]), bf16_bits_to_f32(u[3])};
+    return v;
+  }
+  static __device__ __forceinline__ void st(bf16s *p, f4 v) {
+    us4 u = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+    *reinterpret_cast<us4 *>(p) = u;
+  }
+};
+
+#define DISPATCH_T(dtype, ...)                       \
+  if ((dtype) == NRPN_F32) { typedef float T; __VA_ARGS__; } \
+  else { typedef bf16s T; __VA_ARGS__; }
+
+// =====================================================================================================================
+// per-channel reductions: slabs of 256 rows per block; thread = (4-channel group, row lane)
+// =====================================================================================================================
+constexpr int kSlab = 256;
+
+// MODE 0: (sum x, sum x^2)           MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * (y > 0 if relu)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256)
+chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, long long rows, int c,
+                    const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu, float *__restrict__ partial) {
+  __shared__ float red[2][256][4];
+  const int ct = c / 4;                       // channel groups (<= 256)
+  const int ty_n = 256 / ct;                  // row lanes
+  const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
+  const long long r0 = (long long)blockIdx.x * kSlab, r1 = min(rows, r0 + kSlab);
+  f4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+  if (ty < ty_n) {
+    f4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const f4 *>(mean + tx * 4);
+      const f4 vv = *reinterpret_cast<const f4 *>(var + tx * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) is[k] = 1.0f / sqrtf(vv[k] + eps);
+    }
+    for (long long r = r0 + ty; r < r1; r += ty_n) {
+      const f4 xv = vec4<T>::ld(x + r * c + tx * 4);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += xv[k]; s1[k] += xv[k] * xv[k]; }
+      } else {
+        f4 g = vec4<T>::ld(dy + r * c + tx * 4);
+        if (relu) {
+          const f4 yv = vec4<T>::ld(y + r * c + tx * 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += g[k]; s1[k] += g[k] * ((xv[k] - mu[k]) * is[k]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; }
+  __syncthreads();
+  if (threadIdx.x < ct) {
+    f4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    for (int q = 0; q < ty_n; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a[k] += red[0][q * ct + threadIdx.x][k]; b[k] += red[1][q * ct + threadIdx.x][k]; }
+    float *out = partial + (long long)blockIdx.x * 2 * c;
+    *reinterpret_cast<f4 *>(out + threadIdx.x * 4) = a;
+    *reinterpret_cast<f4 *>(out + c + threadIdx.x * 4) = b;
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int nblocks, long long rows, int c, float *__restrict__ mean,
+                                         float *__restrict__ var, float *__restrict__ rmean, float *__restrict__ rvar, float momentum) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblocks; ++b) { s += (double)partial[(long long)b * 2 * c + ch]; q += (double)partial[(long long)b * 2 * c + c + ch]; }
+  const double m = s / (double)rows;
+  double v = q / (double)rows - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[ch] = (float)m;
+  var[ch] = (float)v;
+  if (rmean) {
+    const double unbiased = rows > 1 ? v * (double)rows / (double)(rows - 1) : v;
+    rmean[ch] = (float)((1.0 - momentum) * (double)rmean[ch] + momentum * m);
+    rvar[ch] = (float)((1.0 - momentum) * (double)rvar[ch] + momentum * unbiased);
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblocks, int c, float *__restrict__ dbeta,
+                                       float *__restrict__ dgamma) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblocks; ++b) { s += (double)partial[(long long)b * 2 * c + ch]; q += (double)partial[(long long)b * 2 * c + c + ch]; }
+  dbeta[ch] = (float)s;
+  dgamma[ch] = (float)q;
+}
+
+extern "C" size_t nrpn_bn_workspace_bytes(int64_t rows, int c) { return (size_t)(cdiv64(rows, kSlab) * 2 * c * 4); }
+
+static int check_bn_shape(const char *who, int64_t rows, int c) {
+  if (rows <= 0 || c <= 0 || c % 4 != 0 || c > 1024 || 256 % (c / 4) != 0)
+    return nrpn_fail(NRPN_ERR_ARG, "%s: C=%d must be a multiple of 4 with C/4 dividing 256 (rows=%lld)", who, c, (long long)rows);
+  return 0;
+}
+
+extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, float *mean, float *var, float *running_mean,
+                             float *running_var, float momentum, void *workspace, nrpn_stream_t stream) {
+  if (int rc = check_bn_shape("bn_stats", rows, c)) return rc;
+  NRPN_REQUIRE(x && mean && var && workspace, "bn_stats: null pointer");
+  const int nb = (int)cdiv64(rows, kSlab);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 0>), dim3(nb), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
+                                       (const T *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0,
+                                       (float *)workspace));
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
+                     var, running_mean, running_var, momentum);
+  NRPN_LAUNCH_CHECK("bn_stats");
+  return NRPN_OK;
+}
+
+// y = relu?((x - mean) * rsqrt(var + eps) * gamma + beta)   -- grid-stride over 4-channel groups
+template <typename T>
+__global__ void bn_apply_kernel(const T *__restrict__ x, T *__restrict__ y, long long groups, int c, const float *__restrict__ mean,
+                                const float *__restrict__ var, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                int relu) {
+  const int ct = c / 4;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(g % ct) * 4;
+    const f4 xv = vec4<T>::ld(x + g * 4);
+    const f4 mu = *reinterpret_cast<const f4 *>(mean + cg), vv = *reinterpret_cast<const f4 *>(var + cg);
+    const f4 ga = *reinterpret_cast<const f4 *>(gamma + cg), be = *reinterpret_cast<const f4 *>(beta + cg);
+    f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float is = 1.0f / sqrtf(vv[k] + eps);
+      o[k] = (xv[k] - mu[k]) * is * ga[k] + be[k];
+      if (relu) o[k] = fmaxf(o[k], 0.f);
+    }
+    vec4<T>::st(y + g * 4, o);
+  }
+}
+
+static inline int ew_blocks(long long work) { long long b = (work + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+extern "C" int nrpn_bn_apply(const void *x, void *y, int64_t rows, int c, int dtype, const float *mean, const float *var,
+                             const float *gamma, const float *beta, float eps, int relu, nrpn_stream_t stream) {
+  NRPN_REQUIRE(rows > 0 && c > 0 && c % 4 == 0, "bn_apply: C=%d must be a multiple of 4", c);
+  NRPN_REQUIRE(x && y && mean && var && gamma && beta, "bn_apply: null pointer");
+  const long long groups = rows * (c / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y,
+                                       groups, c, mean, var, gamma, beta, eps, relu));
+  NRPN_LAUNCH_CHECK("bn_apply");
+  return NRPN_OK;
+}
+
+// dx = gamma * invstd * (dy' - dbeta / R - xhat * dgamma / R)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, T *__restrict__ dx,
+                                    long long groups, int c, long long rows, const float *__restrict__ mean, const float *__restrict__ var,
+                                    const float *__restrict__ gamma, float eps, int relu, const float *__restrict__ dgamma,
+                                    const float *__restrict__ dbeta) {
+  const int ct = c / 4;
+  const float invr = 1.0f / (float)rows;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(g % ct) * 4;
+    const f4 xv = vec4<T>::ld(x + g * 4);
+    f4 gv = vec4<T>::ld(dy + g * 4);
+    if (relu) {
+      const f4 yv = vec4<T>::ld(y + g * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    }
+    const f4 mu = *reinterpret_cast<const f4 *>(mean + cg), vv = *reinterpret_cast<const f4 *>(var + cg);
+    const f4 ga = *reinterpret_cast<const f4 *>(gamma + cg);
+    const f4 dg = *reinterpret_cast<const f4 *>(dgamma + cg), db = *reinterpret_cast<const f4 *>(dbeta + cg);
+    f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float is = 1.0f / sqrtf(vv[k] + eps);
+      const float xh = (xv[k] - mu[k]) * is;
+      o[k] = ga[k] * is * (gv[k] - db[k] * invr - xh * dg[k] * invr);
+    }
+    vec4<T>::st(dx + g * 4, o);
+  }
+}
+
+extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, void *dx, int64_t rows, int c, int dtype, const float *mean,
+                                const float *var, const float *gamma, float eps, int relu, float *dgamma, float *dbeta, void *workspace,
+                                nrpn_stream_t stream) {
+  if (int rc = check_bn_shape("bn_backward", rows, c)) return rc;
+  NRPN_REQUIRE(x && dy && dx && mean && var && gamma && dgamma && dbeta && workspace && (!relu || y), "bn_backward: null pointer");
+  const int nb = (int)cdiv64(rows, kSlab);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
+                                       (long long)rows, c, mean, var, eps, relu, (float *)workspace));
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, (const float *)workspace, nb, c, dbeta, dgamma);
+  const long long groups = rows * (c / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, st, (const T *)x, (const T *)y,
+                                       (const T *)dy, (T *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu,
+                                       (const float *)dgamma, (const float *)dbeta));
+  NRPN_LAUNCH_CHECK("bn_backward");
+  return NRPN_OK;
+}
+
+template <typename T>
+__global__ void relu_bwd_kernel(const T *__restrict__ y, const T *__restrict__ dy, T *__restrict__ dx, long long groups) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long long)gridDim.x * blockDim.x) {
+    const f4 yv = vec4<T>::ld(y + g * 4);
+    f4 gv = vec4<T>::ld(dy + g * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    vec4<T>::st(dx + g * 4, gv);
+  }
+}
+
+extern "C" int nrpn_relu_backward(const void *y, const void *dy, void *dx, int64_t count, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(count > 0 && count % 4 == 0, "relu_backward: count must be a positive multiple of 4");
+  NRPN_REQUIRE(y && dy && dx, "relu_backward: null pointer");
+  const long long groups = count / 4;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream), (const T *)y,
+                                       (const T *)dy, (T *)dx, groups));
+  NRPN_LAUNCH_CHECK("relu_backward");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// MaxPool3d (torch semantics: -inf padding, ceil_mode windows must start inside input+left pad, first max wins)
+// =====================================================================================================================
+static inline int pool_out(int in, int k, int s, int p, int ceil_mode) {
+  int o = ceil_mode ? (in + 2 * p - k + s - 1) / s + 1 : (in + 2 * p - k) / s + 1;
+  if (ceil_mode && (o - 1) * s >= in + p) --o;
+  return o;
+}
+extern "C" int nrpn_pool_out_size(int in, int k, int s, int p, int ceil_mode) { return pool_out(in, k, s, p, ceil_mode); }
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int8_t *__restrict__ arg, int n, int gx, int gy, int gz, int ox,
+                                   int oy, int oz, int c, int k, int s, int p) {
+  const int ct = c / 4;
+  const long long total = (long long)n * ox * oy * oz * ct;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(g % ct) * 4;
+    long long v = g / ct;
+    const int z = (int)(v % oz); v /= oz;
+    const int yy = (int)(v % oy); v /= oy;
+    const int xx = (int)(v % ox);
+    const long long b = v / ox;
+    f4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first[4] = {true, true, true, true};
+    for (int a = 0; a < k; ++a) {
+      const int ix = xx * s - p + a;
+      if ((unsigned)ix >= (unsigned)gx) continue;
+      for (int bq = 0; bq < k; ++bq) {
+        const int iy = yy * s - p + bq;
+        if ((unsigned)iy >= (unsigned)gy) continue;
+        for (int d = 0; d < k; ++d) {
+          const int iz = z * s - p + d;
+          if ((unsigned)iz >= (unsigned)gz) continue;
+          const f4 xv = vec4<T>::ld(x + ((((b * gx + ix) * gy + iy) * gz + iz) * (long long)c + cg));
+          const int code = (a * k + bq) * k + d;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (first[q] || xv[q] > best[q]) { best[q] = xv[q]; bi[q] = code; first[q] = false; }
+        }
+      }
+    }
+    const long long o = (g / ct) * (long long)c + cg;
+    vec4<T>::st(y + o, best);
+    if (arg) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) arg[o + q] = (int8_t)bi[q];
+    }
+  }
+}
+
+// gather form: every input voxel sums the dy of the windows whose argmax points at it (no atomics, deterministic)
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T *__restrict__ dy, const int8_t *__restrict__ arg, T *__restrict__ dx, int n, int gx, int gy, int gz,
+                                   int ox, int oy, int oz, int c, int k, int s, int p) {
+  const int ct = c / 4;
+  const long long total = (long long)n * gx * gy * gz * ct;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(g % ct) * 4;
+    long long v = g / ct;
+    const int z = (int)(v % gz); v /= gz;
+    const int yy = (int)(v % gy); v /= gy;
+    const int xx = (int)(v % gx);
+    const long long b = v / gx;
+    f4 acc = {0, 0, 0, 0};
+    for (int a = 0; a < k; ++a) {
+      const int tx = xx + p - a;
+      if (tx < 0 || tx % s) continue;
+      const int wx = tx / s;
+      if (wx >= ox) continue;
+      for (int bq = 0; bq < k; ++bq) {
+        const int ty = yy + p - bq;
+        if (ty < 0 || ty % s) continue;
+        const int wy = ty / s;
+        if (wy >= oy) continue;
+        for (int d = 0; d < k; ++d) {
+          const int tz = z + p - d;
+          if (tz < 0 || tz % s) continue;
+          const int wz = tz / s;
+          if (wz >= oz) continue;
+          const long long o = ((((b * ox + wx) * oy + wy) * oz + wz) * (long long)c + cg);
+          const int code = (a * k + bq) * k + d;
+          const f4 gv = vec4<T>::ld(dy + o);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += (arg[o + q] == code) ? gv[q] : 0.f;
+        }
+      }
+    }
+    vec4<T>::st(dx + (g / ct) * (long long)c + cg, acc);
+  }
+}
+
+extern "C" int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n, int gx, int gy, int gz, int c, int k, int s, int p,
+                                  int ceil_mode, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_fwd: bad sizes");
+  NRPN_REQUIRE(x && y, "maxpool_fwd: null pointer");
+  const int ox = pool_out(gx, k, s, p, ceil_mode), oy = pool_out(gy, k, s, p, ceil_mode), oz = pool_out(gz, k, s, p, ceil_mode);
+  const long long total = (long long)n * ox * oy * oz * (c / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y,
+                                       argmax, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+  NRPN_LAUNCH_CHECK("maxpool_fwd");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_maxpool3d_bwd(const void *dy, const int8_t *argmax, void *dx, int n, int gx, int gy, int gz, int c, int k, int s, int p,
+                                  int ceil_mode, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_bwd: bad sizes");
+  NRPN_REQUIRE(dy && argmax && dx, "maxpool_bwd: null pointer");
+  const int ox = pool_out(gx, k, s, p, ceil_mode), oy = pool_out(gy, k, s, p, ceil_mode), oz = pool_out(gz, k, s, p, ceil_mode);
+  const long long total = (long long)n * gx * gy * gz * (c / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)dy, argmax,
+                                       (T *)dx, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+  NRPN_LAUNCH_CHECK("maxpool_bwd");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// FPN top-down: fine += nearest(coarse), legacy index rule src = min(floor(dst * (in/out)), in-1) in fp32
+// =====================================================================================================================
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  const float scale = (float)in / (float)out;
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+template <typename T>
+__global__ void upsample_add_fwd_kernel(T *__restrict__ fine, const T *__restrict__ coarse, int n, int fx, int fy, int fz, int cx, int cy,
+                                        int cz, int c) {
+  const int ct = c / 4;
+  const long long total = (long long)n * fx * fy * fz * ct;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(g % ct) * 4;
+    long long v = g / ct;
+    const int z = (int)(v % fz); v /= fz;
+    const int y = (int)(v % fy); v /= fy;
+    const int x = (int)(v % fx);
+    const long long b = v / fx;
+    const long long src = (((b * cx + nearest_src(x, cx, fx)) * cy + nearest_src(y, cy, fy)) * cz + nearest_src(z, cz, fz)) * (long long)c + cg;
+    const long long dst = (g / ct) * (long long)c + cg;
+    f4 a = vec4<T>::ld(fine + dst);
+    const f4 bq = vec4<T>::ld(coarse + src);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += bq[k];
+    vec4<T>::st(fine + dst, a);
+  }
+}
+
+template <typename T>
+__global__ void upsample_add_bwd_kernel(const T *__restrict__ dfine, T *__restrict__ dcoarse, int n, int fx, int fy, int fz, int cx, int cy,
+                                        int cz, int c, int accumulate) {
+  const int ct = c / 4;
+  const long long total = (long long)n * cx * cy * cz * ct;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(g % ct) * 4;
+    long long v = g / ct;
+    const int z = (int)(v % cz); v /= cz;
+    const int y = (int)(v % cy); v /= cy;
+    const int x = (int)(v % cx);
+    const long long b = v / cx;
+    // candidate fine indices around x * fx / cx
+    const int x0 = max(0, (int)((long long)x * fx / cx) - 1), x1 = min(fx - 1, (int)((long long)(x + 1) * fx / cx) + 1);
+    const int y0 = max(0, (int)((long long)y * fy / cy) - 1), y1 = min(fy - 1, (int)((long long)(y + 1) * fy / cy) + 1);
+    const int z0 = max(0, (int)((long long)z * fz / cz) - 1), z1 = min(fz - 1, (int)((long long)(z + 1) * fz / cz) + 1);
+    f4 acc = {0, 0, 0, 0};
+    for (int a = x0; a <= x1; ++a) {
+      if (nearest_src(a, cx, fx) != x) continue;
+      for (int bq = y0; bq <= y1; ++bq) {
+        if (nearest_src(bq, cy, fy) != y) continue;
+        for (int d = z0; d <= z1; ++d) {
+          if (nearest_src(d, cz, fz) != z) continue;
+          const f4 gv = vec4<T>::ld(dfine + ((((b * fx + a) * fy + bq) * fz + d) * (long long)c + cg));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += gv[k];
+        }
+      }
+    }
+    const long long dst = (g / ct) * (long long)c + cg;
+    if (accumulate) {
+      const f4 old = vec4<T>::ld(dcoarse + dst);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += old[k];
+    }
+    vec4<T>::st(dcoarse + dst, acc);
+  }
+}
+
+extern "C" int nrpn_upsample_add_fwd(void *fine, const void *coarse, int n, int fx, int fy, int fz, int cx, int cy, int cz, int c, int dtype,
+                                     nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && fx > 0 && fy > 0 && fz > 0 && cx > 0 && cy > 0 && cz > 0 && c % 4 == 0, "upsample_add_fwd: bad sizes");
+  NRPN_REQUIRE(fine && coarse, "upsample_add_fwd: null pointer");
+  const long long total = (long long)n * fx * fy * fz * (c / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_fwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (T *)fine,
+                                       (const T *)coarse, n, fx, fy, fz, cx, cy, cz, c));
+  NRPN_LAUNCH_CHECK("upsample_add_fwd");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_upsample_add_bwd(const void *dfine, void *dcoarse, int n, int fx, int fy, int fz, int cx, int cy, int cz, int c, int dtype,
+                                     int accumulate, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && fx > 0 && fy > 0 && fz > 0 && cx > 0 && cy > 0 && cz > 0 && c % 4 == 0, "upsample_add_bwd: bad sizes");
+  NRPN_REQUIRE(dfine && dcoarse, "upsample_add_bwd: null pointer");
+  const long long total = (long long)n * cx * cy * cz * (c / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_bwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)dfine,
+                                       (T *)dcoarse, n, fx, fy, fz, cx, cy, cz, c, accumulate));
+  NRPN_LAUNCH_CHECK("upsample_add_bwd");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// layout / dtype conversion: [N][C][V] fp32  <->  [N][V][C] T   (32x32 LDS tile transpose)
+// =====================================================================================================================
+template <typename T, bool TO_CL>
+__global__ void transpose_kernel(const void *__restrict__ src, void *__restrict__ dst, int c, long long voxels) {
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.z;
+  const long long v0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // (32, 8)
+  if (TO_CL) {
+    const float *s = reinterpret_cast<const float *>(src) + b * c * voxels;
+    T *d = reinterpret_cast<T *>(dst) + b * c * voxels;
+    for (int i = ty; i < 32; i += 8)
+      if (c0 + i < c && v0 + tx < voxels) tile[i][tx] = s[(long long)(c0 + i) * voxels + v0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+      if (v0 + i < voxels && c0 + tx < c) elem<T>::st(d + (v0 + i) * c + c0 + tx, tile[tx][i]);
+  } else {
+    const T *s = reinterpret_cast<const T *>(src) + b * c * voxels;
+    float *d = reinterpret_cast<float *>(dst) + b * c * voxels;
+    for (int i = ty; i < 32; i += 8)
+      if (v0 + i < voxels && c0 + tx < c) tile[i][tx] = elem<T>::ld(s + (v0 + i) * c + c0 + tx);
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+      if (c0 + i < c && v0 + tx < voxels) d[(long long)(c0 + i) * voxels + v0 + tx] = tile[tx][i];
+  }
+}
+
+extern "C" int nrpn_ncdhw_to_ndhwc(const float *src, void *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && dst && n > 0 && c > 0 && voxels > 0 && n < 65536, "ncdhw_to_ndhwc: bad args");
+  dim3 grid((unsigned)cdiv64(voxels, 32), (unsigned)((c + 31) / 32), (unsigned)n);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_kernel<T, true>), grid, dim3(32, 8), 0, as_stream(stream), (const void *)src, dst, c,
+                                       (long long)voxels));
+  NRPN_LAUNCH_CHECK("ncdhw_to_ndhwc");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && dst && n > 0 && c > 0 && voxels > 0 && n < 65536, "ndhwc_to_ncdhw: bad args");
+  dim3 grid((unsigned)cdiv64(voxels, 32), (unsigned)((c + 31) / 32), (unsigned)n);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_kernel<T, false>), grid, dim3(32, 8), 0, as_stream(stream), src, (void *)dst, c,
+                                       (long long)voxels));
+  NRPN_LAUNCH_CHECK("ndhwc_to_ncdhw");
+  return NRPN_OK;
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S *__restrict__ s, D *__restrict__ d, long long count) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+    elem<D>::st(d + i, elem<S>::ld(s + i));
+}
+
+extern "C" int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtype, int dst_dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && dst && count > 0, "cast: bad args");
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(ew_blocks(count));
+  if (src_dtype == NRPN_F32 && dst_dtype == NRPN_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16s>), grid, dim3(256), 0, st, (const float *)src, (bf16s *)dst, (long long)count);
+  else if (src_dtype == NRPN_BF16 && dst_dtype == NRPN_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16s, float>), grid, dim3(256), 0, st, (const bf16s *)src, (float *)dst, (long long)count);
+  else if (src_dtype == NRPN_F32 && dst_dtype == NRPN_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), grid, dim3(256), 0, st, (const float *)src, (float *)dst, (long long)count);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16s, bf16s>), grid, dim3(256), 0, st, (const bf16s *)src, (bf16s *)dst, (long long)count);
+  NRPN_LAUNCH_CHECK("cast");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// optimiser on the flat fp32 arena
+// =====================================================================================================================
+__global__ void sumsq_kernel(const float *__restrict__ g, long long count, float *__restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+extern "C" int nrpn_grad_sumsq(const float *grad, int64_t count, float *sumsq, nrpn_stream_t stream) {
+  NRPN_REQUIRE(grad && sumsq && count > 0, "grad_sumsq: bad args");
+  hipStream_t st = as_stream(stream);
+  NRPN_HIP(hipMemsetAsync(sumsq, 0, 4, st));
+  int blocks = ew_blocks(count);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grad, (long long)count, sumsq);
+  NRPN_LAUNCH_CHECK("grad_sumsq");
+  return NRPN_OK;
+}
+
+__global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long long count,
+                             const float *__restrict__ sumsq, float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
+                             float bc2_sqrt) {
+  float coef = 1.0f;
+  if (sumsq && max_norm > 0.f) {
+    const float norm = sqrtf(*sumsq);
+    coef = fminf(1.0f, max_norm / (norm + 1e-6f));
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+
+extern "C" int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count, const float *sumsq,
+                               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               nrpn_stream_t stream) {
+  NRPN_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, "adamw_step: bad args");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, (long long)count,
+                     sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  NRPN_LAUNCH_CHECK("adamw_step");
+  return NRPN_OK;
+}

@@ -1,0 +1,926 @@
+// RPN post-processing and target-assignment kernels (gfx950): rotated IoU, bitmask 3D NMS, segmented top-k,
+// anchor/coder kernels, proposal filter, matcher, sampled losses.  Rows a8-a20 of SURVEY.md section 8a.
+// These stages are scan/sort/IoU-type (HBM- or latency-bound), not GEMMs: one lane per box (pair), wave-wide
+// ballots/shuffles for reductions, LDS for the per-workgroup sort and the NMS row blocks.
+#include "geometry.cuh"
+
+#include <cfloat>
+#include <cstring>
+
+thread_local char g_nrpn_err[512] = "";
+
+int nrpn_fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_nrpn_err, sizeof(g_nrpn_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char *nrpn_last_error(void) { return g_nrpn_err; }
+extern "C" int nrpn_abi_version(void) { return 1; }
+
+extern "C" int nrpn_check_device(int ordinal) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, ordinal) != hipSuccess) return nrpn_fail(NRPN_ERR_DEVICE, "no HIP device %d", ordinal);
+  if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+    return nrpn_fail(NRPN_ERR_DEVICE, "device %d is %s, this library is built for gfx950 only", ordinal, p.gcnArchName);
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// sort_vertices drop-in (one lane per polygon; the reference launches <<<B, pow2<=512>>> with a per-thread stride loop,
+// i.e. a single block when B == 1 -- here the grid is flat over B*N).
+// =====================================================================================================================
+__global__ void sort_vertices_kernel(const float *__restrict__ v, const uint8_t *__restrict__ msk,
+                                     const int32_t *__restrict__ num_valid, int32_t *__restrict__ idx, int64_t bn, int m) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bn) return;
+  v += i * m * 2;
+  msk += i * m;
+  int32_t *out = idx + i * 9;
+  int nv = num_valid[i];
+  int pad = m - 1;
+  for (int j = 8; j < m; ++j)
+    if (!msk[j]) { pad = j; break; }
+  if (nv < 3) {
+    for (int j = 0; j < 9; ++j) out[j] = pad;
+    return;
+  }
+  if (nv > 8) nv = 8;
+  int loc[9];
+  float px = 0.f, py = 0.f;
+  for (int j = 0; j < nv; ++j) {
+    float bx = 1.0f, by = (float)(-1e-8);
+    int take = 0;
+    for (int k = 0; k < m; ++k) {
+      if (!msk[k]) continue;
+      const float x = v[2 * k], y = v[2 * k + 1];
+      bool c = geo::vert_before(x, y, bx, by);
+      if (j > 0) c = c && geo::vert_before(px, py, x, y);
+      if (c) { bx = x; by = y; take = k; }
+    }
+    loc[j] = take;
+    px = v[2 * take];
+    py = v[2 * take + 1];
+  }
+  loc[nv] = loc[0];
+  for (int j = nv + 1; j < 9; ++j) loc[j] = pad;
+  if (nv == 8) {
+    int dup = 0;
+    for (int j = 0; j < 4; ++j)
+      for (int k = 4; k < 8; ++k) dup += (loc[k] == loc[j]);
+    if (dup == 4) {
+      loc[4] = loc[0];
+      for (int j = 5; j < 9; ++j) loc[j] = pad;
+    }
+  }
+  for (int j = 0; j < 9; ++j) out[j] = loc[j];
+}
+
+extern "C" int nrpn_sort_vertices_f32(const float *vertices, const uint8_t *mask, const int32_t *num_valid, int32_t *idx,
+                                      int64_t bn, int m, nrpn_stream_t stream) {
+  NRPN_REQUIRE(bn >= 0 && m >= 9 && m <= 64, "sort_vertices: bad sizes bn=%lld m=%d", (long long)bn, m);
+  if (bn == 0) return NRPN_OK;
+  NRPN_REQUIRE(vertices && mask && num_valid && idx, "sort_vertices: null pointer");
+  hipLaunchKernelGGL(sort_vertices_kernel, dim3((unsigned)cdiv64(bn, 128)), dim3(128), 0, as_stream(stream), vertices, mask,
+                     num_valid, idx, bn, m);
+  NRPN_LAUNCH_CHECK("sort_vertices");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// IoU: paired and all-pairs
+// =====================================================================================================================
+__global__ void iou_pair_obb_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[7], q[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { p[k] = a[i * 7 + k]; q[k] = b[i * 7 + k]; }
+  out[i] = geo::iou3d_obb(p, q);
+}
+
+template <int W>
+__global__ void iou_matrix_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int64_t n,
+                                  int64_t m) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j >= m) return;
+  float p[W], q[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) { p[k] = a[i * W + k]; q[k] = b[j * W + k]; }
+  out[i * m + j] = geo::iou3d<W>(p, q);
+}
+
+extern "C" int nrpn_iou3d_obb_pair_f32(const float *b1, const float *b2, float *iou, int64_t n, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n >= 0, "iou pair: n<0");
+  if (n == 0) return NRPN_OK;
+  NRPN_REQUIRE(b1 && b2 && iou, "iou pair: null pointer");
+  hipLaunchKernelGGL(iou_pair_obb_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(64), 0, as_stream(stream), b1, b2, iou, n);
+  NRPN_LAUNCH_CHECK("iou_pair_obb");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_iou3d_matrix_f32(const float *a, const float *b, float *iou, int64_t n, int64_t m, int box_dim,
+                                     nrpn_stream_t stream) {
+  NRPN_REQUIRE(box_dim == 6 || box_dim == 7, "iou matrix: box_dim must be 6 or 7 (got %d)", box_dim);
+  NRPN_REQUIRE(n >= 0 && m >= 0 && n < 65536, "iou matrix: bad sizes");
+  if (n == 0 || m == 0) return NRPN_OK;
+  NRPN_REQUIRE(a && b && iou, "iou matrix: null pointer");
+  dim3 grid((unsigned)cdiv64(m, 64), (unsigned)n);
+  if (box_dim == 6)
+    hipLaunchKernelGGL(iou_matrix_kernel<6>, grid, dim3(64), 0, as_stream(stream), a, b, iou, n, m);
+  else
+    hipLaunchKernelGGL(iou_matrix_kernel<7>, grid, dim3(64), 0, as_stream(stream), a, b, iou, n, m);
+  NRPN_LAUNCH_CHECK("iou_matrix");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// Bitmask NMS.  Pass 1: 64x64 tiles of the (upper-triangular) suppression matrix, one lane per row, the 64 column
+// boxes staged in LDS.  Pass 2: one workgroup per level walks its rows in blocks of 64; the block's mask rows are
+// pulled into LDS with one coalesced burst, then wave 0 resolves the 64 sequential decisions from LDS.
+// =====================================================================================================================
+constexpr int kMaxNms = 16384;
+constexpr int kNmsLevels = 64;
+
+template <int W>
+__global__ void nms_mask_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ levels,
+                                const int32_t *__restrict__ d_count, int n_max, float thr, unsigned long long *__restrict__ mask,
+                                int words) {
+  const int n = d_count ? min(*d_count, n_max) : n_max;
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+  __shared__ float cbox[64][W + 1];
+  __shared__ int clev[64];
+  const int t = threadIdx.x;
+  const int c = cb * 64 + t;
+  if (c < n) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) cbox[t][k] = boxes[(int64_t)c * W + k];
+    clev[t] = levels ? levels[c] : 0;
+  }
+  __syncthreads();
+  const int r = rb * 64 + t;
+  if (r >= n) return;
+  float me[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) me[k] = boxes[(int64_t)r * W + k];
+  const int mylev = levels ? levels[r] : 0;
+  const int cend = min(64, n - cb * 64);
+  unsigned long long bits = 0ull;
+  for (int j = 0; j < cend; ++j) {
+    const int col = cb * 64 + j;
+    if (col > r && clev[j] == mylev) {
+      float other[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) other[k] = cbox[j][k];
+      const float v = geo::iou3d<W>(me, other);
+      if (!(v <= thr)) bits |= (1ull << j);
+    }
+  }
+  mask[(int64_t)r * words + cb] = bits;
+}
+
+__global__ void __launch_bounds__(256)
+nms_scan_kernel(const int32_t *__restrict__ levels, const int32_t *__restrict__ d_count, int n_max,
+                const unsigned long long *__restrict__ mask, int words, uint8_t *__restrict__ keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+  const int n = d_count ? min(*d_count, n_max) : n_max;
+  const int lev = blockIdx.x;
+  // [s, e): rows whose level == lev (levels is non-decreasing); without levels block 0 owns everything
+  int s = 0, e = 0;
+  if (!levels) {
+    if (lev != 0) return;
+    e = n;
+  } else {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (levels[mid] < lev) lo = mid + 1; else hi = mid; }
+    s = lo;
+    hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (levels[mid] <= lev) lo = mid + 1; else hi = mid; }
+    e = lo;
+  }
+  if (s >= e) return;
+  const int w0 = s >> 6, w1 = (e - 1) >> 6, nw = w1 - w0 + 1;
+  volatile unsigned long long *removed = lds64;  // [nw]
+  unsigned long long *rows = lds64 + nw;        // [64][nw]
+  const int tid = threadIdx.x;
+  for (int w = tid; w < nw; w += blockDim.x) removed[w] = 0ull;
+  __syncthreads();
+  for (int b0 = s & ~63; b0 < e; b0 += 64) {
+    const int bw = b0 >> 6;  // word index of this row block; only columns >= bw matter
+    for (int q = tid; q < 64 * nw; q += blockDim.x) {
+      const int rr = q / nw, w = q - rr * nw;
+      const int row = b0 + rr;
+      unsigned long long v = 0ull;
+      if (row >= s && row < e && (w0 + w) >= bw) v = mask[(int64_t)row * words + (w0 + w)];
+      rows[q] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      for (int rr = 0; rr < 64; ++rr) {
+        const int row = b0 + rr;
+        if (row < s || row >= e) continue;
+        const unsigned long long word = removed[(row >> 6) - w0];
+        const bool dead = (word >> (row & 63)) & 1ull;
+        if (!dead) {
+          if (tid == 0) keep[row] = 1;
+          for (int w = tid; w < nw; w += 64) removed[w] |= rows[rr * nw + w];
+        }
+        // the same wave wrote `removed`; LDS ops of one wave complete in order
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t nrpn_nms3d_workspace_bytes(int64_t n_max) {
+  if (n_max <= 0) return 0;
+  const int64_t words = (n_max + 63) / 64;
+  return (size_t)(n_max * words * 8);
+}
+
+extern "C" int nrpn_nms3d(const float *boxes, const int32_t *levels, const int32_t *d_count, int64_t n_max, int box_dim, float thr,
+                          uint8_t *keep, void *workspace, nrpn_stream_t stream) {
+  NRPN_REQUIRE(box_dim == 6 || box_dim == 7, "nms3d: box_dim must be 6 or 7 (got %d)", box_dim);
+  NRPN_REQUIRE(n_max >= 0 && n_max <= kMaxNms, "nms3d: n_max=%lld outside [0,%d]", (long long)n_max, kMaxNms);
+  if (n_max == 0) return NRPN_OK;
+  NRPN_REQUIRE(boxes && keep && workspace, "nms3d: null pointer");
+  const int words = (int)((n_max + 63) / 64);
+  hipStream_t st = as_stream(stream);
+  NRPN_HIP(hipMemsetAsync(keep, 0, (size_t)n_max, st));
+  dim3 grid(words, words);
+  auto *mask = reinterpret_cast<unsigned long long *>(workspace);
+  if (box_dim == 6)
+    hipLaunchKernelGGL(nms_mask_kernel<6>, grid, dim3(64), 0, st, boxes, levels, d_count, (int)n_max, thr, mask, words);
+  else
+    hipLaunchKernelGGL(nms_mask_kernel<7>, grid, dim3(64), 0, st, boxes, levels, d_count, (int)n_max, thr, mask, words);
+  NRPN_LAUNCH_CHECK("nms_mask");
+  const size_t lds = (size_t)words * 65 * 8;  // worst case: one level spans every word
+  static bool attr_done = false;
+  if (!attr_done) {
+    NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)((kMaxNms / 64) * 65 * 8)));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(levels ? kNmsLevels : 1), dim3(256), lds, st, levels, d_count, (int)n_max, mask, words,
+                     keep);
+  NRPN_LAUNCH_CHECK("nms_scan");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// Segmented top-k: one 1024-thread workgroup per segment.  3-pass radix select on the order-preserving key (LDS
+// histograms), collection of the winners, then an LDS bitonic sort of (key, ~index) so the output order is
+// (score desc, index asc) -- deterministic, unlike torch.topk's unspecified tie order.
+// =====================================================================================================================
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+constexpr int kTopkThreads = 1024;
+
+// exclusive scan of one value per thread (blockDim == 1024) through LDS scratch[1024]; returns (exclusive, total)
+__device__ __forceinline__ int block_excl_scan(int v, int *scratch, int *total) {
+  const int t = threadIdx.x;
+  scratch[t] = v;
+  __syncthreads();
+  for (int off = 1; off < kTopkThreads; off <<= 1) {
+    int add = (t >= off) ? scratch[t - off] : 0;
+    __syncthreads();
+    scratch[t] += add;
+    __syncthreads();
+  }
+  const int incl = scratch[t];
+  *total = scratch[kTopkThreads - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long *a, int P) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = a[i], y = a[ixj];
+          const bool desc = ((i & k) == 0);
+          if (desc ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct TopkSeg { long long begin, end; };
+
+__global__ void __launch_bounds__(kTopkThreads)
+topk_kernel(const float *__restrict__ scores, long long seg_begin, long long seg_end, int k, int P, int32_t *__restrict__ out_idx,
+            float *__restrict__ out_val) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+  unsigned long long *items = lds64;                            // [P]
+  int *hist = reinterpret_cast<int *>(lds64 + P);               // [2048]
+  int *scratch = hist + 2048;                                   // [1024]
+  __shared__ int sh_digit, sh_need, sh_cnt;
+  const int t = threadIdx.x;
+  const long long n = seg_end - seg_begin;
+  const float *s = scores + seg_begin;
+  const int kk = (int)min((long long)k, n);
+  for (int i = t; i < P; i += kTopkThreads) items[i] = 0ull;
+  if (t == 0) sh_cnt = 0;
+  __syncthreads();
+  if (n <= k) {
+    for (long long i = t; i < n; i += kTopkThreads)
+      items[i] = ((unsigned long long)f2key(s[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    __syncthreads();
+  } else {
+    unsigned prefix = 0, pmask = 0;
+    int need = k;
+    const int shifts[3] = {21, 10, 0};
+    const int bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+      const int nb = 1 << bits[pass];
+      for (int i = t; i < 2048; i += kTopkThreads) hist[i] = 0;
+      __syncthreads();
+      for (long long i = t; i < n; i += kTopkThreads) {
+        const unsigned key = f2key(s[i]);
+        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1);
+      }
+      __syncthreads();
+      // suffix counts: thread t owns bins 2t, 2t+1 (nb <= 2048)
+      const int b0 = 2 * t, b1 = 2 * t + 1;
+      const int c0 = (b0 < nb) ? hist[b0] : 0, c1 = (b1 < nb) ? hist[b1] : 0;
+      int tot;
+      const int excl = block_excl_scan(c0 + c1, scratch, &tot);   // elements in bins < 2t
+      const int above1 = tot - excl - c0 - c1;                     // elements in bins > b1
+      const int above0 = above1 + c1;                              // elements in bins > b0
+      if (b1 < nb && above1 < need && need <= above1 + c1) { sh_digit = b1; sh_need = need - above1; }
+      if (b0 < nb && above0 < need && need <= above0 + c0) { sh_digit = b0; sh_need = need - above0; }
+      __syncthreads();
+      prefix |= ((unsigned)sh_digit) << shifts[pass];
+      pmask |= ((unsigned)(nb - 1)) << shifts[pass];
+      need = sh_need;
+      __syncthreads();
+    }
+    const unsigned T = prefix;   // k-th largest key; take every key > T and `need` of the keys == T
+    // keys > T
+    for (long long i = t; i < n; i += kTopkThreads) {
+      const unsigned key = f2key(s[i]);
+      if (key > T) {
+        const int slot = atomicAdd(&sh_cnt, 1);
+        items[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+      }
+    }
+    __syncthreads();
+    const int base = sh_cnt;  // == k - need
+    // keys == T: the `need` smallest indices, found with a contiguous-range ordered pass
+    const long long chunk = (n + kTopkThreads - 1) / kTopkThreads;
+    const long long lo = min(n, (long long)t * chunk), hi = min(n, lo + chunk);
+    int mine = 0;
+    for (long long i = lo; i < hi; ++i) mine += (f2key(s[i]) == T) ? 1 : 0;
+    int tot;
+    int rank = block_excl_scan(mine, scratch, &tot);
+    for (long long i = lo; i < hi && rank < need; ++i) {
+      if (f2key(s[i]) == T) {
+        items[base + rank] = ((unsigned long long)T << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        ++rank;
+      }
+    }
+    __syncthreads();
+  }
+  bitonic_sort_desc(items, P);
+  for (int i = t; i < k; i += kTopkThreads) {
+    if (i < kk) {
+      const unsigned long long it = items[i];
+      out_idx[i] = (int32_t)(seg_begin + (long long)(0xFFFFFFFFu - (unsigned)(it & 0xFFFFFFFFull)));
+      out_val[i] = key2f((unsigned)(it >> 32));
+    } else {
+      out_idx[i] = -1;
+      out_val[i] = -INFINITY;
+    }
+  }
+}
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" int nrpn_segmented_topk_f32(const float *scores, const int64_t *h_offsets, int nseg, int k, int32_t *out_idx,
+                                       float *out_val, nrpn_stream_t stream) {
+  NRPN_REQUIRE(nseg >= 0 && k >= 1 && k <= 16384, "topk: bad nseg=%d k=%d", nseg, k);
+  if (nseg == 0) return NRPN_OK;
+  NRPN_REQUIRE(scores && h_offsets && out_idx && out_val, "topk: null pointer");
+  const int P = next_pow2(k);
+  const size_t lds = (size_t)P * 8 + 2048 * 4 + 1024 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 16384 * 8 + 2048 * 4 + 1024 * 4));
+    attr_done = true;
+  }
+  for (int s = 0; s < nseg; ++s) {
+    NRPN_REQUIRE(h_offsets[s + 1] >= h_offsets[s] && h_offsets[s + 1] < (1ll << 31), "topk: bad segment %d", s);
+    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), lds, as_stream(stream), scores, (long long)h_offsets[s],
+                       (long long)h_offsets[s + 1], k, P, out_idx + (int64_t)s * k, out_val + (int64_t)s * k);
+  }
+  NRPN_LAUNCH_CHECK("topk");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// anchors / coders
+// =====================================================================================================================
+extern "C" int64_t nrpn_anchor_table_words(int levels, int anchors_per_cell) {
+  return 2 + 8ll * levels + 6ll * levels * anchors_per_cell;
+}
+
+__global__ void anchors_kernel(const int32_t *__restrict__ tab, const int64_t *__restrict__ sel, int64_t count,
+                               float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const geo::AnchorCell c = geo::anchor_at(tab, sel ? sel[i] : i);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[i * 6 + k] = c.box[k];
+}
+
+template <int CODER>
+__global__ void decode_kernel(const int32_t *__restrict__ tab, const float *__restrict__ deltas, const int64_t *__restrict__ sel,
+                              int64_t count, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t f = sel ? sel[i] : i;
+  constexpr int DW = CODER ? 8 : 6, BW = CODER ? 7 : 6;
+  float o[BW];
+  if (f < 0) {
+#pragma unroll
+    for (int k = 0; k < BW; ++k) out[i * BW + k] = 0.f;
+    return;
+  }
+  const geo::AnchorCell c = geo::anchor_at(tab, f);
+  float d[DW];
+#pragma unroll
+  for (int k = 0; k < DW; ++k) d[k] = deltas[f * DW + k];
+  if (CODER) geo::decode_midpoint(d, c.box, o);
+  else geo::decode_aabb(d, c.box, o);
+#pragma unroll
+  for (int k = 0; k < BW; ++k) out[i * BW + k] = o[k];
+}
+
+template <int CODER>
+__global__ void encode_kernel(const int32_t *__restrict__ tab, const float *__restrict__ gt, const int64_t *__restrict__ sel,
+                              int64_t count, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  constexpr int DW = CODER ? 8 : 6, BW = CODER ? 7 : 6;
+  const geo::AnchorCell c = geo::anchor_at(tab, sel ? sel[i] : i);
+  float g[BW], o[DW];
+#pragma unroll
+  for (int k = 0; k < BW; ++k) g[k] = gt[i * BW + k];
+  if (CODER) geo::encode_midpoint(g, c.box, o);
+  else geo::encode_aabb(g, c.box, o);
+#pragma unroll
+  for (int k = 0; k < DW; ++k) out[i * DW + k] = o[k];
+}
+
+__global__ void obb_to_aabb_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float o[7], r[6];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) o[k] = in[i * 7 + k];
+  geo::obb_to_aabb(o, r);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[i * 6 + k] = r[k];
+}
+
+extern "C" int nrpn_anchors_f32(const int32_t *table, const int64_t *sel, int64_t count, float *anchors, nrpn_stream_t stream) {
+  NRPN_REQUIRE(count >= 0, "anchors: count<0");
+  if (count == 0) return NRPN_OK;
+  NRPN_REQUIRE(table && anchors, "anchors: null pointer");
+  hipLaunchKernelGGL(anchors_kernel, dim3((unsigned)cdiv64(count, 256)), dim3(256), 0, as_stream(stream), table, sel, count, anchors);
+  NRPN_LAUNCH_CHECK("anchors");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_decode_boxes_f32(const int32_t *table, const float *deltas, const int64_t *sel, int64_t count, int coder,
+                                     float *boxes, nrpn_stream_t stream) {
+  NRPN_REQUIRE(coder == 0 || coder == 1, "decode: coder must be 0 (AABB) or 1 (midpoint), got %d", coder);
+  NRPN_REQUIRE(count >= 0, "decode: count<0");
+  if (count == 0) return NRPN_OK;
+  NRPN_REQUIRE(table && deltas && boxes, "decode: null pointer");
+  dim3 grid((unsigned)cdiv64(count, 256));
+  if (coder == 0) hipLaunchKernelGGL(decode_kernel<0>, grid, dim3(256), 0, as_stream(stream), table, deltas, sel, count, boxes);
+  else hipLaunchKernelGGL(decode_kernel<1>, grid, dim3(256), 0, as_stream(stream), table, deltas, sel, count, boxes);
+  NRPN_LAUNCH_CHECK("decode");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_encode_boxes_f32(const int32_t *table, const float *gt, const int64_t *sel, int64_t count, int coder,
+                                     float *deltas, nrpn_stream_t stream) {
+  NRPN_REQUIRE(coder == 0 || coder == 1, "encode: coder must be 0 (AABB) or 1 (midpoint), got %d", coder);
+  NRPN_REQUIRE(count >= 0, "encode: count<0");
+  if (count == 0) return NRPN_OK;
+  NRPN_REQUIRE(table && gt && deltas, "encode: null pointer");
+  dim3 grid((unsigned)cdiv64(count, 256));
+  if (coder == 0) hipLaunchKernelGGL(encode_kernel<0>, grid, dim3(256), 0, as_stream(stream), table, gt, sel, count, deltas);
+  else hipLaunchKernelGGL(encode_kernel<1>, grid, dim3(256), 0, as_stream(stream), table, gt, sel, count, deltas);
+  NRPN_LAUNCH_CHECK("encode");
+  return NRPN_OK;
+}
+
+template <int CODER, bool ENC>
+__global__ void coder_pairs_kernel(const float *__restrict__ a, const float *__restrict__ anchors, int64_t count, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  constexpr int DW = CODER ? 8 : 6, BW = CODER ? 7 : 6;
+  constexpr int IW = ENC ? BW : DW, OW = ENC ? DW : BW;
+  float in[IW], an[6], o[OW];
+#pragma unroll
+  for (int k = 0; k < IW; ++k) in[k] = a[i * IW + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) an[k] = anchors[i * 6 + k];
+  if (ENC) { if (CODER) geo::encode_midpoint(in, an, o); else geo::encode_aabb(in, an, o); }
+  else { if (CODER) geo::decode_midpoint(in, an, o); else geo::decode_aabb(in, an, o); }
+#pragma unroll
+  for (int k = 0; k < OW; ++k) out[i * OW + k] = o[k];
+}
+
+extern "C" int nrpn_coder_pairs_f32(const float *in, const float *anchors, int64_t count, int coder, int encode, float *out,
+                                    nrpn_stream_t stream) {
+  NRPN_REQUIRE(coder == 0 || coder == 1, "coder_pairs: coder must be 0 or 1 (got %d)", coder);
+  NRPN_REQUIRE(count >= 0, "coder_pairs: count<0");
+  if (count == 0) return NRPN_OK;
+  NRPN_REQUIRE(in && anchors && out, "coder_pairs: null pointer");
+  dim3 grid((unsigned)cdiv64(count, 256));
+  hipStream_t st = as_stream(stream);
+  if (coder == 0 && !encode) hipLaunchKernelGGL((coder_pairs_kernel<0, false>), grid, dim3(256), 0, st, in, anchors, count, out);
+  else if (coder == 0) hipLaunchKernelGGL((coder_pairs_kernel<0, true>), grid, dim3(256), 0, st, in, anchors, count, out);
+  else if (!encode) hipLaunchKernelGGL((coder_pairs_kernel<1, false>), grid, dim3(256), 0, st, in, anchors, count, out);
+  else hipLaunchKernelGGL((coder_pairs_kernel<1, true>), grid, dim3(256), 0, st, in, anchors, count, out);
+  NRPN_LAUNCH_CHECK("coder_pairs");
+  return NRPN_OK;
+}
+
+// head output rows [cells][ld] (fp32; columns [0,A) logits, [A, A + A*dw) deltas) <-> flat per-scene logits [T], deltas [T,dw]
+template <typename T, bool FWD>
+__global__ void head_flatten_kernel(void *__restrict__ head, int64_t cells, int ld, int A, int dw, float *__restrict__ logits,
+                                    float *__restrict__ deltas, const float *__restrict__ scale2) {
+  const int per = A * (1 + dw);
+  const int64_t total = cells * (FWD ? per : ld);
+  const float s0 = (!FWD && scale2) ? scale2[0] : 1.f, s1 = (!FWD && scale2) ? scale2[1] : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (FWD) {
+      const int64_t cell = i / per;
+      const int k = (int)(i - cell * per);
+      const float v = reinterpret_cast<const float *>(head)[cell * ld + k];
+      if (k < A) logits[cell * A + k] = v;
+      else deltas[cell * A * dw + (k - A)] = v;
+    } else {
+      const int64_t cell = i / ld;
+      const int k = (int)(i - cell * ld);
+      float v = 0.f;
+      if (k < A) v = logits[cell * A + k] * s0;
+      else if (k < per) v = deltas[cell * A * dw + (k - A)] * s1;
+      elem<T>::st(reinterpret_cast<T *>(head) + i, v);
+    }
+  }
+}
+
+extern "C" int nrpn_head_flatten_f32(const float *head, int64_t cells, int ld, int anchors_per_cell, int dw, float *logits, float *deltas,
+                                     nrpn_stream_t stream) {
+  NRPN_REQUIRE(head && logits && deltas && cells > 0 && anchors_per_cell * (1 + dw) <= ld, "head_flatten: bad args");
+  const int64_t total = cells * anchors_per_cell * (1 + dw);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((head_flatten_kernel<float, true>), dim3(blocks), dim3(256), 0, as_stream(stream), (void *)head, cells, ld,
+                     anchors_per_cell, dw, logits, deltas, (const float *)nullptr);
+  NRPN_LAUNCH_CHECK("head_flatten");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_head_unflatten(const float *g_logits, const float *g_deltas, int64_t cells, int ld, int anchors_per_cell, int dw,
+                                   const float *scale2, void *d_head, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(d_head && g_logits && g_deltas && cells > 0 && anchors_per_cell * (1 + dw) <= ld, "head_unflatten: bad args");
+  const int64_t total = cells * ld;
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  if (dtype == NRPN_F32)
+    hipLaunchKernelGGL((head_flatten_kernel<float, false>), dim3(blocks), dim3(256), 0, as_stream(stream), d_head, cells, ld,
+                       anchors_per_cell, dw, (float *)g_logits, (float *)g_deltas, scale2);
+  else
+    hipLaunchKernelGGL((head_flatten_kernel<unsigned short, false>), dim3(blocks), dim3(256), 0, as_stream(stream), d_head, cells, ld,
+                       anchors_per_cell, dw, (float *)g_logits, (float *)g_deltas, scale2);
+  NRPN_LAUNCH_CHECK("head_unflatten");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_obb_to_aabb_f32(const float *obb, float *aabb, int64_t n, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n >= 0, "obb_to_aabb: n<0");
+  if (n == 0) return NRPN_OK;
+  NRPN_REQUIRE(obb && aabb, "obb_to_aabb: null pointer");
+  hipLaunchKernelGGL(obb_to_aabb_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, as_stream(stream), obb, aabb, n);
+  NRPN_LAUNCH_CHECK("obb_to_aabb");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// Proposal filter: one 1024-thread workgroup, three stable compactions (empty slots; OBB centre test on the boxes
+// ONLY -- quirk B3; small-box + score threshold), each a block scan over thread-contiguous runs of 16 entries.
+// =====================================================================================================================
+constexpr int kFilterMax = 16384;
+constexpr int kPerThread = kFilterMax / kTopkThreads;  // 16
+
+template <int W>
+__global__ void __launch_bounds__(kTopkThreads)
+filter_kernel(const float *__restrict__ boxes, const float *__restrict__ logits, const int32_t *__restrict__ levels,
+              const uint8_t *__restrict__ valid, int n, float sx, float sy, float sz, float min_size, float score_thresh, int fix_clip,
+              float *__restrict__ tmp_boxes, float *__restrict__ out_boxes, float *__restrict__ out_scores,
+              int32_t *__restrict__ out_levels, int32_t *__restrict__ tmp_idx, int32_t *__restrict__ d_count) {
+  __shared__ int scratch[kTopkThreads];
+  const int t = threadIdx.x;
+  const int lo = t * kPerThread;
+  // ---- stage 0: drop empty candidate slots; tmp_idx[j] = source row of the j-th live candidate
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) { const int i = lo + q; cnt += (i < n && valid[i]) ? 1 : 0; }
+  int n0;
+  int pos = block_excl_scan(cnt, scratch, &n0);
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) { const int i = lo + q; if (i < n && valid[i]) tmp_idx[pos++] = i; }
+  __syncthreads();
+  // ---- stage 1: boxes only.  AABB: clamp.  OBB: drop boxes whose centre is outside; scores/levels keep their slots.
+  cnt = 0;
+  bool okb[kPerThread];
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) {
+    const int j = lo + q;
+    okb[q] = false;
+    if (j < n0) {
+      const float *b = boxes + (int64_t)tmp_idx[j] * W;
+      if (W == 6) okb[q] = true;
+      else okb[q] = (b[0] >= 0.f && b[0] <= sx) && (b[1] >= 0.f && b[1] <= sy) && (b[2] >= 0.f && b[2] <= sz);
+      cnt += okb[q] ? 1 : 0;
+    }
+  }
+  int n1;
+  pos = block_excl_scan(cnt, scratch, &n1);
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) {
+    const int j = lo + q;
+    if (j < n0 && okb[q]) {
+      const float *b = boxes + (int64_t)tmp_idx[j] * W;
+      float *o = tmp_boxes + (int64_t)pos * (W + 1);
+      if (W == 6) {
+        o[0] = fminf(fmaxf(b[0], 0.f), sx); o[1] = fminf(fmaxf(b[1], 0.f), sy); o[2] = fminf(fmaxf(b[2], 0.f), sz);
+        o[3] = fminf(fmaxf(b[3], 0.f), sx); o[4] = fminf(fmaxf(b[4], 0.f), sy); o[5] = fminf(fmaxf(b[5], 0.f), sz);
+      } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) o[k] = b[k];
+      }
+      // which candidate's score/level rides with this box: its own (fixed behaviour) or slot `pos` (reference quirk B3)
+      o[W] = __int_as_float(fix_clip ? j : pos);
+      ++pos;
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: remove_small_boxes + score threshold on the (box, paired score) rows
+  cnt = 0;
+  float sc[kPerThread];
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) {
+    const int j = lo + q;
+    okb[q] = false;
+    if (j < n1) {
+      const float *b = tmp_boxes + (int64_t)j * (W + 1);
+      const int src = tmp_idx[__float_as_int(b[W])];
+      const float l = logits[src];
+      sc[q] = 1.0f / (1.0f + expf(-l));
+      bool big;
+      if (W == 6) big = (b[3] - b[0] >= min_size) && (b[4] - b[1] >= min_size) && (b[5] - b[2] >= min_size);
+      else big = (b[3] >= min_size) && (b[4] >= min_size) && (b[5] >= min_size);
+      okb[q] = big && (sc[q] >= score_thresh);
+      cnt += okb[q] ? 1 : 0;
+    }
+  }
+  int n2;
+  pos = block_excl_scan(cnt, scratch, &n2);
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) {
+    const int j = lo + q;
+    if (j < n1 && okb[q]) {
+      const float *b = tmp_boxes + (int64_t)j * (W + 1);
+      const int src = tmp_idx[__float_as_int(b[W])];
+#pragma unroll
+      for (int k = 0; k < W; ++k) out_boxes[(int64_t)pos * W + k] = b[k];
+      out_scores[pos] = sc[q];
+      out_levels[pos] = levels[src];
+      ++pos;
+    }
+  }
+  if (t == 0) *d_count = n2;
+}
+
+extern "C" size_t nrpn_filter_workspace_bytes(int64_t n, int box_dim) { return (size_t)(n * (box_dim + 1) * 4 + n * 4); }
+
+extern "C" int nrpn_filter_candidates_f32(const float *boxes, const float *logits, const int32_t *levels, const uint8_t *cand_valid,
+                                          int64_t n, int box_dim, const float *h_grid_size3, float min_size, float score_thresh,
+                                          int fix_obb_clip, float *out_boxes, float *out_scores, int32_t *out_levels,
+                                          int32_t *d_count, void *workspace, nrpn_stream_t stream) {
+  NRPN_REQUIRE(box_dim == 6 || box_dim == 7, "filter: box_dim must be 6 or 7 (got %d)", box_dim);
+  NRPN_REQUIRE(n >= 0 && n <= kFilterMax, "filter: n=%lld outside [0,%d]", (long long)n, kFilterMax);
+  NRPN_REQUIRE(boxes && logits && levels && cand_valid && h_grid_size3 && out_boxes && out_scores && out_levels && d_count &&
+                   workspace, "filter: null pointer");
+  float *tmp_boxes = reinterpret_cast<float *>(workspace);
+  int32_t *tmp_idx = reinterpret_cast<int32_t *>(tmp_boxes + n * (box_dim + 1));
+  const float sx = h_grid_size3[0], sy = h_grid_size3[1], sz = h_grid_size3[2];
+  if (box_dim == 6)
+    hipLaunchKernelGGL(filter_kernel<6>, dim3(1), dim3(kTopkThreads), 0, as_stream(stream), boxes, logits, levels, cand_valid, (int)n,
+                       sx, sy, sz, min_size, score_thresh, fix_obb_clip, tmp_boxes, out_boxes, out_scores, out_levels, tmp_idx, d_count);
+  else
+    hipLaunchKernelGGL(filter_kernel<7>, dim3(1), dim3(kTopkThreads), 0, as_stream(stream), boxes, logits, levels, cand_valid, (int)n,
+                       sx, sy, sz, min_size, score_thresh, fix_obb_clip, tmp_boxes, out_boxes, out_scores, out_levels, tmp_idx, d_count);
+  NRPN_LAUNCH_CHECK("filter");
+  return NRPN_OK;
+}
+
+// final gather of the NMS survivors in (score desc, index asc) order
+__global__ void __launch_bounds__(kTopkThreads)
+select_kept_kernel(const float *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ levels,
+                   const uint8_t *__restrict__ keep, const int32_t *__restrict__ d_count, int n_max, int W, int P, int post,
+                   float *__restrict__ out_boxes, float *__restrict__ out_scores, float *__restrict__ out_levels,
+                   int32_t *__restrict__ d_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+  __shared__ int kept;
+  const int n = d_count ? min(*d_count, n_max) : n_max;
+  if (threadIdx.x == 0) kept = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    unsigned long long v = 0ull;
+    if (i < n && keep[i]) { v = ((unsigned long long)f2key(scores[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i); ++mine; }
+    lds64[i] = v;
+  }
+  if (mine) atomicAdd(&kept, mine);
+  __syncthreads();
+  bitonic_sort_desc(lds64, P);
+  const int m = min(kept, post);
+  for (int i = threadIdx.x; i < post; i += blockDim.x) {
+    if (i < m) {
+      const int src = (int)(0xFFFFFFFFu - (unsigned)(lds64[i] & 0xFFFFFFFFull));
+      for (int k = 0; k < W; ++k) out_boxes[(int64_t)i * W + k] = boxes[(int64_t)src * W + k];
+      out_scores[i] = scores[src];
+      out_levels[i] = (float)levels[src];
+    } else {
+      for (int k = 0; k < W; ++k) out_boxes[(int64_t)i * W + k] = 0.f;
+      out_scores[i] = 0.f;
+      out_levels[i] = -1.f;
+    }
+  }
+  if (threadIdx.x == 0) *d_out = m;
+}
+
+extern "C" int nrpn_select_kept_f32(const float *boxes, const float *scores, const int32_t *levels, const uint8_t *keep,
+                                    const int32_t *d_count, int64_t n, int box_dim, int post_top_n, float *out_boxes,
+                                    float *out_scores, float *out_levels, int32_t *d_out_count, nrpn_stream_t stream) {
+  NRPN_REQUIRE(box_dim == 6 || box_dim == 7, "select: box_dim must be 6 or 7 (got %d)", box_dim);
+  NRPN_REQUIRE(n >= 1 && n <= 16384 && post_top_n >= 1, "select: bad n=%lld post=%d", (long long)n, post_top_n);
+  NRPN_REQUIRE(boxes && scores && levels && keep && out_boxes && out_scores && out_levels && d_out_count, "select: null pointer");
+  const int P = next_pow2((int)n);
+  static bool attr_done = false;
+  if (!attr_done) {
+    NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(select_kept_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 16384 * 8));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(select_kept_kernel, dim3(1), dim3(kTopkThreads), (size_t)P * 8, as_stream(stream), boxes, scores, levels, keep,
+                     d_count, (int)n, box_dim, P, post_top_n, out_boxes, out_scores, out_levels, d_out_count);
+  NRPN_LAUNCH_CHECK("select_kept");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// Matcher: anchors are recomputed from their flat index (never stored); two passes because the "low quality" rule
+// needs every ground-truth box's maximum over all anchors first.  Both passes run the identical IoU code so the
+// float == comparison of the reference (utils.py:191-211) is exact.
+// =====================================================================================================================
+constexpr int kMaxGt = 1024;
+
+__device__ __forceinline__ bool anchor_in_padding(const int32_t *tab, const geo::AnchorCell &c, float ox, float oy, float oz) {
+  const int32_t *t = tab + 2 + 8 * c.level;
+  const int lx = (int)ceilf(ox / (float)t[3]), ly = (int)ceilf(oy / (float)t[4]), lz = (int)ceilf(oz / (float)t[5]);
+  return !(c.ix < lx && c.iy < ly && c.iz < lz);
+}
+
+template <int PASS>
+__global__ void match_kernel(const int32_t *__restrict__ tab, int64_t total, const float *__restrict__ gt, int G, float fg, float bg,
+                             int has_ori, float ox, float oy, float oz, float *__restrict__ gtmax, float *__restrict__ labels,
+                             int32_t *__restrict__ matched) {
+  __shared__ float sgt[kMaxGt * 6];
+  __shared__ float smax[kMaxGt];
+  for (int i = threadIdx.x; i < G * 6; i += blockDim.x) sgt[i] = gt[i];
+  if (PASS == 1)
+    for (int i = threadIdx.x; i < G; i += blockDim.x) smax[i] = gtmax[i];
+  __syncthreads();
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= total) return;
+  const geo::AnchorCell c = geo::anchor_at(tab, f);
+  const bool padded = has_ori && anchor_in_padding(tab, c, ox, oy, oz);
+  float best = -INFINITY;
+  int besti = 0;
+  bool attains = false;
+  for (int g = 0; g < G; ++g) {
+    const float q = padded ? -1.0f : geo::iou3d_aabb(sgt + g * 6, c.box);
+    if (q > best) { best = q; besti = g; }
+    if (PASS == 0) atomicMax(reinterpret_cast<int *>(gtmax) + g, __float_as_int(q));
+    else attains = attains || (q == smax[g]);
+  }
+  if (PASS == 1) {
+    int idx = besti;
+    if (best < bg) idx = -1;
+    else if (best < fg) idx = -2;
+    if (attains) idx = besti;
+    float lab = (idx >= 0) ? 1.0f : (idx == -1 ? 0.0f : -1.0f);
+    if (padded) lab = -1.0f;
+    labels[f] = lab;
+    matched[f] = idx < 0 ? 0 : idx;
+  }
+}
+
+extern "C" int nrpn_match_anchors_f32(const int32_t *table, int64_t total_anchors, const float *gt_aabb, int num_gt, float fg_thresh,
+                                      float bg_thresh, const float *h_ori_size3, float *labels, int32_t *matched, float *workspace,
+                                      nrpn_stream_t stream) {
+  NRPN_REQUIRE(total_anchors > 0, "match: no anchors");
+  NRPN_REQUIRE(num_gt >= 1 && num_gt <= kMaxGt, "match: num_gt=%d outside [1,%d] (empty targets are handled by the caller)", num_gt, kMaxGt);
+  NRPN_REQUIRE(table && gt_aabb && labels && matched && workspace, "match: null pointer");
+  hipStream_t st = as_stream(stream);
+  // atomicMax on the int view: every IoU is >= 0 or exactly -1, both order correctly as signed ints; 0x80.. = lowest
+  NRPN_HIP(hipMemsetAsync(workspace, 0x80, (size_t)num_gt * 4, st));
+  const float ox = h_ori_size3 ? h_ori_size3[0] : 0.f, oy = h_ori_size3 ? h_ori_size3[1] : 0.f, oz = h_ori_size3 ? h_ori_size3[2] : 0.f;
+  dim3 grid((unsigned)cdiv64(total_anchors, 256));
+  hipLaunchKernelGGL(match_kernel<0>, grid, dim3(256), 0, st, table, total_anchors, gt_aabb, num_gt, fg_thresh, bg_thresh,
+                     h_ori_size3 ? 1 : 0, ox, oy, oz, workspace, labels, matched);
+  hipLaunchKernelGGL(match_kernel<1>, grid, dim3(256), 0, st, table, total_anchors, gt_aabb, num_gt, fg_thresh, bg_thresh,
+                     h_ori_size3 ? 1 : 0, ox, oy, oz, workspace, labels, matched);
+  NRPN_LAUNCH_CHECK("match");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// Sampled losses (<= a few hundred rows): one workgroup, wave shuffles + LDS for the two reductions, gradients
+// written straight into the (caller-zeroed) dense gradient buffers of the head outputs.
+// =====================================================================================================================
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256)
+sampled_loss_kernel(const float *__restrict__ logits, const float *__restrict__ deltas, int dw, const float *__restrict__ targets,
+                    const int64_t *__restrict__ pos, int64_t npos, const int64_t *__restrict__ neg, int64_t nneg, float beta,
+                    float *__restrict__ loss2, float *__restrict__ g_logits, float *__restrict__ g_deltas) {
+  __shared__ float sh[4];
+  const int64_t ns = npos + nneg;
+  const float inv = 1.0f / (float)ns;
+  float bce = 0.f, reg = 0.f;
+  for (int64_t i = threadIdx.x; i < ns; i += blockDim.x) {
+    const bool is_pos = i < npos;
+    const int64_t r = is_pos ? pos[i] : neg[i - npos];
+    const float x = logits[r], y = is_pos ? 1.f : 0.f;
+    bce += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    if (g_logits) g_logits[r] = (1.0f / (1.0f + expf(-x)) - y) * inv;
+  }
+  for (int64_t i = threadIdx.x; i < npos * dw; i += blockDim.x) {
+    const int64_t p = i / dw;
+    const int k = (int)(i - p * dw);
+    const int64_t r = pos[p];
+    const float d = deltas[r * dw + k] - targets[p * dw + k];
+    const float ad = fabsf(d);
+    reg += (ad < beta) ? 0.5f * d * d / beta : ad - 0.5f * beta;
+    if (g_deltas) g_deltas[r * dw + k] = ((ad < beta) ? d / beta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f))) * inv;
+  }
+  const float b = block_sum_256(bce, sh);
+  const float g = block_sum_256(reg, sh);
+  if (threadIdx.x == 0) { loss2[0] = b * inv; loss2[1] = g * inv; }
+}
+
+extern "C" int nrpn_rpn_sampled_loss_f32(const float *logits, const float *deltas, int dw, const float *targets, const int64_t *pos,
+                                         int64_t npos, const int64_t *neg, int64_t nneg, float beta, float *loss2, float *g_logits,
+                                         float *g_deltas, nrpn_stream_t stream) {
+  NRPN_REQUIRE(dw == 6 || dw == 8, "sampled loss: dw must be 6 or 8 (got %d)", dw);
+  NRPN_REQUIRE(npos >= 0 && nneg >= 0 && npos + nneg > 0, "sampled loss: empty sample");
+  NRPN_REQUIRE(logits && deltas && loss2 && (npos == 0 || (pos && targets)) && (nneg == 0 || neg), "sampled loss: null pointer");
+  hipLaunchKernelGGL(sampled_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, deltas, dw, targets, pos, npos, neg, nneg,
+                     beta, loss2, g_logits, g_deltas);
+  NRPN_LAUNCH_CHECK("sampled_loss");
+  return NRPN_OK;
+}

@@ -1,0 +1,95 @@
+"""ctypes binding of ``libnerfrpn_hip.so`` (C ABI in ``include/nerfrpn.h``).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, this module raises.
+``build()`` compiles the library in-tree (``make -C nerf_rpn_amd/csrc``); hipcc cross-compiles gfx950 without a GPU.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libnerfrpn_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "nerfrpn.h")
+
+F32, BF16 = 0, 1
+CONV_BIAS, CONV_RELU, CONV_OUT_F32 = 1, 2, 4
+
+_lib = None
+
+
+class NrpnError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile every HIP translation unit for gfx950 and link the shared library (in-tree)."""
+    if force:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "clean"])
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"])
+    return SO_PATH
+
+
+def declared_symbols():
+    """Every ``nrpn_*`` function declared in include/nerfrpn.h (used by the ABI test)."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nrpn_[a-z0-9_]+)\s*\(", text)))
+
+
+def _ctype(decl):
+    decl = decl.strip()
+    if "*" in decl or decl.startswith("nrpn_stream_t"):
+        return ctypes.c_void_p
+    base = decl.replace("const", "").split()
+    t = " ".join(base[:-1]) if len(base) > 1 else base[0]
+    if t in ("int64_t", "long long", "size_t"):
+        return ctypes.c_int64
+    if t == "int":
+        return ctypes.c_int
+    if t == "float":
+        return ctypes.c_float
+    raise NrpnError(f"unmapped C type in nerfrpn.h: {decl!r}")
+
+
+def _prototypes():
+    """Parse include/nerfrpn.h into {name: (restype, [argtypes])} so ctypes converts and checks every argument."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int|size_t|int64_t|const char \*)\s*(nrpn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        args = args.strip()
+        argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
+        restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "int64_t": ctypes.c_int64,
+                   "const char *": ctypes.c_char_p}[ret]
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise NrpnError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback for the HIP path)")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (restype, argtypes) in _prototypes().items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = restype, argtypes
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call ``nrpn_<name>`` and raise NrpnError with the library's message on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, "nrpn_" + name)(*args)
+    if rc != 0:
+        raise NrpnError(f"nrpn_{name} failed ({rc}): {lib.nrpn_last_error().decode()}")
+    return rc
+
+
+def query(name, *args):
+    """Call a size query (returns a number, not a status)."""
+    return getattr(load(), "nrpn_" + name)(*args)

@@ -1,0 +1,95 @@
+"""Executes standard ``torch.nn`` container modules (Conv3d / BatchNorm3d / ReLU / MaxPool3d / Sequential) on the HIP
+kernels.  The nn modules only hold parameters under the reference's state-dict names; the arithmetic is
+``nerf_rpn_amd.ops`` on channels-last tensors, with conv+BN+ReLU and conv+ReLU patterns fused the way the kernels
+expect (bias/ReLU in the conv epilogue, ReLU inside the BN apply)."""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _pack_of(mod):
+    pk = mod.__dict__.get("_nrpn_pack")
+    if pk is None:
+        pk = ops.PackedWeight()
+        mod.__dict__["_nrpn_pack"] = pk
+    return pk
+
+
+def conv3d(mod, x, relu=False, out_f32=False):
+    """nn.Conv3d (k 1|3, stride 1, same padding; or the 4-channel k7 stem) on a channels-last tensor."""
+    k = mod.kernel_size[0]
+    if k == 7:
+        if mod.in_channels != 4 or mod.padding[0] != 3:
+            raise NotImplementedError("k7 conv is only implemented for the 4-channel stem")
+        cache = mod.__dict__.setdefault("_nrpn_stem", {})
+        y = ops.StemFn.apply(x, mod.weight, mod.bias, mod.stride[0], cache)
+        if relu:
+            raise NotImplementedError("stem is always followed by BatchNorm in this model family")
+        return y
+    if k not in (1, 3) or mod.stride[0] != 1 or mod.padding[0] != k // 2:
+        raise NotImplementedError(f"Conv3d k={k} stride={mod.stride} padding={mod.padding} has no HIP kernel yet")
+    return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, relu, out_f32, 1, mod.weight, mod.bias)
+
+
+def batch_norm(mod, x, relu):
+    training = mod.training or mod.running_mean is None
+    if mod.training and mod.track_running_stats and mod.num_batches_tracked is not None:
+        mod.num_batches_tracked.add_(1)
+    return ops.BatchNormFn.apply(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, training,
+                                 mod.momentum if mod.momentum is not None else 0.1, mod.eps, relu)
+
+
+def max_pool(mod, x):
+    k = mod.kernel_size if isinstance(mod.kernel_size, int) else mod.kernel_size[0]
+    s = mod.stride if isinstance(mod.stride, int) else mod.stride[0]
+    p = mod.padding if isinstance(mod.padding, int) else mod.padding[0]
+    return ops.MaxPoolFn.apply(x, k, s, p, bool(mod.ceil_mode))
+
+
+def run_modules(mods, x):
+    """Run a flat list of nn modules on a channels-last tensor, fusing conv -> [BN] -> [ReLU] runs."""
+    mods = list(mods)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        nxt2 = mods[i + 2] if i + 2 < len(mods) else None
+        if isinstance(m, nn.Conv3d):
+            if isinstance(nxt, nn.BatchNorm3d):
+                x = conv3d(m, x)
+                fuse = isinstance(nxt2, nn.ReLU)
+                x = batch_norm(nxt, x, fuse)
+                i += 3 if fuse else 2
+            elif isinstance(nxt, nn.ReLU):
+                x = conv3d(m, x, relu=True)
+                i += 2
+            else:
+                x = conv3d(m, x)
+                i += 1
+        elif isinstance(m, nn.MaxPool3d):
+            x = max_pool(m, x)
+            i += 1
+        elif isinstance(m, nn.Sequential):
+            x = run_modules(m, x)
+            i += 1
+        elif isinstance(m, nn.BatchNorm3d):
+            fuse = isinstance(nxt, nn.ReLU)
+            x = batch_norm(m, x, fuse)
+            i += 2 if fuse else 1
+        else:
+            raise NotImplementedError(f"no HIP kernel mapping for module {type(m).__name__}")
+    return x
+
+
+def as_ncdhw(x):
+    """Channels-last [N,X,Y,Z,C] -> the reference's logical [N,C,X,Y,Z] (a free view)."""
+    return x.permute(0, 4, 1, 2, 3)
+
+
+def as_ndhwc(x, dtype):
+    """Accept either a channels-last-backed NCDHW view (free) or a plain NCDHW tensor (converted by a kernel)."""
+    cl = x.permute(0, 2, 3, 4, 1)
+    if cl.is_contiguous() and cl.dtype == dtype:
+        return cl
+    return ops.to_channels_last(x, dtype)

@@ -1,0 +1,588 @@
+"""Tensor-level wrappers over the C ABI (``include/nerfrpn.h``).
+
+PyTorch is used only for device memory, streams and autograd graph stitching: every function here hands raw device
+pointers + the current HIP stream to ``libnerfrpn_hip.so``.  Activations are channels-last tensors of shape
+``[N, X, Y, Z, C]`` (fp32 or bf16).  There is no CPU / eager fallback: non-CUDA tensors raise.
+"""
+import itertools
+import math
+
+import torch
+
+from . import lib
+from .lib import BF16, CONV_BIAS, CONV_OUT_F32, CONV_RELU, F32, call, query
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise lib.NrpnError("HIP op called with a non-CUDA tensor (the product path has no CPU fallback)")
+        if not t.is_contiguous():
+            raise lib.NrpnError(f"HIP op needs contiguous tensors, got strides {t.stride()} for shape {tuple(t.shape)}")
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise lib.NrpnError(f"unsupported dtype {t.dtype} (fp32 / bf16 only)")
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+# ======================================================================================================================
+# rotated IoU / NMS / top-k
+# ======================================================================================================================
+def sort_vertices(vertices, mask, num_valid):
+    """Drop-in for reference ``sort_vertices.sort_vertices_forward`` (cuda_op/sort_vert.cpp:6-33)."""
+    vertices = vertices.float().contiguous()
+    m8 = mask.to(torch.uint8).contiguous()
+    nv = num_valid.to(torch.int32).contiguous()
+    _chk(vertices, m8, nv)
+    B, N, M = m8.shape
+    out = torch.zeros((B, N, 9), dtype=torch.int32, device=vertices.device)
+    call("sort_vertices_f32", _p(vertices), _p(m8), _p(nv), _p(out), B * N, M, _s())
+    return out
+
+
+def iou3d_pair(b1, b2):
+    """Paired rotated 3D IoU, boxes [..., 7] -> [...] (reference cal_iou_3d)."""
+    shape = b1.shape[:-1]
+    a, b = _f32(b1).reshape(-1, 7).contiguous(), _f32(b2).reshape(-1, 7).contiguous()
+    _chk(a, b)
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    call("iou3d_obb_pair_f32", _p(a), _p(b), _p(out), a.shape[0], _s())
+    return out.reshape(shape)
+
+
+def iou3d_matrix(a, b):
+    """All-pairs IoU [n,w] x [m,w] -> [n,m], w = 6 (AABB) or 7 (OBB) (reference box_iou_3d)."""
+    if a.shape[1] != b.shape[1] or a.shape[1] not in (6, 7):
+        raise ValueError(f"The second dimension of boxes1 and boxes2 should be the same, both 6 or 7. But get {a.shape[1]} and {b.shape[1]}.")
+    a, b = _f32(a).contiguous(), _f32(b).contiguous()
+    _chk(a, b)
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    for i in range(0, a.shape[0], 32768):
+        part = a[i:i + 32768]
+        call("iou3d_matrix_f32", _p(part), _p(b), _p(out[i:]), part.shape[0], b.shape[0], a.shape[1], _s())
+    return out
+
+
+def nms3d_sorted(boxes, levels, thr, count=None):
+    """Greedy NMS on boxes already score-descending inside each (non-decreasing) level run -> uint8 keep mask."""
+    boxes = _f32(boxes).contiguous()
+    _chk(boxes, levels, count)
+    n = boxes.shape[0]
+    keep = torch.empty(n, dtype=torch.uint8, device=boxes.device)
+    if n == 0:
+        return keep
+    ws = torch.empty(query("nms3d_workspace_bytes", n), dtype=torch.uint8, device=boxes.device)
+    call("nms3d", _p(boxes), _p(levels), _p(count), n, boxes.shape[1], float(thr), _p(keep), _p(ws), _s())
+    return keep
+
+
+def segmented_topk(scores, offsets, k):
+    """Per-segment top-k in (score desc, index asc) order.  offsets: python list of nseg+1 ints."""
+    import ctypes
+    scores = scores.contiguous()
+    _chk(scores)
+    nseg = len(offsets) - 1
+    idx = torch.empty((nseg, k), dtype=torch.int32, device=scores.device)
+    val = torch.empty((nseg, k), dtype=torch.float32, device=scores.device)
+    host = (ctypes.c_int64 * (nseg + 1))(*[int(o) for o in offsets])
+    call("segmented_topk_f32", _p(scores), ctypes.addressof(host), nseg, int(k), _p(idx), _p(val), _s())
+    return idx, val
+
+
+def argsort_desc(scores):
+    """(score desc, index asc) permutation of a 1-D tensor with n <= 16384 (deterministic argsort)."""
+    n = scores.numel()
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=scores.device)
+    if n > 16384:
+        raise lib.NrpnError("argsort_desc supports at most 16384 elements")
+    idx, _ = segmented_topk(_f32(scores).reshape(-1), [0, n], n)
+    return idx[0].long()
+
+
+# ======================================================================================================================
+# anchors / coders
+# ======================================================================================================================
+ANCHOR_SIZES = ((8,), (16,), (32,), (64,))
+ASPECT_RATIOS = (((1., 1., 1.), (1., 1., 2.), (1., 2., 2.), (1., 1., 3.), (1., 3., 3.)),) * 4
+
+
+def unique_ratio_permutations(ratios):
+    """The reference iterates ``set(itertools.permutations(r))`` per ratio (anchor.py:57-60); CPython's hash order of
+    float tuples is deterministic, so the same expression reproduces the channel <-> anchor mapping of checkpoints."""
+    out = []
+    for r in ratios:
+        out += list(set(itertools.permutations(r)))
+    return out
+
+
+def base_anchor_table(scales, ratios):
+    """anchor.py:49-82 (is_normalized=False): [A,6] rounded half-to-even, on the host."""
+    r = torch.tensor(unique_ratio_permutations(ratios), dtype=torch.float32)
+    s = torch.as_tensor(scales, dtype=torch.float32)
+    e = (r[:, None, :] * s[None, :, None]).reshape(-1, 3)
+    return (torch.cat([-e, e], dim=1) / 2).round()
+
+
+class AnchorTable:
+    """Device-side description of the anchor pyramid (layout in nerfrpn.h); anchors are computed from flat indices."""
+
+    def __init__(self, mesh_size, grids, sizes=ANCHOR_SIZES, ratios=ASPECT_RATIOS, device="cuda"):
+        bases = [base_anchor_table(s, r) for s, r in zip(sizes, ratios)]
+        self.A = bases[0].shape[0]
+        if any(b.shape[0] != self.A for b in bases):
+            raise lib.NrpnError("all pyramid levels must have the same number of anchors per cell")
+        self.grids = [tuple(int(v) for v in g) for g in grids]
+        self.strides = [tuple(int(mesh_size[i]) // g[i] for i in range(3)) for g in self.grids]
+        self.cells = [g[0] * g[1] * g[2] for g in self.grids]
+        self.counts = [c * self.A for c in self.cells]
+        self.offsets = [0]
+        for c in self.counts:
+            self.offsets.append(self.offsets[-1] + c)
+        self.total = self.offsets[-1]
+        L = len(self.grids)
+        words = torch.zeros(int(query("anchor_table_words", L, self.A)), dtype=torch.int32)
+        words[0], words[1] = L, self.A
+        for l, (g, s) in enumerate(zip(self.grids, self.strides)):
+            first = self.offsets[l]
+            lo = first & 0xFFFFFFFF
+            lo = lo - (1 << 32) if lo >= (1 << 31) else lo
+            words[2 + 8 * l: 2 + 8 * l + 8] = torch.tensor([g[0], g[1], g[2], s[0], s[1], s[2], lo, first >> 32], dtype=torch.int32)
+        fl = torch.cat([b.reshape(-1) for b in bases]).view(torch.int32)
+        words[2 + 8 * L:] = fl
+        self.words = words.to(device)
+        self.base = bases
+
+    def level_of(self, device):
+        return torch.cat([torch.full((c,), i, dtype=torch.int64, device=device) for i, c in enumerate(self.counts)])
+
+
+def anchors(table, sel=None, count=None):
+    count = table.total if sel is None else sel.numel()
+    out = torch.empty((count, 6), dtype=torch.float32, device=table.words.device)
+    _chk(sel)
+    call("anchors_f32", _p(table.words), _p(sel), count, _p(out), _s())
+    return out
+
+
+def decode_boxes(table, deltas, sel, coder):
+    """deltas [T, 6|8] (flat anchor order), sel int64 [K] or None -> boxes [K, 6|7]."""
+    deltas = _f32(deltas).contiguous()
+    _chk(deltas, sel)
+    count = deltas.shape[0] if sel is None else sel.numel()
+    out = torch.empty((count, 7 if coder else 6), dtype=torch.float32, device=deltas.device)
+    call("decode_boxes_f32", _p(table.words), _p(deltas), _p(sel), count, int(coder), _p(out), _s())
+    return out
+
+
+def encode_boxes(table, gt, sel, coder):
+    gt = _f32(gt).contiguous()
+    _chk(gt, sel)
+    count = gt.shape[0]
+    out = torch.empty((count, 8 if coder else 6), dtype=torch.float32, device=gt.device)
+    call("encode_boxes_f32", _p(table.words), _p(gt), _p(sel), count, int(coder), _p(out), _s())
+    return out
+
+
+def coder_pairs(inp, anchor_boxes, coder, encode):
+    inp, anchor_boxes = _f32(inp).contiguous(), _f32(anchor_boxes).contiguous()
+    _chk(inp, anchor_boxes)
+    if inp.shape[0] != anchor_boxes.shape[0]:
+        raise AssertionError("coder: row count mismatch")
+    width = (8 if coder else 6) if encode else (7 if coder else 6)
+    out = torch.empty((inp.shape[0], width), dtype=torch.float32, device=inp.device)
+    call("coder_pairs_f32", _p(inp), _p(anchor_boxes), inp.shape[0], int(coder), int(bool(encode)), _p(out), _s())
+    return out
+
+
+def obb_to_aabb(obb):
+    obb = _f32(obb).contiguous()
+    _chk(obb)
+    out = torch.empty((obb.shape[0], 6), dtype=torch.float32, device=obb.device)
+    call("obb_to_aabb_f32", _p(obb), _p(out), obb.shape[0], _s())
+    return out
+
+
+# ======================================================================================================================
+# proposal filter / target assignment / losses
+# ======================================================================================================================
+def filter_candidates(boxes, logits, levels, valid, grid_size, min_size, score_thresh, fix_obb_clip=False):
+    import ctypes
+    _chk(boxes, logits, levels, valid)
+    n, w = boxes.shape
+    dev = boxes.device
+    ob = torch.empty((n, w), dtype=torch.float32, device=dev)
+    os_ = torch.empty(n, dtype=torch.float32, device=dev)
+    ol = torch.empty(n, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(16, query("filter_workspace_bytes", n, w)), dtype=torch.uint8, device=dev)
+    host = (ctypes.c_float * 3)(*[float(v) for v in grid_size])
+    call("filter_candidates_f32", _p(boxes), _p(logits), _p(levels), _p(valid), n, w, ctypes.addressof(host), float(min_size),
+         float(score_thresh), int(bool(fix_obb_clip)), _p(ob), _p(os_), _p(ol), _p(cnt), _p(ws), _s())
+    return ob, os_, ol, cnt
+
+
+def select_kept(boxes, scores, levels, keep, count, post_top_n):
+    _chk(boxes, scores, levels, keep, count)
+    n, w = boxes.shape
+    dev = boxes.device
+    ob = torch.empty((post_top_n, w), dtype=torch.float32, device=dev)
+    os_ = torch.empty(post_top_n, dtype=torch.float32, device=dev)
+    ol = torch.empty(post_top_n, dtype=torch.float32, device=dev)
+    oc = torch.zeros(1, dtype=torch.int32, device=dev)
+    call("select_kept_f32", _p(boxes), _p(scores), _p(levels), _p(keep), _p(count), n, w, int(post_top_n), _p(ob), _p(os_), _p(ol),
+         _p(oc), _s())
+    return ob, os_, ol, oc
+
+
+def match_anchors(table, gt_aabb, fg, bg, ori_size=None):
+    """labels f32 [T] in {1,0,-1} and clamped match index int32 [T] (reference assign_targets_to_anchors + Matcher)."""
+    import ctypes
+    gt_aabb = _f32(gt_aabb).contiguous()
+    _chk(gt_aabb)
+    dev = gt_aabb.device
+    labels = torch.empty(table.total, dtype=torch.float32, device=dev)
+    matched = torch.empty(table.total, dtype=torch.int32, device=dev)
+    ws = torch.empty(gt_aabb.shape[0], dtype=torch.float32, device=dev)
+    host = None
+    hp = 0
+    if ori_size is not None:
+        host = (ctypes.c_float * 3)(*[float(v) for v in ori_size])
+        hp = ctypes.addressof(host)
+    call("match_anchors_f32", _p(table.words), table.total, _p(gt_aabb), gt_aabb.shape[0], float(fg), float(bg), hp, _p(labels),
+         _p(matched), _p(ws), _s())
+    return labels, matched
+
+
+class SampledLossFn(torch.autograd.Function):
+    """BCE-with-logits (mean over pos+neg) and smooth-L1 (sum over pos / (|pos|+|neg|)) with fused backward
+    (reference compute_loss, rpn.py:372-419).  logits [M], deltas [M,dw] flat over the batch."""
+
+    @staticmethod
+    def forward(ctx, logits, deltas, targets, pos, neg, beta):
+        logits, deltas = logits.contiguous(), deltas.contiguous()
+        targets = targets.contiguous()
+        _chk(logits, deltas, targets, pos, neg)
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)
+        g_logits = torch.zeros_like(logits)
+        g_deltas = torch.zeros_like(deltas)
+        call("rpn_sampled_loss_f32", _p(logits), _p(deltas), deltas.shape[-1], _p(targets), _p(pos), pos.numel(), _p(neg), neg.numel(),
+             float(beta), _p(out), _p(g_logits), _p(g_deltas), _s())
+        ctx.save_for_backward(g_logits, g_deltas)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_obj, g_reg):
+        g_logits, g_deltas = ctx.saved_tensors
+        return g_logits * g_obj, g_deltas * g_reg, None, None, None, None
+
+
+class FlattenHeadFn(torch.autograd.Function):
+    """Per-level head rows [N, cells_l, ld] -> logits [N, T], deltas [N, T, dw] in the reference's (level, x, y, z, a) order
+    (concat_box_prediction_layers, rpn.py:105-130); backward scatters dense gradients back into the padded head rows."""
+
+    @staticmethod
+    def forward(ctx, A, dw, grad_dtype, *heads):
+        n = heads[0].shape[0]
+        cells = [h.shape[1] for h in heads]
+        T = sum(cells) * A
+        dev = heads[0].device
+        logits = torch.empty((n, T), dtype=torch.float32, device=dev)
+        deltas = torch.empty((n, T, dw), dtype=torch.float32, device=dev)
+        off = 0
+        for h, c in zip(heads, cells):
+            _chk(h)
+            for i in range(n):
+                call("head_flatten_f32", _p(h[i]), c, h.shape[2], A, dw, _p(logits[i, off:]), _p(deltas[i, off:]), _s())
+            off += c * A
+        ctx.meta = (A, dw, cells, [h.shape[2] for h in heads], grad_dtype)
+        return logits, deltas
+
+    @staticmethod
+    def backward(ctx, g_logits, g_deltas):
+        A, dw, cells, lds, grad_dtype = ctx.meta
+        g_logits, g_deltas = g_logits.contiguous(), g_deltas.contiguous()
+        n = g_logits.shape[0]
+        outs = []
+        off = 0
+        for c, ld in zip(cells, lds):
+            d = torch.empty((n, c, ld), dtype=grad_dtype, device=g_logits.device)
+            for i in range(n):
+                call("head_unflatten", _p(g_logits[i, off:]), _p(g_deltas[i, off:]), c, ld, A, dw, 0, _p(d[i]), _dt(d), _s())
+            outs.append(d)
+            off += c * A
+        return (None, None, None, *outs)
+
+
+# ======================================================================================================================
+# conv / norm / pool with autograd
+# ======================================================================================================================
+class PackedWeight:
+    """GEMM-layout copies of one or more reference-layout conv weights sharing a GEMM (rows_total rows), refreshed when
+    the parameters change (tensor._version)."""
+
+    def __init__(self):
+        self.key = None
+        self.fwd = None
+        self.dgrad = None
+
+    def get(self, weights, dtype, rows_total, need_dgrad):
+        key = tuple((w.data_ptr(), w._version) for w in weights) + (dtype, rows_total, need_dgrad)
+        if key == self.key:
+            return self.fwd, self.dgrad
+        cin = weights[0].shape[1]
+        taps = weights[0][0, 0].numel()
+        dev = weights[0].device
+        padded = rows_total != sum(w.shape[0] for w in weights)
+        alloc = torch.zeros if padded else torch.empty
+        fwd = alloc((taps, rows_total, cin), dtype=dtype, device=dev)
+        dgrad = alloc((taps, cin, rows_total), dtype=dtype, device=dev) if need_dgrad else None
+        row = 0
+        for w in weights:
+            wc = w.detach().contiguous()
+            call("pack_conv_weight", _p(wc), w.shape[0], cin, taps, _dt(fwd), _p(fwd), _p(dgrad), rows_total, row, _s())
+            row += w.shape[0]
+        self.key, self.fwd, self.dgrad = key, fwd, dgrad
+        return fwd, dgrad
+
+
+def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype):
+    n, gx, gy, gz, cin = x.shape
+    y = torch.empty((n, gx, gy, gz, cout), dtype=out_dtype, device=x.device)
+    if out_dtype == torch.float32 and x.dtype == torch.bfloat16:
+        flags |= CONV_OUT_F32
+    if bias is not None:
+        flags |= CONV_BIAS
+    call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _s())
+    return y
+
+
+class ConvFn(torch.autograd.Function):
+    """Conv3d k in {1,3}, stride 1, 'same' padding, channels-last, optional fused bias + ReLU.
+    ``weights``: one or more reference-layout parameters that share the GEMM (their rows are concatenated, then padded to
+    ``rows_total``); the output has rows_total channels."""
+
+    @staticmethod
+    def forward(ctx, x, pack, rows_total, relu, out_f32, nw, *wb):
+        weights, biases = wb[:nw], wb[nw:]
+        _chk(x)
+        ksize = weights[0].shape[2]
+        need_dgrad = x.requires_grad
+        wp, wpd = pack.get(weights, x.dtype, rows_total, need_dgrad)
+        bias = None
+        if biases[0] is not None:
+            bias = torch.cat([b.detach().float() for b in biases]) if nw > 1 else biases[0].detach().float().contiguous()
+            if bias.numel() < rows_total:
+                bias = torch.cat([bias, bias.new_zeros(rows_total - bias.numel())])
+        out_dtype = torch.float32 if out_f32 else x.dtype
+        y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype)
+        ctx.save_for_backward(x, y if relu else None, wpd, *weights)
+        ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, wpd, *weights = ctx.saved_tensors
+        rows_total, relu, nw, ksize, has_bias = ctx.meta
+        n, gx, gy, gz, cin = x.shape
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if relu:
+            dyr = torch.empty_like(dy)
+            yy = y if y.dtype == dy.dtype else y.to(dy.dtype)
+            call("relu_backward", _p(yy), _p(dy), _p(dyr), dy.numel(), _dt(dy), _s())
+            dy = dyr
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype)
+        taps = ksize ** 3
+        gwp = torch.empty((taps, rows_total, cin), dtype=torch.float32, device=x.device)
+        gb = torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None
+        call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), _s())
+        gws, gbs, row = [], [], 0
+        for w in weights:
+            gw = torch.empty_like(w, dtype=torch.float32)
+            call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(gw), 0, _s())
+            gws.append(gw)
+            gbs.append(gb[row:row + w.shape[0]].clone() if has_bias else None)
+            row += w.shape[0]
+        return (dx, None, None, None, None, None, *gws, *gbs)
+
+
+class StemFn(torch.autograd.Function):
+    """Conv3d(4 -> C, k7, pad 3, stride s) on [N,X,Y,Z,4] (reference feature_extractor.py:336,341)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, cache):
+        _chk(x)
+        key = (weight.data_ptr(), weight._version, x.dtype)
+        if cache.get("key") != key:
+            kpad = query("stem_kpad", _dt(x))
+            wp = torch.empty((weight.shape[0], kpad), dtype=x.dtype, device=x.device)
+            call("pack_stem_weight", _p(weight.detach().contiguous()), weight.shape[0], _dt(x), _p(wp), _s())
+            cache["key"], cache["wp"] = key, wp
+        wp = cache["wp"]
+        n, gx, gy, gz, _ = x.shape
+        o = [(g - 1) // stride + 1 for g in (gx, gy, gz)]
+        cout = weight.shape[0]
+        y = torch.empty((n, o[0], o[1], o[2], cout), dtype=x.dtype, device=x.device)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        call("conv3d_stem_fwd", _p(x), _p(wp), _p(b), _p(y), n, gx, gy, gz, cout, stride, _dt(x), CONV_BIAS if b is not None else 0, _s())
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (stride, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, has_bias = ctx.meta
+        dy = dy.contiguous()
+        n, gx, gy, gz, _ = x.shape
+        cout = weight.shape[0]
+        kpad = query("stem_kpad", _dt(x))
+        gwp = torch.empty((cout, kpad), dtype=torch.float32, device=x.device)
+        gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        call("conv3d_stem_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cout, stride, _dt(x), _s())
+        gw = torch.empty_like(weight, dtype=torch.float32)
+        call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(gw), 0, _s())
+        return None, gw, gb, None, None
+
+
+class BatchNormFn(torch.autograd.Function):
+    """BatchNorm3d (+ fused ReLU) on channels-last rows; training uses per-rank batch statistics (no SyncBN, as the reference)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu):
+        _chk(x)
+        c = x.shape[-1]
+        rows = x.numel() // c
+        dev = x.device
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            var = torch.empty(c, dtype=torch.float32, device=dev)
+            ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=dev)
+            call("bn_stats", _p(x), rows, c, _dt(x), _p(mean), _p(var), _p(rmean), _p(rvar), float(momentum), _p(ws), _s())
+        else:
+            mean, var = rmean.float().contiguous(), rvar.float().contiguous()
+        y = torch.empty_like(x)
+        call("bn_apply", _p(x), _p(y), rows, c, _dt(x), _p(mean), _p(var), _p(g32), _p(b32), float(eps), int(relu), _s())
+        ctx.save_for_backward(x, y, mean, var, g32)
+        ctx.meta = (training, eps, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, g32 = ctx.saved_tensors
+        training, eps, relu = ctx.meta
+        if not training:
+            raise lib.NrpnError("BatchNorm backward in eval mode is not supported by the HIP path")
+        dy = dy.contiguous()
+        c = x.shape[-1]
+        rows = x.numel() // c
+        dev = x.device
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=dev)
+        call("bn_backward", _p(x), _p(y), _p(dy), _p(dx), rows, c, _dt(x), _p(mean), _p(var), _p(g32), float(eps), int(relu), _p(dgamma),
+             _p(dbeta), _p(ws), _s())
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p, ceil_mode):
+        _chk(x)
+        n, gx, gy, gz, c = x.shape
+        o = [query("pool_out_size", g, k, s, p, int(ceil_mode)) for g in (gx, gy, gz)]
+        y = torch.empty((n, o[0], o[1], o[2], c), dtype=x.dtype, device=x.device)
+        arg = torch.empty(y.shape, dtype=torch.int8, device=x.device) if x.requires_grad else None
+        call("maxpool3d_fwd", _p(x), _p(y), _p(arg), n, gx, gy, gz, c, k, s, p, int(ceil_mode), _dt(x), _s())
+        ctx.save_for_backward(arg)
+        ctx.meta = (x.shape, k, s, p, ceil_mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        shape, k, s, p, ceil_mode = ctx.meta
+        dy = dy.contiguous()
+        n, gx, gy, gz, c = shape
+        dx = torch.empty(shape, dtype=dy.dtype, device=dy.device)
+        call("maxpool3d_bwd", _p(dy), _p(arg), _p(dx), n, gx, gy, gz, c, k, s, p, int(ceil_mode), _dt(dy), _s())
+        return dx, None, None, None, None
+
+
+class UpsampleAddFn(torch.autograd.Function):
+    """fine += nearest_upsample(coarse), in place on ``fine`` (FPN top-down, reference fpn.py:150-155)."""
+
+    @staticmethod
+    def forward(ctx, fine, coarse):
+        _chk(fine, coarse)
+        n, fx, fy, fz, c = fine.shape
+        _, cx, cy, cz, _ = coarse.shape
+        call("upsample_add_fwd", _p(fine), _p(coarse), n, fx, fy, fz, cx, cy, cz, c, _dt(fine), _s())
+        ctx.mark_dirty(fine)
+        ctx.meta = (fine.shape, coarse.shape)
+        return fine
+
+    @staticmethod
+    def backward(ctx, d):
+        fshape, cshape = ctx.meta
+        d = d.contiguous()
+        n, fx, fy, fz, c = fshape
+        _, cx, cy, cz, _ = cshape
+        dc = torch.empty(cshape, dtype=d.dtype, device=d.device)
+        call("upsample_add_bwd", _p(d), _p(dc), n, fx, fy, fz, cx, cy, cz, c, _dt(d), 0, _s())
+        return d, dc
+
+
+def to_channels_last(x, dtype):
+    """[N,C,X,Y,Z] fp32 -> [N,X,Y,Z,C] dtype."""
+    x = x.float().contiguous()
+    _chk(x)
+    n, c = x.shape[:2]
+    out = torch.empty((n, *x.shape[2:], c), dtype=dtype, device=x.device)
+    call("ncdhw_to_ndhwc", _p(x), _p(out), n, c, x[0, 0].numel(), _dt(out), _s())
+    return out
+
+
+def to_channels_first(x):
+    """[N,X,Y,Z,C] -> [N,C,X,Y,Z] fp32 (a real copy; use ``x.permute(0,4,1,2,3)`` for a free view)."""
+    _chk(x)
+    n, c = x.shape[0], x.shape[-1]
+    out = torch.empty((n, c, *x.shape[1:4]), dtype=torch.float32, device=x.device)
+    call("ndhwc_to_ncdhw", _p(x), _p(out), n, c, x[0, ..., 0].numel(), _dt(x), _s())
+    return out
+
+
+# ======================================================================================================================
+# flat-arena optimiser
+# ======================================================================================================================
+def grad_sumsq(grad_flat, out):
+    call("grad_sumsq", _p(grad_flat), grad_flat.numel(), _p(out), _s())
+
+
+def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step):
+    call("adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), float(max_norm), float(lr), float(betas[0]), float(betas[1]),
+         float(eps), float(wd), int(step), _s())

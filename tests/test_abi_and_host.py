@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/nerfrpn.h declares; host-side logic."""
+import itertools
+import os
+import subprocess
+
+import pytest
+import torch
+
+from nerf_rpn_amd import lib
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(lib.SO_PATH):
+        lib.build()
+    names = lib.declared_symbols()
+    assert len(names) >= 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.SO_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    L = lib.load()   # also binds argtypes for every prototype; AttributeError on mismatch
+    assert L.nrpn_abi_version() == 1
+    assert lib.query("anchor_table_words", 4, 13) == 2 + 32 + 6 * 4 * 13
+    assert lib.query("pool_out_size", 40, 2, 2, 0, 1) == 20 and lib.query("pool_out_size", 5, 2, 2, 0, 1) == 3
+    assert lib.query("pool_out_size", 80, 3, 2, 1, 0) == 40
+
+
+def test_argument_errors_are_reported_not_fatal():
+    with pytest.raises(lib.NrpnError, match="box_dim"):
+        lib.call("iou3d_matrix_f32", 0, 0, 0, 1, 1, 5, 0)
+    with pytest.raises(lib.NrpnError, match="ksize"):
+        lib.call("conv3d_fwd", 1, 1, 0, 1, 1, 4, 4, 4, 64, 64, 64, 5, 0, 0, 0)
+
+
+def test_product_path_has_no_cpu_fallback():
+    from nerf_rpn_amd import ops
+    with pytest.raises(lib.NrpnError, match="non-CUDA"):
+        ops.iou3d_pair(torch.zeros(1, 7), torch.zeros(1, 7))
+
+
+def test_anchor_table_and_ratio_order():
+    from nerf_rpn_amd import ops
+    from oracle import anchors as OA
+    assert tuple(ops.unique_ratio_permutations(ops.ASPECT_RATIOS[0])) == OA.RATIO_ORDER
+    t = ops.AnchorTable((160, 160, 160), [(40,) * 3, (20,) * 3, (10,) * 3, (5,) * 3], device="cpu")
+    assert t.A == 13 and t.total == 950625 and t.offsets == [0, 832000, 936000, 949000, 950625]
+    assert t.strides == [(4,) * 3, (8,) * 3, (16,) * 3, (32,) * 3]
+    t2 = ops.AnchorTable((200, 200, 130), [(50, 50, 33)] * 4, device="cpu")
+    assert t2.strides[0] == (4, 4, 3)   # floor stride, quirk B2
+    for s in ops.ANCHOR_SIZES:
+        assert torch.equal(ops.base_anchor_table(s, ops.ASPECT_RATIOS[0]), OA.base_anchors(s))
+
+
+def test_state_dict_keys_match_reference_layout():
+    from nerf_rpn_amd.model import VGG_FPN, RPNHead
+    from oracle import nets
+    for res in (160, 64):
+        a, b = VGG_FPN("EF", 4, True, res), nets.VGGFPN("EF", 4, res)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys()) and len(sa) == 135
+        assert all(sa[k].shape == sb[k].shape for k in sa)
+    for rot in (False, True):
+        a, b = RPNHead(256, 13, 4, rotate=rot), nets.RPNHead(256, 13, 4, rot)
+        assert {k: v.shape for k, v in a.state_dict().items()} == {k: v.shape for k, v in b.state_dict().items()}
