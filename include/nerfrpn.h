@@ -234,12 +234,13 @@ int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtype, int dst_
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 arena.  [a21]  (clip_grad_norm_ + AdamW, run_rpn.py:345-349,390-395)
- *   sumsq: f32 device scalar (zeroed by nrpn_grad_sumsq); step applies g *= min(1, max_norm/(sqrt(sumsq)+1e-6)),
+ *   grad_scale folds the 1/world_size of the data-parallel mean into both kernels (sum all-reduce, no extra pass).
+ *   sumsq: f32 device scalar = sum((g*grad_scale)^2) (zeroed by nrpn_grad_sumsq); step applies g *= grad_scale * min(1, max_norm/(sqrt(sumsq)+1e-6)),
  *   then decoupled-weight-decay Adam with bias correction (torch.optim.AdamW semantics).
  * ---------------------------------------------------------------------------------------------- */
-int nrpn_grad_sumsq(const float *grad, int64_t count, float *sumsq, nrpn_stream_t stream);
+int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scale, float *sumsq, nrpn_stream_t stream);
 int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count,
-                    const float *sumsq, float max_norm, float lr, float beta1, float beta2, float eps,
+                    const float *sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, nrpn_stream_t stream);
 
 #ifdef __cplusplus

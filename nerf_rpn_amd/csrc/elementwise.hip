@@ -523,34 +523,34 @@ extern "C" int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtyp
 // =====================================================================================================================
 // optimiser on the flat fp32 arena
 // =====================================================================================================================
-__global__ void sumsq_kernel(const float *__restrict__ g, long long count, float *__restrict__ out) {
+__global__ void sumsq_kernel(const float *__restrict__ g, long long count, float scale, float *__restrict__ out) {
   __shared__ float sh[4];
   float s = 0.f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) { const float t = g[i] * scale; s += t * t; }
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
-extern "C" int nrpn_grad_sumsq(const float *grad, int64_t count, float *sumsq, nrpn_stream_t stream) {
+extern "C" int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scale, float *sumsq, nrpn_stream_t stream) {
   NRPN_REQUIRE(grad && sumsq && count > 0, "grad_sumsq: bad args");
   hipStream_t st = as_stream(stream);
   NRPN_HIP(hipMemsetAsync(sumsq, 0, 4, st));
   int blocks = ew_blocks(count);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grad, (long long)count, sumsq);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grad, (long long)count, grad_scale, sumsq);
   NRPN_LAUNCH_CHECK("grad_sumsq");
   return NRPN_OK;
 }
 
 __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long long count,
-                             const float *__restrict__ sumsq, float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
-                             float bc2_sqrt) {
-  float coef = 1.0f;
+                             const float *__restrict__ sumsq, float grad_scale, float max_norm, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt) {
+  float coef = grad_scale;
   if (sumsq && max_norm > 0.f) {
     const float norm = sqrtf(*sumsq);
-    coef = fminf(1.0f, max_norm / (norm + 1e-6f));
+    coef = grad_scale * fminf(1.0f, max_norm / (norm + 1e-6f));
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
@@ -566,13 +566,13 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
 }
 
 extern "C" int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count, const float *sumsq,
-                               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                nrpn_stream_t stream) {
   NRPN_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, "adamw_step: bad args");
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, (long long)count,
-                     sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+                     sumsq, grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
   NRPN_LAUNCH_CHECK("adamw_step");
   return NRPN_OK;
 }

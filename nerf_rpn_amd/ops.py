@@ -579,10 +579,10 @@ def to_channels_first(x):
 # ======================================================================================================================
 # flat-arena optimiser
 # ======================================================================================================================
-def grad_sumsq(grad_flat, out):
-    call("grad_sumsq", _p(grad_flat), grad_flat.numel(), _p(out), _s())
+def grad_sumsq(grad_flat, out, grad_scale=1.0):
+    call("grad_sumsq", _p(grad_flat), grad_flat.numel(), float(grad_scale), _p(out), _s())
 
 
-def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step):
-    call("adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), float(max_norm), float(lr), float(betas[0]), float(betas[1]),
+def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step, grad_scale=1.0):
+    call("adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), float(grad_scale), float(max_norm), float(lr), float(betas[0]), float(betas[1]),
          float(eps), float(wd), int(step), _s())

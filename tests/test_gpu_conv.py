@@ -1,0 +1,204 @@
+"""GPU parity: conv3d family + BN / pool / upsample / optimiser kernels vs a plain torch fp32 CPU reference of the
+same op (fp32 kernels: 1e-4-class tolerances; bf16 kernels: bf16-rounded inputs, fp32 accumulate, 2e-2)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def cf(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12)).item()
+
+
+CASES = [  # (N, grid, Cin, Cout, k)
+    (2, (7, 6, 5), 64, 96, 3), (1, (9, 8, 8), 16, 64, 3), (1, (5, 5, 5), 128, 256, 3), (2, (6, 5, 4), 256, 256, 1),
+    (1, (10, 10, 10), 64, 128, 1), (1, (4, 4, 3), 32, 13, 1)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_forward_backward(case, dtype, dev):
+    from nerf_rpn_amd import ops
+    from nerf_rpn_amd.model import hip_nn
+    n, grid, cin, cout, k = case
+    if dtype == torch.bfloat16 and (cin * 2) % 64:
+        pytest.skip("Cin*2 must be a multiple of 64 bytes")
+    if (cout * (4 if dtype == torch.float32 else 2)) % 16:
+        pytest.skip("wgrad needs 16-byte rows; small heads go through the padded fused-head GEMM")
+    torch.manual_seed(0)
+    conv = nn.Conv3d(cin, cout, k, padding=k // 2)
+    x = torch.randn(n, cin, *grid)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        conv.weight.data = conv.weight.data.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(conv(xr))
+    gy = torch.randn_like(yr)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+    ref = dict(y=yr.detach(), dx=xr.grad, dw=conv.weight.grad.clone(), db=conv.bias.grad.clone())
+    conv.zero_grad()
+    hconv = nn.Conv3d(cin, cout, k, padding=k // 2).to(dev)
+    hconv.load_state_dict(conv.state_dict())
+    xh = cl(x).to(dev).to(dtype).requires_grad_(True)
+    yh = hip_nn.conv3d(hconv, xh, relu=True)
+    yh.backward(cl(gy).to(dev).to(dtype))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert relerr(cf(yh.detach().float().cpu()), ref["y"]) < tol
+    assert relerr(cf(xh.grad.float().cpu()), ref["dx"]) < tol
+    assert relerr(hconv.weight.grad.cpu(), ref["dw"]) < tol
+    assert relerr(hconv.bias.grad.cpu(), ref["db"]) < tol
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+def test_wgrad_bf16_transpose_read_modes(tr, dev):
+    """Both bf16 operand-fetch modes (ds_read_b64_tr_b16 and the scalar gather) must give the same weight gradient."""
+    from nerf_rpn_amd import lib
+    from nerf_rpn_amd.model import hip_nn
+    lib.call("set_wgrad_transpose_read", tr)
+    try:
+        torch.manual_seed(1)
+        conv = nn.Conv3d(64, 128, 3, padding=1)
+        x = torch.randn(1, 64, 6, 7, 5).bfloat16().float()
+        xr = x.clone().requires_grad_(True)
+        y = conv(xr)
+        gy = torch.randn_like(y).bfloat16().float()
+        y.backward(gy)
+        h = nn.Conv3d(64, 128, 3, padding=1).to(dev)
+        h.load_state_dict(conv.state_dict())
+        xh = cl(x).to(dev).bfloat16().requires_grad_(True)
+        hip_nn.conv3d(h, xh).backward(cl(gy).to(dev).bfloat16())
+        assert relerr(h.weight.grad.cpu(), conv.weight.grad) < 2e-2, f"tr_mode={tr}"
+    finally:
+        lib.call("set_wgrad_transpose_read", 1)
+
+
+@pytest.mark.parametrize("stride,grid", [(2, (16, 14, 13)), (1, (9, 8, 7))])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem(stride, grid, dtype, dev):
+    from nerf_rpn_amd.model import hip_nn
+    torch.manual_seed(0)
+    conv = nn.Conv3d(4, 64, 7, stride=stride, padding=3)
+    x = torch.rand(2, 4, *grid)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        conv.weight.data = conv.weight.data.bfloat16().float()
+    y = conv(x)
+    gy = torch.randn_like(y)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    y.backward(gy)
+    h = nn.Conv3d(4, 64, 7, stride=stride, padding=3).to(dev)
+    h.load_state_dict(conv.state_dict())
+    yh = hip_nn.conv3d(h, cl(x).to(dev).to(dtype))
+    assert tuple(yh.shape[1:4]) == tuple(y.shape[2:])
+    yh.backward(cl(gy).to(dev).to(dtype))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert relerr(cf(yh.detach().float().cpu()), y.detach()) < tol
+    assert relerr(h.weight.grad.cpu(), conv.weight.grad) < tol
+    assert relerr(h.bias.grad.cpu(), conv.bias.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_relu(dtype, dev):
+    from nerf_rpn_amd.model import hip_nn
+    torch.manual_seed(0)
+    c = 128
+    bn = nn.BatchNorm3d(c)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    x = torch.randn(2, c, 9, 7, 6) * 2 + 0.7
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    y = F.relu(bn(xr))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    h = nn.BatchNorm3d(c).to(dev)
+    h.load_state_dict({k: v.clone() for k, v in nn.BatchNorm3d(c).state_dict().items()})
+    h.weight.data.copy_(bn.weight.data)
+    h.bias.data.copy_(bn.bias.data)
+    xh = cl(x).to(dev).to(dtype).requires_grad_(True)
+    yh = hip_nn.batch_norm(h, xh, True)
+    yh.backward(cl(gy).to(dev).to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert relerr(cf(yh.detach().float().cpu()), y.detach()) < tol
+    assert relerr(cf(xh.grad.float().cpu()), xr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert relerr(h.weight.grad.cpu(), bn.weight.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert relerr(h.bias.grad.cpu(), bn.bias.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert torch.allclose(h.running_mean.cpu(), bn.running_mean, atol=1e-5) and torch.allclose(h.running_var.cpu(), bn.running_var, rtol=1e-4)
+    assert int(h.num_batches_tracked) == 1
+    h.eval(); bn.eval()
+    with torch.no_grad():
+        ye = hip_nn.batch_norm(h, cl(x).to(dev).to(dtype), False)
+        assert relerr(cf(ye.float().cpu()), bn(x)) < tol * 5
+
+
+@pytest.mark.parametrize("cfg", [(3, 2, 1, False, (16, 15, 13)), (2, 2, 0, True, (9, 8, 5)), (2, 2, 0, True, (10, 10, 10))])
+def test_maxpool(cfg, dev):
+    from nerf_rpn_amd import ops
+    k, s, p, ceil_mode, grid = cfg
+    torch.manual_seed(0)
+    x = F.relu(torch.randn(2, 64, *grid))      # many exact-zero ties, as after ReLU
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool3d(xr, k, s, p, ceil_mode=ceil_mode)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xh = cl(x).to(dev).requires_grad_(True)
+    yh = ops.MaxPoolFn.apply(xh, k, s, p, ceil_mode)
+    assert torch.equal(cf(yh.detach().cpu()), y.detach())
+    yh.backward(cl(gy).to(dev))
+    assert torch.allclose(cf(xh.grad.cpu()), xr.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("sizes", [((10, 10, 10), (5, 5, 5)), ((9, 7, 5), (5, 4, 3)), ((33, 20, 7), (17, 10, 4))])
+def test_upsample_add(sizes, dev):
+    from nerf_rpn_amd import ops
+    fine_s, coarse_s = sizes
+    torch.manual_seed(0)
+    fine, coarse = torch.randn(2, 32, *fine_s), torch.randn(2, 32, *coarse_s)
+    fr, cr = fine.clone().requires_grad_(True), coarse.clone().requires_grad_(True)
+    y = fr + F.interpolate(cr, size=fine_s, mode="nearest")
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    fh = cl(fine).to(dev).requires_grad_(True)
+    ch = cl(coarse).to(dev).requires_grad_(True)
+    yh = ops.UpsampleAddFn.apply(fh * 1.0, ch)
+    assert torch.allclose(cf(yh.detach().cpu()), y.detach(), atol=1e-6)
+    yh.backward(cl(gy).to(dev))
+    assert torch.allclose(cf(ch.grad.cpu()), cr.grad, atol=1e-5) and torch.allclose(cf(fh.grad.cpu()), fr.grad, atol=1e-6)
+
+
+def test_layout_roundtrip_and_adamw(dev):
+    from nerf_rpn_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 5, 7, 6, 3)
+    c = ops.to_channels_last(x.to(dev), torch.float32)
+    assert torch.equal(c.cpu(), cl(x)) and torch.equal(ops.to_channels_first(c).cpu(), x)
+    assert torch.equal(ops.to_channels_last(x.to(dev), torch.bfloat16).cpu(), cl(x).bfloat16())
+    p = torch.randn(10007)
+    g = torch.randn(10007) * 3
+    ref = nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=3e-4, weight_decay=1e-2)
+    ph, m, v = p.to(dev), torch.zeros(10007, device=dev), torch.zeros(10007, device=dev)
+    ss = torch.zeros(1, device=dev)
+    for step in (1, 2, 3):
+        ref.grad = g.clone() * step
+        torch.nn.utils.clip_grad_norm_([ref], 0.1)
+        opt.step()
+        gh = (g * step).to(dev)
+        ops.grad_sumsq(gh, ss)
+        ops.adamw_step(ph, gh, m, v, ss, 0.1, 3e-4, (0.9, 0.999), 1e-8, 1e-2, step)
+    assert torch.allclose(ph.cpu(), ref.detach(), atol=1e-6)

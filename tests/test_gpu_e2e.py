@@ -1,0 +1,111 @@
+"""GPU parity, end to end: the HIP model against golden vectors captured from the reference (VGG19-EF + FPN + RPN with
+seeded, tie-free weights): features, proposals / scores / levels (eval), losses, sampled sets and gradients (train)."""
+import numpy as np
+import pytest
+import torch
+
+from fixture_init import seeded_state
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def build(rotated, resolution, dev, reg_loss="smooth_l1", pre=2500, post=2500):
+    from nerf_rpn_amd.model import VGG_FPN, RPNHead, NeRFRegionProposalNetwork, AnchorGenerator3D
+    from nerf_rpn_amd import ops
+    bb = VGG_FPN("EF", 4, True, resolution)
+    hd = RPNHead(256, 13, 4, rotate=rotated)
+    seeded_state(bb, 1)
+    seeded_state(hd, 2)
+    m = NeRFRegionProposalNetwork(bb, AnchorGenerator3D(ops.ANCHOR_SIZES, ops.ASPECT_RATIOS), hd, rpn_pre_nms_top_n_train=2500,
+                                  rpn_pre_nms_top_n_test=pre, rpn_post_nms_top_n_train=2500, rpn_post_nms_top_n_test=post,
+                                  rpn_nms_thresh=0.3, rpn_fg_iou_thresh=0.35, rpn_bg_iou_thresh=0.2, rpn_batch_size_per_mesh=256,
+                                  rpn_positive_fraction=0.5, rpn_score_thresh=0.0, rotated_bbox=rotated, reg_loss_type=reg_loss)
+    return m.to(dev)
+
+
+def scene(shape, seed):
+    return torch.rand(4, *[int(s) for s in shape], generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("name", ["eval_aabb_s2", "eval_obb_s2", "eval_obb_s1_cfg0", "eval_aabb_batch2"])
+def test_eval_matches_reference(name, golden, dev):
+    g = golden(name)
+    m = build(bool(g["rotated"]), int(g["resolution"]), dev, pre=int(g["pre"])).eval()
+    xs = [scene(s, 100 + i).to(dev) for i, s in enumerate(g["shapes"])]
+    with torch.no_grad():
+        (feats, props, lvls), losses, scores = m(xs)
+    assert losses == {}
+    for i, f in enumerate(feats):
+        assert list(f.shape) == g[f"feat{i}_shape"].tolist()
+        got = f.float().contiguous().reshape(-1)[T(g[f"feat{i}_idx"], dev)].cpu()
+        ref = T(g[f"feat{i}_val"])
+        assert torch.allclose(got, ref, atol=1e-4 * max(1.0, ref.abs().max().item()), rtol=1e-4), (name, i, (got - ref).abs().max())
+    for i in range(len(xs)):
+        rp, rs, rl = T(g[f"proposals{i}"]), T(g[f"scores{i}"]), T(g[f"levels{i}"])
+        assert props[i].shape == rp.shape, (name, props[i].shape, rp.shape)       # same survivors => same NMS decisions
+        assert torch.allclose(scores[i].cpu(), rs, atol=1e-4)
+        assert torch.equal(lvls[i].cpu(), rl)
+        assert torch.allclose(props[i].cpu(), rp, atol=2e-3, rtol=1e-4), (props[i].cpu() - rp).abs().max()
+
+
+@pytest.mark.parametrize("name", ["train_aabb", "train_obb", "train_obb_iou", "train_obb_giou", "train_obb_diou", "train_aabb_batch2"])
+def test_train_matches_reference(name, golden, dev):
+    g = golden(name)
+    rot = bool(g["rotated"])
+    m = build(rot, 160, dev, str(g["reg_loss_type"])).train()
+    xs = [scene(s, 200 + i).to(dev) for i, s in enumerate(g["shapes"])]
+    gts = [T(g[f"gt{i}"], dev) for i in range(len(xs))]
+    pos, neg = T(g["pos_idx"], dev), T(g["neg_idx"], dev)
+    m.rpn.sampler_hook = lambda labels: (pos, neg)
+    _, losses, _ = m(xs, gts)
+    assert torch.equal(torch.cat(m.rpn.last_aux["labels"]).cpu().to(torch.int8), T(g["labels"]))     # matcher: exact
+    for k in ("loss_objectness", "loss_rpn_box_reg", "loss_rpn_box_reg_2d"):
+        ref = float(g[k])
+        assert abs(losses[k].item() - ref) < 1e-4 * max(1.0, abs(ref)), (name, k, losses[k].item(), ref)
+    (losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"] + 0.0 * losses["loss_rpn_box_reg_2d"]).backward()
+    params = dict(m.backbone.named_parameters())
+    params.update({"head." + k: v for k, v in m.rpn.head.named_parameters()})
+    worst = 0.0
+    for k, p in params.items():
+        gn = float(g["gnorm/" + k])
+        assert p.grad is not None, k
+        if "grad/" + k in g:
+            ref = T(g["grad/" + k])
+            got = p.grad.cpu()
+        else:
+            ref = T(g["gval/" + k])
+            got = p.grad.reshape(-1)[T(g["gidx/" + k], dev)].cpu()
+        # conv biases in front of a train-mode BatchNorm have mathematically-zero gradients (rounding noise only)
+        err = max(0.0, (got - ref).abs().max().item() - 5e-5) / (ref.abs().max().item() + 1e-12)
+        worst = max(worst, err)
+        assert err < 5e-3, (name, k, err)
+        assert abs(p.grad.norm().item() - gn) < 5e-3 * gn + 1e-4, (name, k)
+
+
+def test_proposal_npz_contract(tmp_path, dev):
+    """The .npz a trainer writes (reference run_rpn.py:453) has keys 'proposal' [K,6|7] f32 and 'score' [K] f32."""
+    m = build(True, 64, dev, pre=300).eval()
+    with torch.no_grad():
+        (_, props, _), _, scores = m([scene((16, 16, 16), 3).to(dev)])
+    p = tmp_path / "scene.npz"
+    np.savez(p, proposal=props[0][:, :7].cpu(), score=scores[0].cpu())
+    z = np.load(p)
+    assert z["proposal"].dtype == np.float32 and z["proposal"].shape[1] == 7 and z["score"].shape == (z["proposal"].shape[0],)
+
+
+def test_bf16_forward_is_close_to_fp32(dev):
+    m = build(False, 160, dev).eval()
+    x = [scene((48, 48, 48), 100).to(dev)]
+    with torch.no_grad():
+        (f32, _, _), _, _ = m(x)
+        m.set_compute_dtype(torch.bfloat16)
+        (f16, p16, _), _, s16 = m(x)
+    for a, b in zip(f32, f16):
+        rel = ((a.float() - b.float()).abs().max() / a.float().abs().max()).item()
+        assert rel < 0.08, rel
+    assert p16[0].shape[0] > 0 and torch.isfinite(s16[0]).all()
