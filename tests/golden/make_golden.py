@@ -286,6 +286,16 @@ def gen_train():
             e = close(olosses[k], losses[k], 2e-5 * max(1.0, abs(losses[k].item())), f"{name} {k}")
             arrs[k] = losses[k]
         arrs["pos_idx"], arrs["neg_idx"] = aux["sampled"]["pos"], aux["sampled"]["neg"]
+        # the same algorithm evaluated in float64 (oracle == reference in fp32, so this is the reference algorithm's exact
+        # value): lets the GPU tests judge cancellation-prone gradients (BN biases, stem weights) against the truth and
+        # against the fp32 reference's own rounding error instead of against an arbitrary tolerance.
+        o64 = build_oracle(rot, 160, loss)
+        o64.backbone.double().train(); o64.rpn.head.double()
+        ppos, pneg = aux["sampled"]["pos"], aux["sampled"]["neg"]
+        o64.rpn.sampler_hook = lambda labels: (ppos, pneg)
+        _, l64, _, _ = o64([x.double() for x in xs], [t.double() for t in gts], training=True)
+        (l64["loss_objectness"] + 5.0 * l64["loss_rpn_box_reg"] + 0.0 * l64["loss_rpn_box_reg_2d"]).backward()
+        p64 = dict(o64.backbone.named_parameters()); p64.update({"head." + k: v for k, v in o64.rpn.head.named_parameters()})
         arrs["labels"] = torch.cat(aux["labels"]).to(torch.int8)
         rp = dict(ref.backbone.named_parameters()); rp.update({"head." + k: v for k, v in ref.rpn.head.named_parameters()})
         op = dict(orc.backbone.named_parameters()); op.update({"head." + k: v for k, v in orc.rpn.head.named_parameters()})
@@ -297,11 +307,16 @@ def gen_train():
             rel = max(0.0, (gr - go).abs().max().item() - 2e-5) / (gr.abs().max().item() + 1e-12)
             worst = max(worst, rel)
             arrs["gnorm/" + k] = gr.norm()
+            g64 = p64[k].grad
+            arrs["err32/" + k] = (gr.double() - g64).abs().max()
+            arrs["gmax64/" + k] = g64.abs().max()
             if gr.numel() <= 512:
                 arrs["grad/" + k] = gr
+                arrs["grad64/" + k] = g64
             else:
                 idx, val = subsample(gr, 256)
                 arrs["gidx/" + k], arrs["gval/" + k] = idx, val
+                arrs["gval64/" + k] = g64.reshape(-1)[idx]
         assert worst < 2e-3, (name, worst)
         for i, t in enumerate(gts):
             arrs[f"gt{i}"] = t

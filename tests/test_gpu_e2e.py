@@ -47,10 +47,29 @@ def test_eval_matches_reference(name, golden, dev):
         assert torch.allclose(got, ref, atol=1e-4 * max(1.0, ref.abs().max().item()), rtol=1e-4), (name, i, (got - ref).abs().max())
     for i in range(len(xs)):
         rp, rs, rl = T(g[f"proposals{i}"]), T(g[f"scores{i}"]), T(g[f"levels{i}"])
-        assert props[i].shape == rp.shape, (name, props[i].shape, rp.shape)       # same survivors => same NMS decisions
-        assert torch.allclose(scores[i].cpu(), rs, atol=1e-4)
-        assert torch.equal(lvls[i].cpu(), rl)
-        assert torch.allclose(props[i].cpu(), rp, atol=2e-3, rtol=1e-4), (props[i].cpu() - rp).abs().max()
+        gp, gs, gl = props[i].cpu(), scores[i].cpu(), lvls[i].cpu()
+        # Anchors in the zero-padded part of a batched scene get logit -inf => score exactly 0: thousands of exact ties whose
+        # top-k order is unspecified in torch (quirk B7).  They sort last and can never suppress a positive-score box, so
+        # parity is defined on the positive-score proposals.
+        if len(xs) > 1:
+            gp, gl, gs = gp[gs > 0], gl[gs > 0], gs[gs > 0]
+            rp, rl, rs = rp[rs > 0], rl[rs > 0], rs[rs > 0]
+        assert gp.shape == rp.shape, (name, gp.shape, rp.shape)
+        assert torch.allclose(gs, rs, atol=1e-4)
+        # rows are ordered by score; two proposals whose scores differ by < 2e-6 may legitimately swap (GPU expf/sigmoid
+        # differ from the CPU's in the last ulp), so each reference row is matched to the best row among its score-ties.
+        near = (gs[None, :] - rs[:, None]).abs() <= 2e-6
+        diff = (gp[None, :, :] - rp[:, None, :]).abs()
+        tol = 2e-3 + 1e-4 * rp.abs()[:, None, :]
+        ok = ((diff <= tol).all(dim=2) & near & (gl[None, :] == rl[:, None])).any(dim=1)
+        if not ok.all():
+            bad = torch.where(~ok)[0]
+            j = diff[bad].amax(dim=2).argmin(dim=1)
+            msg = [(int(b), rp[b].tolist(), float(rs[b]), float(rl[b]), int(jj), gp[jj].tolist(), float(gs[jj]), float(gl[jj]))
+                   for b, jj in zip(bad[:4], j[:4])]
+            raise AssertionError((name, int((~ok).sum()), msg))
+        swapped = int((~torch.isclose(gp, rp, atol=2e-3, rtol=1e-4).all(dim=1)).sum())
+        assert swapped <= max(4, rp.shape[0] // 50), swapped
 
 
 @pytest.mark.parametrize("name", ["train_aabb", "train_obb", "train_obb_iou", "train_obb_giou", "train_obb_diou", "train_aabb_batch2"])
@@ -70,21 +89,27 @@ def test_train_matches_reference(name, golden, dev):
     (losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"] + 0.0 * losses["loss_rpn_box_reg_2d"]).backward()
     params = dict(m.backbone.named_parameters())
     params.update({"head." + k: v for k, v in m.rpn.head.named_parameters()})
-    worst = 0.0
+    # Gradient parity.  Each kernel's backward is checked to 2e-5 in test_gpu_conv.py; end to end, the fp32 reference itself is
+    # only defined up to its own rounding (sparse gradients from <= 256 sampled anchors, BatchNorm cancellation, max-pool
+    # routing): `err32/<param>` in the fixture is the reference's distance from the same algorithm run in float64.  The HIP
+    # result must agree with the reference within max(0.5 % of the gradient scale, 4 x that intrinsic uncertainty).
+    flat_ref, flat_got = [], []
     for k, p in params.items():
-        gn = float(g["gnorm/" + k])
         assert p.grad is not None, k
         if "grad/" + k in g:
-            ref = T(g["grad/" + k])
-            got = p.grad.cpu()
+            ref, got = T(g["grad/" + k]), p.grad.cpu()
         else:
-            ref = T(g["gval/" + k])
-            got = p.grad.reshape(-1)[T(g["gidx/" + k], dev)].cpu()
-        # conv biases in front of a train-mode BatchNorm have mathematically-zero gradients (rounding noise only)
-        err = max(0.0, (got - ref).abs().max().item() - 5e-5) / (ref.abs().max().item() + 1e-12)
-        worst = max(worst, err)
-        assert err < 5e-3, (name, k, err)
-        assert abs(p.grad.norm().item() - gn) < 5e-3 * gn + 1e-4, (name, k)
+            ref, got = T(g["gval/" + k]), p.grad.reshape(-1)[T(g["gidx/" + k], dev)].cpu()
+        scale = float(g["gmax64/" + k])
+        err = (got - ref).abs().max().item()
+        allowed = max(5e-3 * scale, 4.0 * float(g["err32/" + k])) + 5e-5
+        assert err <= allowed, (name, k, err, allowed, scale)
+        if scale > 1e-6:
+            flat_ref.append(ref.reshape(-1) / scale)
+            flat_got.append(got.reshape(-1) / scale)
+    a, b = torch.cat(flat_ref).double(), torch.cat(flat_got).double()
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    assert cos > 0.995, (name, cos)
 
 
 def test_proposal_npz_contract(tmp_path, dev):
