@@ -557,14 +557,24 @@ class UpsampleAddFn(torch.autograd.Function):
         return d, dc
 
 
+class _ToChannelsLast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        x = x.float().contiguous()
+        _chk(x)
+        n, c = x.shape[:2]
+        out = torch.empty((n, *x.shape[2:], c), dtype=dtype, device=x.device)
+        call("ncdhw_to_ndhwc", _p(x), _p(out), n, c, x[0, 0].numel(), _dt(out), _s())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_channels_first(g.contiguous()), None
+
+
 def to_channels_last(x, dtype):
-    """[N,C,X,Y,Z] fp32 -> [N,X,Y,Z,C] dtype."""
-    x = x.float().contiguous()
-    _chk(x)
-    n, c = x.shape[:2]
-    out = torch.empty((n, *x.shape[2:], c), dtype=dtype, device=x.device)
-    call("ncdhw_to_ndhwc", _p(x), _p(out), n, c, x[0, 0].numel(), _dt(out), _s())
-    return out
+    """[N,C,X,Y,Z] fp32 -> [N,X,Y,Z,C] dtype (differentiable)."""
+    return _ToChannelsLast.apply(x, dtype)
 
 
 def to_channels_first(x):
