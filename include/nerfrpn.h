@@ -178,12 +178,17 @@ int nrpn_pack_conv_weight(const float *w_ref, int cout, int cin, int taps, int d
 /* packed fp32 weight gradient [taps][rows_total][Cin] -> reference layout (optionally accumulating into gw_ref) */
 int nrpn_unpack_conv_wgrad(const float *gw_packed, int cout, int cin, int taps, int rows_total, int row_offset,
                            float *gw_ref, int accumulate, nrpn_stream_t stream);
+/* `workspace` (nrpn_conv3d_fwd_workspace_bytes; may be NULL = never split): for small grids the K loop is split over
+ * blockIdx.z and fp32 partials are reduced through it so the 10^3 / 5^3 pyramid levels still fill 256 CUs. */
+size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
 int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
-                    int cout, int wrows, int ksize, int dtype, int flags, nrpn_stream_t stream);
+                    int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream);
 /* wgrad: gw_packed f32 [taps][wrows][Cin] (zero-filled by the call, split-K partials are atomically added);
  * optional gbias f32 [Cout] = column sums of dy. */
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
                       int cin, int cout, int wrows, int ksize, int dtype, nrpn_stream_t stream);
+/* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
+int nrpn_set_conv_kstep_bytes(int kb);
 int nrpn_colsum(const void *dy, long long rows, int c, int dtype, float *out, nrpn_stream_t stream);
 /* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
 int nrpn_set_wgrad_transpose_read(int on);

@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((ext_vector_type(4))) short s4v;
 typedef unsigned short bf16s;  // raw bf16 storage
 
+static int g_conv_kb_value();
 template <typename T> struct Mma;
 template <> struct Mma<float> {
   static __device__ __forceinline__ void run(f16v &acc, const f4 &a, const f4 &b) {
@@ -57,32 +58,40 @@ struct ConvArgs {
   int taps;           // 1, 27 (MODE 0) or 343 (MODE 1)
   int stride;         // MODE 1 only
   int flags;
+  int ksplit;         // > 1: blockIdx.z owns a slice of the K loop and atomically adds fp32 partials into `ws`
+  float *ws;          // [M][Cout] fp32, zero-filled by the launcher (split-K only)
 };
 
-template <typename T, int BN, int MODE, bool OUTF32>
+template <typename T, int BN, int MODE, bool OUTF32, int KB>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   constexpr int BM = 128;
   constexpr int WAVES_N = (BN == 128) ? 2 : 1;
   constexpr int TM = (BN == 128) ? 2 : 1;   // 32x32 tiles per wave along M
   constexpr int TN = 2;                      // ... along N
-  constexpr int KE = 64 / (int)sizeof(T);    // K elements per step
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  constexpr int KE = KB / (int)sizeof(T);    // K elements per step
+  constexpr int PPR = KB / 16;               // 16-byte pieces per tile row (4 or 8)
+  constexpr int RSTEP = 256 / PPR;           // row distance between a thread's pieces
+  constexpr int A_RPT = BM / RSTEP;          // A rows per thread (2 or 4)
+  constexpr int B_RPT = BN / RSTEP;          // B rows per thread (1, 2 or 4)
+  constexpr int SWZ_SH = (KB == 64) ? 2 : 1; // rows per 256-byte LDS bank row = 256 / KB
+  constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB;
   __shared__ __attribute__((aligned(16))) char lds[2 * (A_BYTES + B_BYTES)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int lr = tid >> 2, ls = tid & 3;
+  const int lr = tid / PPR, ls = tid % PPR;
 
-  // ---- loader state: two A rows (lr, lr+64) and up to two B rows per thread, one 16-byte slot each
-  long long a_off[2];    // element offset of the row's voxel (MODE 0) / unused (MODE 1)
-  int a_x[2], a_y[2], a_z[2];
-  bool a_ok[2];
-  long long a_nbase[2];  // MODE 1: element offset of batch n
+  // ---- loader state per A row: element offset of the voxel, per-scene coordinates, and a 27-bit mask of in-bounds taps
+  long long a_off[A_RPT];
+  int a_x[A_RPT], a_y[A_RPT], a_z[A_RPT];
+  bool a_ok[A_RPT];
+  unsigned a_mask[A_RPT];
+  long long a_nbase[A_RPT];  // MODE 1: element offset of batch n
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const long long v = m0 + lr + 64 * i;
+  for (int i = 0; i < A_RPT; ++i) {
+    const long long v = m0 + lr + RSTEP * i;
     a_ok[i] = v < p.M;
     const long long vv = a_ok[i] ? v : 0;
     const int oz = (int)(vv % p.OZ);
@@ -92,10 +101,23 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const int ox = (int)(t2 % p.OX);
     const long long n = t2 / p.OX;
     a_x[i] = ox; a_y[i] = oy; a_z[i] = oz;
-    if (MODE == 0) a_off[i] = vv * p.Cin;
-    else { a_off[i] = 0; a_nbase[i] = n * (long long)p.X * p.Y * p.Z * 4; }
+    a_off[i] = (MODE == 0) ? vv * p.Cin : 0;
+    a_nbase[i] = (MODE == 0) ? 0 : n * (long long)p.X * p.Y * p.Z * 4;
+    unsigned m = 0;
+    if (MODE == 0 && a_ok[i]) {
+      if (p.taps == 27) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
+          const bool in = (unsigned)(ox + dx) < (unsigned)p.X && (unsigned)(oy + dy) < (unsigned)p.Y && (unsigned)(oz + dz) < (unsigned)p.Z;
+          m |= in ? (1u << t) : 0u;
+        }
+      } else {
+        m = 1u;
+      }
+    }
+    a_mask[i] = m;
   }
-  constexpr int B_ROWS_PER_THREAD = BN / 64;
   const T *wbase = reinterpret_cast<const T *>(p.w);
   const T *xbase = reinterpret_cast<const T *>(p.x);
 
@@ -103,37 +125,51 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   const int nk = (MODE == 0) ? p.taps * cpt : (p.taps * 4 + KE - 1) / KE;        // total K-steps
   const int kpad = nk * KE;                                                        // MODE 1 weight row length
 
-  f4 ra[2], rb[B_ROWS_PER_THREAD];
+  // split-K: this workgroup runs K-steps [ks_begin, ks_end)
+  int ks_begin = 0, ks_end = nk;
+  if (p.ksplit > 1) {
+    const int per = (nk + p.ksplit - 1) / p.ksplit;
+    ks_begin = blockIdx.z * per;
+    ks_end = min(nk, ks_begin + per);
+    if (ks_begin >= ks_end) return;
+  }
+
+  f4 ra[A_RPT], rb[B_RPT];
+  // incremental (tap, chunk) walk of the K loop for MODE 0 -- no divisions in the steady state
+  int l_tap = ks_begin / cpt, l_chunk = ks_begin - l_tap * cpt;
+  int l_dx = 0, l_dy = 0, l_dz = 0;
+  if (p.taps == 27) { l_dx = l_tap / 9 - 1; l_dy = (l_tap / 3) % 3 - 1; l_dz = l_tap % 3 - 1; }
+  const long long w_tap_stride = (long long)p.wrows * p.Cin;
 
   auto load_step = [&](int ks) {
     if (MODE == 0) {
-      const int tap = ks / cpt;
-      const int c0 = (ks - tap * cpt) * KE;
-      int dx = 0, dy = 0, dz = 0;
-      if (p.taps == 27) { dx = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dz = tap % 3 - 1; }
-      const long long shift = ((long long)dx * p.Y * p.Z + (long long)dy * p.Z + dz) * p.Cin + c0;
+      const int c0 = l_chunk * KE;
+      const long long shift = ((long long)l_dx * p.Y * p.Z + (long long)l_dy * p.Z + l_dz) * p.Cin + c0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool in = a_ok[i] && (unsigned)(a_x[i] + dx) < (unsigned)p.X && (unsigned)(a_y[i] + dy) < (unsigned)p.Y &&
-                        (unsigned)(a_z[i] + dz) < (unsigned)p.Z;
+      for (int i = 0; i < A_RPT; ++i) {
+        const bool in = (a_mask[i] >> l_tap) & 1u;
         ra[i] = in ? ldg16(reinterpret_cast<const char *>(xbase + a_off[i] + shift) + ls * 16) : zero4();
       }
+      const T *wt = wbase + (long long)l_tap * w_tap_stride + c0;
 #pragma unroll
-      for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-        const int row = n0 + lr + 64 * i;
-        rb[i] = (row < p.wrows)
-                    ? ldg16(reinterpret_cast<const char *>(wbase + ((long long)tap * p.wrows + row) * p.Cin + c0) + ls * 16)
-                    : zero4();
+      for (int i = 0; i < B_RPT; ++i) {
+        const int row = n0 + lr + RSTEP * i;
+        rb[i] = (row < p.wrows) ? ldg16(reinterpret_cast<const char *>(wt + (long long)row * p.Cin) + ls * 16) : zero4();
+      }
+      if (++l_chunk == cpt) {
+        l_chunk = 0;
+        ++l_tap;
+        if (++l_dz > 1) { l_dz = -1; if (++l_dy > 1) { l_dy = -1; ++l_dx; } }
       }
     } else {
       // stem: slot ls of K-step ks covers taps [t0, t0 + TPS), 4 input channels each
       constexpr int TPS = 16 / (4 * (int)sizeof(T));  // taps per 16-byte slot: 1 (fp32) or 2 (bf16)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < A_RPT; ++i) {
         f4 v = zero4();
 #pragma unroll
         for (int q = 0; q < TPS; ++q) {
-          const int tap = (ks * 4 + ls) * TPS + q;
+          const int tap = (ks * PPR + ls) * TPS + q;
           const int dx = tap / 49, dy = (tap / 7) % 7, dz = tap % 7;
           const int ix = a_x[i] * p.stride - 3 + dx, iy = a_y[i] * p.stride - 3 + dy, iz = a_z[i] * p.stride - 3 + dz;
           const bool in = a_ok[i] && tap < p.taps && (unsigned)ix < (unsigned)p.X && (unsigned)iy < (unsigned)p.Y &&
@@ -150,8 +186,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         ra[i] = v;
       }
 #pragma unroll
-      for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-        const int row = n0 + lr + 64 * i;
+      for (int i = 0; i < B_RPT; ++i) {
+        const int row = n0 + lr + RSTEP * i;
         rb[i] = (row < p.wrows) ? ldg16(reinterpret_cast<const char *>(wbase + (long long)row * kpad + ks * KE) + ls * 16) : zero4();
       }
     }
@@ -161,14 +197,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     char *A = lds + buf * (A_BYTES + B_BYTES);
     char *B = A + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = lr + 64 * i;
-      *reinterpret_cast<f4 *>(A + r * 64 + ((ls ^ ((r >> 2) & 3)) << 4)) = ra[i];
+    for (int i = 0; i < A_RPT; ++i) {
+      const int r = lr + RSTEP * i;
+      *reinterpret_cast<f4 *>(A + r * KB + ((ls ^ ((r >> SWZ_SH) & (PPR - 1))) << 4)) = ra[i];
     }
 #pragma unroll
-    for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-      const int r = lr + 64 * i;
-      *reinterpret_cast<f4 *>(B + r * 64 + ((ls ^ ((r >> 2) & 3)) << 4)) = rb[i];
+    for (int i = 0; i < B_RPT; ++i) {
+      const int r = lr + RSTEP * i;
+      *reinterpret_cast<f4 *>(B + r * KB + ((ls ^ ((r >> SWZ_SH) & (PPR - 1))) << 4)) = rb[i];
     }
   };
 
@@ -180,36 +216,52 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_step(0);
+  load_step(ks_begin);
   store_step(0);
   __syncthreads();
 
   const int fr = lane & 31, fk = lane >> 5;
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_step(ks + 1);
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int buf = (ks - ks_begin) & 1;
+    if (ks + 1 < ks_end) load_step(ks + 1);
     const char *A = lds + buf * (A_BYTES + B_BYTES);
     const char *B = A + A_BYTES;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KB / 32; ++s) {
       f4 af[TM], bfv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int r = (wm * TM + i) * 32 + fr;
-        af[i] = *reinterpret_cast<const f4 *>(A + r * 64 + (((s * 2 + fk) ^ ((r >> 2) & 3)) << 4));
+        af[i] = *reinterpret_cast<const f4 *>(A + r * KB + (((s * 2 + fk) ^ ((r >> SWZ_SH) & (PPR - 1))) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int r = (wn * TN + j) * 32 + fr;
-        bfv[j] = *reinterpret_cast<const f4 *>(B + r * 64 + (((s * 2 + fk) ^ ((r >> 2) & 3)) << 4));
+        bfv[j] = *reinterpret_cast<const f4 *>(B + r * KB + (((s * 2 + fk) ^ ((r >> SWZ_SH) & (PPR - 1))) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bfv[j]);
     }
-    if (ks + 1 < nk) store_step(buf ^ 1);
+    if (ks + 1 < ks_end) store_step(buf ^ 1);
     __syncthreads();
+  }
+
+  if (p.ksplit > 1) {   // partial sums; bias / ReLU / cast happen in splitk_epilogue_kernel
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + fr;
+      if (col >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, lane);
+          if (v < p.M) atomicAdd(p.ws + v * p.Cout + col, acc[i][j][r]);
+        }
+    }
+    return;
   }
 
   // ---- epilogue: bias / ReLU, store channels-last
@@ -236,20 +288,62 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   }
 }
 
+template <typename T, bool OUTF32>
+__global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
+                                       int cout, int relu) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float o = ws[i] + (bias ? bias[i % cout] : 0.f);
+    if (relu) o = fmaxf(o, 0.f);
+    if (OUTF32) reinterpret_cast<float *>(y)[i] = o;
+    else elem<T>::st(reinterpret_cast<T *>(y) + i, o);
+  }
+}
+
+// split the K loop when the (M, N) tiling alone cannot fill 256 CUs (the 10^3 / 5^3 pyramid levels)
+static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes) {
+  const int bn = cout <= 64 ? 64 : 128;
+  const long long tiles = cdiv64(M, 128) * ((cout + bn - 1) / bn);
+  const int kb = (g_conv_kb_value() == 128 && (cin * elem_bytes) % 128 == 0) ? 128 : 64;
+  const int nk = taps * (cin * elem_bytes / kb);
+  if (tiles >= 128 || nk < 16) return 1;
+  long long s = (384 + tiles - 1) / tiles;
+  if (s > nk / 8) s = nk / 8;
+  if (s > 64) s = 64;
+  return s < 2 ? 1 : (int)s;
+}
+
+static int g_conv_kb = 128;   // K-step bytes of the k1/k3 kernels (64 or 128); tuning knob, see tools/bench_conv.py
+static int g_conv_kb_value() { return g_conv_kb; }
+extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
+  if (kb != 64 && kb != 128) return nrpn_fail(NRPN_ERR_ARG, "conv k-step must be 64 or 128 bytes");
+  g_conv_kb = kb;
+  return NRPN_OK;
+}
+
 template <typename T, int MODE>
 static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const int bn = (a.Cout <= 64) ? 64 : 128;
-  dim3 grid((unsigned)cdiv64(a.M, 128), (unsigned)((a.Cout + bn - 1) / bn));
-#define NRPN_LC(BN_, OF_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_>), grid, dim3(256), 0, st, a)
-  if (bn == 64) { if (out_f32) NRPN_LC(64, true); else NRPN_LC(64, false); }
-  else { if (out_f32) NRPN_LC(128, true); else NRPN_LC(128, false); }
+  dim3 grid((unsigned)cdiv64(a.M, 128), (unsigned)((a.Cout + bn - 1) / bn), (unsigned)(a.ksplit > 1 ? a.ksplit : 1));
+  // the 128-byte K-step needs Cin*elemsize % 128 == 0; the stem gather keeps the 64-byte step
+  const bool wide = MODE == 0 && g_conv_kb == 128 && (a.Cin * (int)sizeof(T)) % 128 == 0;
+#define NRPN_LC(BN_, OF_, KB_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_, KB_>), grid, dim3(256), 0, st, a)
+#define NRPN_LC2(BN_, OF_) do { if (wide) NRPN_LC(BN_, OF_, 128); else NRPN_LC(BN_, OF_, 64); } while (0)
+  if (bn == 64) { if (out_f32) NRPN_LC2(64, true); else NRPN_LC2(64, false); }
+  else { if (out_f32) NRPN_LC2(128, true); else NRPN_LC2(128, false); }
+#undef NRPN_LC2
 #undef NRPN_LC
   NRPN_LAUNCH_CHECK("conv_igemm");
   return NRPN_OK;
 }
 
+extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
+  const long long M = (long long)n * gx * gy * gz;
+  const int s = conv_ksplit(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
+  return s > 1 ? (size_t)(M * cout * 4) : 0;
+}
+
 extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
-                               int cout, int wrows, int ksize, int dtype, int flags, nrpn_stream_t stream) {
+                               int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_fwd: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_fwd: bad dtype %d", dtype);
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && cin > 0 && cout > 0 && wrows >= cout, "conv3d_fwd: bad sizes");
@@ -262,8 +356,26 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // the kernel splits v into (batch, x, y, z) with these
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.flags = flags & 3;
   const bool out_f32 = (flags & NRPN_CONV_OUT_F32) != 0;
-  if (dtype == NRPN_F32) return launch_conv<float, 0>(a, true, as_stream(stream));
-  return launch_conv<bf16s, 0>(a, out_f32, as_stream(stream));
+  hipStream_t st = as_stream(stream);
+  a.ksplit = workspace ? conv_ksplit(a.M, cout, cin, a.taps, dtype == NRPN_F32 ? 4 : 2) : 1;
+  if (a.ksplit > 1) {
+    a.ws = reinterpret_cast<float *>(workspace);
+    NRPN_HIP(hipMemsetAsync(workspace, 0, (size_t)(a.M * cout * 4), st));
+  }
+  int rc = (dtype == NRPN_F32) ? launch_conv<float, 0>(a, true, st) : launch_conv<bf16s, 0>(a, out_f32, st);
+  if (rc || a.ksplit <= 1) return rc;
+  const long long total = a.M * cout;
+  const int blocks = (int)min((long long)4096, (total + 255) / 256);
+  const float *b = (flags & NRPN_CONV_BIAS) ? bias : nullptr;
+  const int relu = (flags & NRPN_CONV_RELU) ? 1 : 0;
+  if (dtype == NRPN_F32 || out_f32) {
+    if (dtype == NRPN_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu);
+    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu);
+  } else {
+    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu);
+  }
+  NRPN_LAUNCH_CHECK("splitk_epilogue");
+  return NRPN_OK;
 }
 
 extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
@@ -302,7 +414,7 @@ struct WgradArgs {
 
 template <typename T> struct WgCfg;
 template <> struct WgCfg<float> { static constexpr int KV = 32, RS = 128 * 4 + 64; };
-template <> struct WgCfg<bf16s> { static constexpr int KV = 32, RS = 128 * 2 + 64; };
+template <> struct WgCfg<bf16s> { static constexpr int KV = 64, RS = 128 * 2 + 64; };
 
 // one 32(channel) x 16-byte K fragment out of a [voxel][channel] LDS tile
 template <typename T>
@@ -375,6 +487,20 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 
   f4 ra[PIECES], rb[PIECES];
 
+  // per piece: voxel row inside the chunk, 16-byte column, and (MODE 0) the running per-scene coordinates of that voxel
+  int pz[PIECES], py[PIECES], px[PIECES];
+  if (MODE == 0) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const long long v = c_begin * KV + (tid + 256 * i) / PIECES_ROW;
+      pz[i] = (int)(v % p.Z);
+      const long long t1 = v / p.Z;
+      py[i] = (int)(t1 % p.Y);
+      px[i] = (int)((t1 / p.Y) % p.X);
+    }
+  }
+  const long long tap_shift = ((long long)dx * p.Y + dy) * p.Z + dz;
+
   auto load_chunk = [&](long long ch) {
     const long long v0 = ch * KV;
 #pragma unroll
@@ -391,17 +517,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
       // B
       if (MODE == 0) {
         const int c0 = n0 + col * (16 / (int)sizeof(T));
-        bool in = vok && c0 < p.Cin;
-        long long src = 0;
-        if (in) {
-          const int z = (int)(v % p.Z);
-          const long long t1 = v / p.Z;
-          const int y = (int)(t1 % p.Y);
-          const int x = (int)((t1 / p.Y) % p.X);
-          in = (unsigned)(x + dx) < (unsigned)p.X && (unsigned)(y + dy) < (unsigned)p.Y && (unsigned)(z + dz) < (unsigned)p.Z;
-          src = (v + ((long long)dx * p.Y + dy) * p.Z + dz) * p.Cin + c0;
-        }
-        rb[i] = in ? ldg16(xbase + src) : zero4();
+        const bool in = vok && c0 < p.Cin && (unsigned)(px[i] + dx) < (unsigned)p.X && (unsigned)(py[i] + dy) < (unsigned)p.Y &&
+                        (unsigned)(pz[i] + dz) < (unsigned)p.Z;
+        rb[i] = in ? ldg16(xbase + (v + tap_shift) * p.Cin + c0) : zero4();
+        // advance this piece's voxel by one chunk (carry loops: KV / Z iterations, no division)
+        pz[i] += KV;
+        while (pz[i] >= p.Z) { pz[i] -= p.Z; if (++py[i] >= p.Y) { py[i] = 0; if (++px[i] >= p.X) px[i] = 0; } }
       } else {
         // stem: column = taps [t0, t0 + TPS) x 4 channels of the im2col row of output voxel v
         constexpr int TPS = 16 / (4 * (int)sizeof(T));
@@ -500,9 +621,9 @@ extern "C" int nrpn_set_wgrad_transpose_read(int on) { g_wgrad_tr_mode = on ? 1 
 template <typename T, int MODE>
 static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
   const int tiles = ((a.wrows + 127) / 128) * ntiles_n * (MODE == 0 ? a.taps : 1);
-  const long long chunks = (a.M + 31) / 32;
+  const long long chunks = (a.M + WgCfg<T>::KV - 1) / WgCfg<T>::KV;
   long long ks = (1024 + tiles - 1) / tiles;
-  if (ks > chunks / 4) ks = chunks / 4;
+  if (ks > chunks / 16) ks = chunks / 16;     // >= 16 chunks per workgroup so the 128x128 atomic epilogue stays amortised
   if (ks < 1) ks = 1;
   if (ks > 4096) ks = 4096;
   a.ksplit = (int)ks;
@@ -521,10 +642,35 @@ static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
   return NRPN_OK;
 }
 
-// per-channel column sums of dY (bias gradient): rows x C -> C
+// per-channel column sums of dY (bias gradient): rows x C -> C.  256-row slabs per block; a thread owns 4 consecutive
+// channels (8/16-byte loads) of every (256 / (C/4))-th row, LDS reduces the row lanes, one atomic per channel per block.
 template <typename T>
-__global__ void colsum_kernel(const T *__restrict__ dy, long long rows, int c, float *__restrict__ out) {
-  // blockDim = (64, 4): x strides channels, y strides rows inside the block's row slab
+__global__ void __launch_bounds__(256) colsum_kernel(const T *__restrict__ dy, long long rows, int c, float *__restrict__ out) {
+  __shared__ float red[256][4];
+  const int ct = c / 4, lanes = 256 / ct;
+  const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
+  const long long r0 = (long long)blockIdx.x * 256, r1 = min(rows, r0 + 256);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ty < lanes)
+    for (long long r = r0 + ty; r < r1; r += lanes) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += elem<T>::ld(dy + r * c + tx * 4 + k);
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < ct) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = 0.f;
+      for (int q = 0; q < lanes; ++q) a += red[q * ct + threadIdx.x][k];
+      atomicAdd(out + threadIdx.x * 4 + k, a);
+    }
+  }
+}
+
+template <typename T>
+__global__ void colsum_generic_kernel(const T *__restrict__ dy, long long rows, int c, float *__restrict__ out) {
   const long long per = (rows + gridDim.x - 1) / gridDim.x;
   const long long r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
   for (int ch = threadIdx.x; ch < c; ch += 64) {
@@ -538,9 +684,15 @@ extern "C" int nrpn_colsum(const void *dy, long long rows, int c, int dtype, flo
   NRPN_REQUIRE(dy && out && rows > 0 && c > 0, "colsum: bad args");
   hipStream_t st = as_stream(stream);
   NRPN_HIP(hipMemsetAsync(out, 0, (size_t)c * 4, st));
-  const int blocks = (int)min((long long)1024, (rows + 63) / 64);
-  if (dtype == NRPN_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(64, 4), 0, st, (const float *)dy, rows, c, out);
-  else hipLaunchKernelGGL(colsum_kernel<bf16s>, dim3(blocks), dim3(64, 4), 0, st, (const bf16s *)dy, rows, c, out);
+  if (c % 4 == 0 && c <= 1024 && 256 % (c / 4) == 0) {
+    const int blocks = (int)((rows + 255) / 256);
+    if (dtype == NRPN_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)dy, rows, c, out);
+    else hipLaunchKernelGGL(colsum_kernel<bf16s>, dim3(blocks), dim3(256), 0, st, (const bf16s *)dy, rows, c, out);
+  } else {
+    const int blocks = (int)min((long long)1024, (rows + 63) / 64);
+    if (dtype == NRPN_F32) hipLaunchKernelGGL(colsum_generic_kernel<float>, dim3(blocks), dim3(64, 4), 0, st, (const float *)dy, rows, c, out);
+    else hipLaunchKernelGGL(colsum_generic_kernel<bf16s>, dim3(blocks), dim3(64, 4), 0, st, (const bf16s *)dy, rows, c, out);
+  }
   NRPN_LAUNCH_CHECK("colsum");
   return NRPN_OK;
 }

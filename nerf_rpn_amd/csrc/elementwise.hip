@@ -87,12 +87,29 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
   }
 }
 
+// finalize: block = (64 channels, 16 partial-lanes); fp64 accumulation of the fp32 block partials
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nblocks, int c, int ch, double &s, double &q) {
+  __shared__ double rs[16][64], rq[16][64];
+  double a = 0.0, b = 0.0;
+  if (ch < c)
+    for (int blk = threadIdx.y; blk < nblocks; blk += 16) {
+      a += (double)partial[(long long)blk * 2 * c + ch];
+      b += (double)partial[(long long)blk * 2 * c + c + ch];
+    }
+  rs[threadIdx.y][threadIdx.x] = a;
+  rq[threadIdx.y][threadIdx.x] = b;
+  __syncthreads();
+  s = 0.0; q = 0.0;
+  if (threadIdx.y == 0)
+    for (int k = 0; k < 16; ++k) { s += rs[k][threadIdx.x]; q += rq[k][threadIdx.x]; }
+}
+
 __global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int nblocks, long long rows, int c, float *__restrict__ mean,
                                          float *__restrict__ var, float *__restrict__ rmean, float *__restrict__ rvar, float momentum) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b) { s += (double)partial[(long long)b * 2 * c + ch]; q += (double)partial[(long long)b * 2 * c + c + ch]; }
+  const int ch = blockIdx.x * 64 + threadIdx.x;
+  double s, q;
+  reduce_partials(partial, nblocks, c, ch, s, q);
+  if (threadIdx.y != 0 || ch >= c) return;
   const double m = s / (double)rows;
   double v = q / (double)rows - m * m;
   if (v < 0.0) v = 0.0;
@@ -107,10 +124,10 @@ __global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int 
 
 __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblocks, int c, float *__restrict__ dbeta,
                                        float *__restrict__ dgamma) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b) { s += (double)partial[(long long)b * 2 * c + ch]; q += (double)partial[(long long)b * 2 * c + c + ch]; }
+  const int ch = blockIdx.x * 64 + threadIdx.x;
+  double s, q;
+  reduce_partials(partial, nblocks, c, ch, s, q);
+  if (threadIdx.y != 0 || ch >= c) return;
   dbeta[ch] = (float)s;
   dgamma[ch] = (float)q;
 }
@@ -132,7 +149,7 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
   DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 0>), dim3(nb), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
                                        (const T *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0,
                                        (float *)workspace));
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
                      var, running_mean, running_var, momentum);
   NRPN_LAUNCH_CHECK("bn_stats");
   return NRPN_OK;
@@ -213,7 +230,7 @@ extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, vo
   hipStream_t st = as_stream(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
                                        (long long)rows, c, mean, var, eps, relu, (float *)workspace));
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, (const float *)workspace, nb, c, dbeta, dgamma);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma);
   const long long groups = rows * (c / 4);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, st, (const T *)x, (const T *)y,
                                        (const T *)dy, (T *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu,

@@ -826,19 +826,34 @@ __global__ void match_kernel(const int32_t *__restrict__ tab, int64_t total, con
     for (int i = threadIdx.x; i < G; i += blockDim.x) smax[i] = gtmax[i];
   __syncthreads();
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= total) return;
-  const geo::AnchorCell c = geo::anchor_at(tab, f);
+  const bool live = f < total;
+  const geo::AnchorCell c = geo::anchor_at(tab, live ? f : 0);
   const bool padded = has_ori && anchor_in_padding(tab, c, ox, oy, oz);
   float best = -INFINITY;
   int besti = 0;
   bool attains = false;
+  if (PASS == 0) {
+    // per-GT maximum over all anchors: wave shuffle max -> LDS -> one global atomic per GT per block
+    // (every IoU is >= 0 or exactly -1, so the signed-int view orders correctly)
+    for (int i = threadIdx.x; i < G; i += blockDim.x) smax[i] = __int_as_float(0x80808080);
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+      float q = live ? (padded ? -1.0f : geo::iou3d_aabb(sgt + g * 6, c.box)) : __int_as_float(0x80808080);
+      int qi = __float_as_int(q);
+      for (int off = 32; off > 0; off >>= 1) qi = max(qi, __shfl_down(qi, off, 64));
+      if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int *>(smax) + g, qi);
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) atomicMax(reinterpret_cast<int *>(gtmax) + g, __float_as_int(smax[g]));
+    return;
+  }
+  if (!live) return;
   for (int g = 0; g < G; ++g) {
     const float q = padded ? -1.0f : geo::iou3d_aabb(sgt + g * 6, c.box);
     if (q > best) { best = q; besti = g; }
-    if (PASS == 0) atomicMax(reinterpret_cast<int *>(gtmax) + g, __float_as_int(q));
-    else attains = attains || (q == smax[g]);
+    attains = attains || (q == smax[g]);
   }
-  if (PASS == 1) {
+  {
     int idx = besti;
     if (best < bg) idx = -1;
     else if (best < fg) idx = -2;

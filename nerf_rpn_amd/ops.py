@@ -371,7 +371,9 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype):
         flags |= CONV_OUT_F32
     if bias is not None:
         flags |= CONV_BIAS
-    call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _s())
+    wsb = query("conv3d_fwd_workspace_bytes", n, gx, gy, gz, cin, cout, ksize, _dt(x))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), _s())
     return y
 
 
