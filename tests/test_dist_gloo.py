@@ -1,0 +1,90 @@
+"""CPU, world_size 2 (gloo): the data-parallel gradient exchange of nerf_rpn_amd.engine.FlatTrainer -- rank-0 weight
+broadcast, bucketed SUM all-reduce launched from post-accumulate hooks, unused-parameter buckets, 1/world folding.
+(The optimiser kernels themselves are GPU-only and are covered by tests/test_gpu_conv.py::test_layout_roundtrip_and_adamw.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 16)
+        self.unused = nn.Linear(4, 4)      # never touched by forward: its bucket must still be reduced (zeros)
+        self.c = nn.Linear(16, 3)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def _worker(rank, world, port, bucket_bytes, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_rpn_amd.engine import FlatTrainer
+    torch.manual_seed(100 + rank)            # different init per rank: the trainer must broadcast rank 0's weights
+    model = Tiny()
+    tr = FlatTrainer(model, bucket_bytes=bucket_bytes)
+    w0 = tr.p_arena.clone()
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(8, 8, generator=g), torch.randn(8, 3, generator=g)
+    xs, ys = x_all[rank * 4:(rank + 1) * 4], y_all[rank * 4:(rank + 1) * 4]
+    for _ in range(2):                       # two rounds: bucket counters must re-arm
+        tr.g_arena.zero_()
+        ((model(xs) - ys) ** 2).sum().backward()
+        tr.sync_gradients()
+    q.put((rank, w0, tr.g_arena.clone() / world, len(tr.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [64, 1 << 20])
+def test_flat_trainer_gradient_exchange(bucket_bytes):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w_a, g_a, nb), (_, w_b, g_b, _) = res
+    assert torch.equal(w_a, w_b)                             # rank 0's weights everywhere
+    assert torch.allclose(g_a, g_b)                          # identical reduced gradients
+    assert nb >= (4 if bucket_bytes == 64 else 1)
+    # reference: single process, whole batch, same (rank-0) weights; mean over ranks of per-rank sums = sum/2
+    torch.manual_seed(100)
+    ref = Tiny()
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(8, 8, generator=g), torch.randn(8, 3, generator=g)
+    ((ref(x_all) - y_all) ** 2).sum().backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ref.parameters()]) / 2
+    assert torch.allclose(g_a, flat, atol=1e-5)
+
+
+def test_one_cycle_matches_torch():
+    from nerf_rpn_amd.engine import one_cycle
+    p = nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=3e-4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-4, total_steps=50)
+    for step in range(50):
+        lr, b1 = one_cycle(step, 50, 3e-4)
+        assert abs(lr - opt.param_groups[0]["lr"]) < 1e-12 and abs(b1 - opt.param_groups[0]["betas"][0]) < 1e-12, step
+        opt.step()
+        if step < 49:
+            sched.step()
