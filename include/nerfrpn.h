@@ -185,8 +185,9 @@ int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, i
                     int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream);
 /* wgrad: gw_packed f32 [taps][wrows][Cin] (zero-filled by the call, split-K partials are atomically added);
  * optional gbias f32 [Cout] = column sums of dy. */
+size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int ksize);
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
-                      int cin, int cout, int wrows, int ksize, int dtype, nrpn_stream_t stream);
+                      int cin, int cout, int wrows, int ksize, int dtype, void *workspace, nrpn_stream_t stream);
 /* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
 int nrpn_set_conv_kstep_bytes(int kb);
 int nrpn_colsum(const void *dy, long long rows, int c, int dtype, float *out, nrpn_stream_t stream);

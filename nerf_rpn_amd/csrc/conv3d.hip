@@ -37,7 +37,26 @@ template <> struct Mma<bf16s> {
 };
 
 __device__ __forceinline__ f4 ldg16(const void *p) { return *reinterpret_cast<const f4 *>(p); }
+// 16-byte raw-buffer load: a lane whose offset is >= the descriptor's num_records gets zeros from the hardware, so border
+// taps / tail rows need no branch and no select -- every load of a K-step issues back to back.
+typedef __attribute__((ext_vector_type(4))) unsigned int u4v;
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f4 bufld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
 __device__ __forceinline__ f4 zero4() { f4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// XCD-aware workgroup order.  The dispatcher places linear workgroup id b on XCD b % 8 (observed, speed only); each XCD has
+// a private 4 MiB L2.  Remapping id -> (id % 8) * ceil(n/8) + id / 8 hands every XCD one CONTIGUOUS range of logical tiles,
+// so neighbouring tiles (which share halo voxels / weight panels / K-slices) hit the same L2 instead of eight different ones.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
+  const unsigned q = n / 8, r = n % 8, xcd = id % 8, slot = id / 8;
+  // bijective for any n: the first r XCDs own q+1 ids, the rest q
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
 // C/D fragment of the 32x32 MFMA: register r of lane l holds (row, col) = ((r&3) + 8*(r>>2) + 4*(l>>5), l&31)
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -58,12 +77,13 @@ struct ConvArgs {
   int taps;           // 1, 27 (MODE 0) or 343 (MODE 1)
   int stride;         // MODE 1 only
   int flags;
+  unsigned x_bytes, w_bytes;   // extents for the raw-buffer descriptors (out-of-range lanes read 0)
   int ksplit;         // > 1: blockIdx.z owns a slice of the K loop and atomically adds fp32 partials into `ws`
   float *ws;          // [M][Cout] fp32, zero-filled by the launcher (split-K only)
 };
 
 template <typename T, int BN, int MODE, bool OUTF32, int KB>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
   constexpr int BM = 128;
   constexpr int WAVES_N = (BN == 128) ? 2 : 1;
   constexpr int TM = (BN == 128) ? 2 : 1;   // 32x32 tiles per wave along M
@@ -79,8 +99,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const unsigned ntiles = (p.Cout + BN - 1) / BN;
+  const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * ntiles;
+  const unsigned zsplit = blockIdx.x / tiles;                      // split-K slice (0 when ksplit == 1)
+  const unsigned tile = xcd_remap(blockIdx.x - zsplit * tiles, tiles);
+  const long long m0 = (long long)(tile / ntiles) * BM;
+  const int n0 = (int)(tile % ntiles) * BN;
   const int lr = tid / PPR, ls = tid % PPR;
 
   // ---- loader state per A row: element offset of the voxel, per-scene coordinates, and a 27-bit mask of in-bounds taps
@@ -129,33 +153,37 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   int ks_begin = 0, ks_end = nk;
   if (p.ksplit > 1) {
     const int per = (nk + p.ksplit - 1) / p.ksplit;
-    ks_begin = blockIdx.z * per;
+    ks_begin = zsplit * per;
     ks_end = min(nk, ks_begin + per);
     if (ks_begin >= ks_end) return;
   }
 
-  f4 ra[A_RPT], rb[B_RPT];
+  // MODE 0: byte offsets for the raw-buffer loads (loop invariant); kOOB marks rows that must read zeros
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+  unsigned a_voff[A_RPT], b_voff[B_RPT];
+#pragma unroll
+  for (int i = 0; i < A_RPT; ++i) a_voff[i] = (unsigned)(a_off[i] * (long long)sizeof(T)) + ls * 16;
+#pragma unroll
+  for (int i = 0; i < B_RPT; ++i) {
+    const int row = n0 + lr + RSTEP * i;
+    b_voff[i] = row < p.wrows ? (unsigned)((long long)row * p.Cin * (long long)sizeof(T)) + ls * 16 : kOOB;
+  }
+  f4 ra0[A_RPT], rb0[B_RPT];
   // incremental (tap, chunk) walk of the K loop for MODE 0 -- no divisions in the steady state
   int l_tap = ks_begin / cpt, l_chunk = ks_begin - l_tap * cpt;
   int l_dx = 0, l_dy = 0, l_dz = 0;
   if (p.taps == 27) { l_dx = l_tap / 9 - 1; l_dy = (l_tap / 3) % 3 - 1; l_dz = l_tap % 3 - 1; }
   const long long w_tap_stride = (long long)p.wrows * p.Cin;
 
-  auto load_step = [&](int ks) {
+  auto load_step = [&](int ks, f4 (&ra)[A_RPT], f4 (&rb)[B_RPT]) {
     if (MODE == 0) {
       const int c0 = l_chunk * KE;
-      const long long shift = ((long long)l_dx * p.Y * p.Z + (long long)l_dy * p.Z + l_dz) * p.Cin + c0;
+      const unsigned shift = (unsigned)((((l_dx * p.Y + l_dy) * p.Z + l_dz) * p.Cin + c0) * (int)sizeof(T));
 #pragma unroll
-      for (int i = 0; i < A_RPT; ++i) {
-        const bool in = (a_mask[i] >> l_tap) & 1u;
-        ra[i] = in ? ldg16(reinterpret_cast<const char *>(xbase + a_off[i] + shift) + ls * 16) : zero4();
-      }
-      const T *wt = wbase + (long long)l_tap * w_tap_stride + c0;
+      for (int i = 0; i < A_RPT; ++i) ra[i] = bufld16(xr, ((a_mask[i] >> l_tap) & 1u) ? a_voff[i] + shift : kOOB);
+      const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * (long long)sizeof(T));
 #pragma unroll
-      for (int i = 0; i < B_RPT; ++i) {
-        const int row = n0 + lr + RSTEP * i;
-        rb[i] = (row < p.wrows) ? ldg16(reinterpret_cast<const char *>(wt + (long long)row * p.Cin) + ls * 16) : zero4();
-      }
+      for (int i = 0; i < B_RPT; ++i) rb[i] = bufld16(wr, b_voff[i] + wshift);
       if (++l_chunk == cpt) {
         l_chunk = 0;
         ++l_tap;
@@ -193,7 +221,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     }
   };
 
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const f4 (&ra)[A_RPT], const f4 (&rb)[B_RPT]) {
     char *A = lds + buf * (A_BYTES + B_BYTES);
     char *B = A + A_BYTES;
 #pragma unroll
@@ -216,14 +244,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_step(ks_begin);
-  store_step(0);
-  __syncthreads();
-
   const int fr = lane & 31, fk = lane >> 5;
-  for (int ks = ks_begin; ks < ks_end; ++ks) {
-    const int buf = (ks - ks_begin) & 1;
-    if (ks + 1 < ks_end) load_step(ks + 1);
+  auto compute_step = [&](int buf) {
     const char *A = lds + buf * (A_BYTES + B_BYTES);
     const char *B = A + A_BYTES;
 #pragma unroll
@@ -244,8 +266,26 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bfv[j]);
     }
-    if (ks + 1 < ks_end) store_step(buf ^ 1);
+  };
+
+  // Software pipeline: while step k is multiplied out of LDS buffer k&1, the loads of step k+1 are in flight into the
+  // staging registers and are written to the other buffer after the MFMAs.  The loop is unrolled by two so both LDS
+  // buffers are compile-time constants (immediate ds offsets, no address arithmetic in the loop).
+  load_step(ks_begin, ra0, rb0);
+  store_step(0, ra0, rb0);
+  __syncthreads();
+  int ks = ks_begin;
+  while (ks < ks_end) {
+    if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+    compute_step(0);
+    if (ks + 1 < ks_end) store_step(1, ra0, rb0);
     __syncthreads();
+    if (++ks >= ks_end) break;
+    if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+    compute_step(1);
+    if (ks + 1 < ks_end) store_step(0, ra0, rb0);
+    __syncthreads();
+    ++ks;
   }
 
   if (p.ksplit > 1) {   // partial sums; bias / ReLU / cast happen in splitk_epilogue_kernel
@@ -323,7 +363,7 @@ extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
 template <typename T, int MODE>
 static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const int bn = (a.Cout <= 64) ? 64 : 128;
-  dim3 grid((unsigned)cdiv64(a.M, 128), (unsigned)((a.Cout + bn - 1) / bn), (unsigned)(a.ksplit > 1 ? a.ksplit : 1));
+  dim3 grid((unsigned)(cdiv64(a.M, 128) * ((a.Cout + bn - 1) / bn) * (a.ksplit > 1 ? a.ksplit : 1)));
   // the 128-byte K-step needs Cin*elemsize % 128 == 0; the stem gather keeps the 64-byte step
   const bool wide = MODE == 0 && g_conv_kb == 128 && (a.Cin * (int)sizeof(T)) % 128 == 0;
 #define NRPN_LC(BN_, OF_, KB_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_, KB_>), grid, dim3(256), 0, st, a)
@@ -355,6 +395,9 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
   a.M = (long long)n * gx * gy * gz;
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // the kernel splits v into (batch, x, y, z) with these
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.flags = flags & 3;
+  NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && (long long)a.taps * wrows * cin * es < (1ll << 31),
+               "conv3d_fwd: activation / weight tensors must stay below 2 GiB (32-bit buffer offsets)");
+  a.x_bytes = (unsigned)(a.M * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);
   const bool out_f32 = (flags & NRPN_CONV_OUT_F32) != 0;
   hipStream_t st = as_stream(stream);
   a.ksplit = workspace ? conv_ksplit(a.M, cout, cin, a.taps, dtype == NRPN_F32 ? 4 : 2) : 1;
@@ -409,7 +452,10 @@ struct WgradArgs {
   int Cin, Cout, wrows, taps, stride;
   int ksplit;         // voxel range is cut into ksplit slices (blockIdx.z / taps)
   int kpad;           // MODE 1
-  int tr_mode;        // bf16: 1 = ds_read_b64_tr_b16, 0 = scalar 16-bit gathers (slow reference path)
+  int ntiles_n;       // cin (MODE 0) / k (MODE 1) tiles
+  const unsigned *vmask;   // MODE 0, taps == 27: per-voxel 27-bit mask of in-bounds taps (built by tap_mask_kernel)
+  unsigned x_bytes, dy_bytes;
+  float *gbias;       // optional: column sums of dY, accumulated by the (centre tap, first n-tile) workgroups from their LDS A tiles
 };
 
 template <typename T> struct WgCfg;
@@ -417,49 +463,46 @@ template <> struct WgCfg<float> { static constexpr int KV = 32, RS = 128 * 4 + 6
 template <> struct WgCfg<bf16s> { static constexpr int KV = 64, RS = 128 * 2 + 64; };
 
 // one 32(channel) x 16-byte K fragment out of a [voxel][channel] LDS tile
-template <typename T>
-__device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, int lane, int tr_mode);
+template <typename T, bool TR>
+__device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, int lane);
 
-template <>
-__device__ __forceinline__ f4 wg_frag<float>(const char *tile, int ctile0, int kbase, int lane, int) {
-  // 16 bytes = 4 k-values for lane-half h: voxels kbase + 4h .. +3 (the same permutation on A and B)
-  constexpr int RS = WgCfg<float>::RS;
-  const int c = ctile0 + (lane & 31), h = lane >> 5;
-  f4 v;
+template <typename T, bool TR>
+__device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, int lane) {
+  if (sizeof(T) == 4) {
+    // 16 bytes = 4 k-values for lane-half h: voxels kbase + 4h .. +3 (the same permutation on A and B)
+    constexpr int RS = WgCfg<float>::RS;
+    const int c = ctile0 + (lane & 31), h = lane >> 5;
+    f4 v;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float *>(tile + (kbase + 4 * h + q) * RS + c * 4);
-  return v;
-}
-
-template <>
-__device__ __forceinline__ f4 wg_frag<bf16s>(const char *tile, int ctile0, int kbase, int lane, int tr_mode) {
-  // 16 bytes = 8 bf16 k-values for lane-half h: voxels kbase + 8h .. +7, channel ctile0 + (lane & 31)
-  constexpr int RS = WgCfg<bf16s>::RS;
-  const int h = lane >> 5;
-  if (tr_mode) {
-    // transpose read: inside a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by lanes
-    // 4j + (i >> 2), j = 0..3.  Lane p therefore addresses voxel (p >> 2), channels cbase + 4 (p & 3) .. +3.
-    const int p = lane & 15;
-    const int cbase = ctile0 + 16 * ((lane >> 4) & 1);
-    const int vb = kbase + 8 * h;
-    const char *a0 = tile + (vb + (p >> 2)) * RS + (cbase + 4 * (p & 3)) * 2;
-    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0));
-    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0 + 4 * RS));
-    typedef __attribute__((ext_vector_type(8))) short s8v;
-    s8v r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float *>(tile + (kbase + 4 * h + q) * RS + c * 4);
+    return v;
+  } else {
+    // 16 bytes = 8 bf16 k-values for lane-half h: voxels kbase + 8h .. +7, channel ctile0 + (lane & 31)
+    constexpr int RS = WgCfg<bf16s>::RS;
+    const int h = lane >> 5;
+    if (TR) {
+      // transpose read: inside a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by lanes
+      // 4j + (i >> 2), j = 0..3.  Lane p therefore addresses voxel (p >> 2), channels cbase + 4 (p & 3) .. +3.
+      const int p = lane & 15;
+      const int cbase = ctile0 + 16 * ((lane >> 4) & 1);
+      const int vb = kbase + 8 * h;
+      const char *a0 = tile + (vb + (p >> 2)) * RS + (cbase + 4 * (p & 3)) * 2;
+      const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0));
+      const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0 + 4 * RS));
+      typedef __attribute__((ext_vector_type(2))) long long l2v;
+      l2v r = {__builtin_bit_cast(long long, lo), __builtin_bit_cast(long long, hi)};
+      return __builtin_bit_cast(f4, r);
+    }
+    const int c = ctile0 + (lane & 31);
+    typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+    u8v r;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const unsigned short *>(tile + (kbase + 8 * h + q) * RS + c * 2);
     return __builtin_bit_cast(f4, r);
   }
-  const int c = ctile0 + (lane & 31);
-  typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
-  u8v r;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const unsigned short *>(tile + (kbase + 8 * h + q) * RS + c * 2);
-  return __builtin_bit_cast(f4, r);
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool TR>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   constexpr int KV = WgCfg<T>::KV, RS = WgCfg<T>::RS;
   constexpr int TILE = KV * RS;
@@ -470,10 +513,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * 128;   // cout tile
-  const int n0 = blockIdx.y * 128;   // cin tile (MODE 0) / k tile (MODE 1)
-  const int tap = (MODE == 0) ? (int)(blockIdx.z % p.taps) : 0;
-  const int slice = (MODE == 0) ? (int)(blockIdx.z / p.taps) : (int)blockIdx.z;
+  // 1-D grid, voxel slice slowest: id = ((slice * taps + tap) * ntn + ntile) * ntm + mtile.  All workgroups of a slice read the
+  // same dY / X rows, and the XCD remap keeps a slice on one XCD's L2.
+  const unsigned ntm = (p.wrows + 127) / 128, ntn = p.ntiles_n, tps = (MODE == 0) ? p.taps : 1;
+  unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(id % ntm) * 128;   // cout tile
+  id /= ntm;
+  const int n0 = (int)(id % ntn) * 128;   // cin tile (MODE 0) / k tile (MODE 1)
+  id /= ntn;
+  const int tap = (int)(id % tps);
+  const int slice = (int)(id / tps);
   int dx = 0, dy = 0, dz = 0;
   if (MODE == 0 && p.taps == 27) { dx = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dz = tap % 3 - 1; }
 
@@ -487,43 +536,50 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 
   f4 ra[PIECES], rb[PIECES];
 
-  // per piece: voxel row inside the chunk, 16-byte column, and (MODE 0) the running per-scene coordinates of that voxel
-  int pz[PIECES], py[PIECES], px[PIECES];
-  if (MODE == 0) {
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-      const long long v = c_begin * KV + (tid + 256 * i) / PIECES_ROW;
-      pz[i] = (int)(v % p.Z);
-      const long long t1 = v / p.Z;
-      py[i] = (int)(t1 % p.Y);
-      px[i] = (int)((t1 / p.Y) % p.X);
-    }
-  }
+  // MODE 0 loader: raw-buffer loads (out-of-range offsets read zeros, so tail rows / border taps / column tails need no
+  // branches); border validity of a voxel for this workgroup's tap comes from a per-voxel 27-bit mask, fetched one chunk
+  // ahead so the mask -> address dependency never stalls the data loads.
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(p.vmask, (unsigned)(p.M * 4));
   const long long tap_shift = ((long long)dx * p.Y + dy) * p.Z + dz;
+  unsigned a_voff[PIECES], b_voff[PIECES], m_voff[PIECES], m_next[PIECES];
+  const bool use_mask = MODE == 0 && p.taps == 27;
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int pc = tid + 256 * i;
+    const int row = pc / PIECES_ROW, col = pc % PIECES_ROW;
+    const long long v = c_begin * KV + row;
+    const int ca = m0 + col * (16 / (int)sizeof(T)), cb = n0 + col * (16 / (int)sizeof(T));
+    a_voff[i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * (long long)sizeof(T)) : kOOB;
+    b_voff[i] = cb < p.Cin ? (unsigned)(((v + tap_shift) * p.Cin + cb) * (long long)sizeof(T)) : kOOB;
+    m_voff[i] = (unsigned)(v * 4);
+    m_next[i] = (v < p.M) ? 1u : 0u;
+    if (MODE == 0 && use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
+  }
+  const unsigned a_step = (unsigned)(KV * p.Cout * (int)sizeof(T)), b_step = (unsigned)(KV * p.Cin * (int)sizeof(T));
 
   auto load_chunk = [&](long long ch) {
     const long long v0 = ch * KV;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int pc = tid + 256 * i;
-      const int row = pc / PIECES_ROW, col = pc % PIECES_ROW;   // voxel row in the chunk, 16-byte column
-      const long long v = v0 + row;
-      const bool vok = v < p.M;
-      // A: dY[v][m0 + ...]
-      {
-        const int c0 = m0 + col * (16 / (int)sizeof(T));
-        ra[i] = (vok && c0 < p.Cout) ? ldg16(dybase + v * p.Cout + c0) : zero4();
-      }
-      // B
       if (MODE == 0) {
-        const int c0 = n0 + col * (16 / (int)sizeof(T));
-        const bool in = vok && c0 < p.Cin && (unsigned)(px[i] + dx) < (unsigned)p.X && (unsigned)(py[i] + dy) < (unsigned)p.Y &&
-                        (unsigned)(pz[i] + dz) < (unsigned)p.Z;
-        rb[i] = in ? ldg16(xbase + (v + tap_shift) * p.Cin + c0) : zero4();
-        // advance this piece's voxel by one chunk (carry loops: KV / Z iterations, no division)
-        pz[i] += KV;
-        while (pz[i] >= p.Z) { pz[i] -= p.Z; if (++py[i] >= p.Y) { py[i] = 0; if (++px[i] >= p.X) px[i] = 0; } }
+        ra[i] = bufld16(dyr, a_voff[i]);
+        const bool in = (m_next[i] >> tap) & 1u;      // 0 beyond the tensor (the mask load itself was out of range)
+        rb[i] = bufld16(xr, (in && b_voff[i] != kOOB) ? b_voff[i] : kOOB);
+        a_voff[i] = a_voff[i] == kOOB ? kOOB : a_voff[i] + a_step;
+        b_voff[i] = b_voff[i] == kOOB ? kOOB : b_voff[i] + b_step;
+        m_voff[i] += KV * 4;
+        if (use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
+        else m_next[i] = (m_voff[i] < (unsigned)(p.M * 4)) ? 1u : 0u;
       } else {
+        const int pc = tid + 256 * i;
+        const int row = pc / PIECES_ROW, col = pc % PIECES_ROW;   // voxel row in the chunk, 16-byte column
+        const long long v = v0 + row;
+        const bool vok = v < p.M;
+        {
+          const int c0 = m0 + col * (16 / (int)sizeof(T));
+          ra[i] = (vok && c0 < p.Cout) ? ldg16(dybase + v * p.Cout + c0) : zero4();
+        }
         // stem: column = taps [t0, t0 + TPS) x 4 channels of the im2col row of output voxel v
         constexpr int TPS = 16 / (4 * (int)sizeof(T));
         f4 val = zero4();
@@ -571,6 +627,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool do_bias = p.gbias != nullptr && n0 == 0 && tap == ((MODE == 0 && p.taps == 27) ? 13 : 0);
+  float bias_acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   load_chunk(c_begin);
   store_chunk(0);
   __syncthreads();
@@ -579,13 +637,28 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     if (ch + 1 < c_end) load_chunk(ch + 1);
     const char *A = lds + buf * 2 * TILE;
     const char *B = A + TILE;
+    if (do_bias) {   // thread t owns one 16-byte column group of the dY tile and every (256 / PIECES_ROW)-th voxel row
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const f4 v = *reinterpret_cast<const f4 *>(A + (tid / PIECES_ROW + i * (256 / PIECES_ROW)) * RS + (tid % PIECES_ROW) * 16);
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bias_acc[e] += v[e];
+        } else {
+          typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+          const u8v h = __builtin_bit_cast(u8v, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bias_acc[e] += bf16_bits_to_f32(h[e]);
+        }
+      }
+    }
 #pragma unroll
     for (int kb = 0; kb < KV; kb += KSUB) {
       f4 af[2], bfv[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = wg_frag<T>(A, (wm * 2 + i) * 32, kb, lane, p.tr_mode);
+      for (int i = 0; i < 2; ++i) af[i] = wg_frag<T, TR>(A, (wm * 2 + i) * 32, kb, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfv[j] = wg_frag<T>(B, (wn * 2 + j) * 32, kb, lane, p.tr_mode);
+      for (int j = 0; j < 2; ++j) bfv[j] = wg_frag<T, TR>(B, (wn * 2 + j) * 32, kb, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -596,6 +669,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     buf ^= 1;
   }
 
+  if (do_bias) {
+    constexpr int EPP = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) {
+      const int bc = m0 + (tid % PIECES_ROW) * EPP + e;
+      if (bc < p.Cout) atomicAdd(p.gbias + bc, bias_acc[e]);
+    }
+  }
   const int fr = lane & 31;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -615,6 +696,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   }
 }
 
+// bit t of mask[v] = 1 iff voxel v shifted by tap t = (dx+1)*9 + (dy+1)*3 + (dz+1) stays inside its scene
+__global__ void tap_mask_kernel(unsigned *__restrict__ mask, long long M, int X, int Y, int Z) {
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= M) return;
+  const int z = (int)(v % Z);
+  const long long t1 = v / Z;
+  const int y = (int)(t1 % Y);
+  const int x = (int)((t1 / Y) % X);
+  unsigned m = 0;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
+    if ((unsigned)(x + dx) < (unsigned)X && (unsigned)(y + dy) < (unsigned)Y && (unsigned)(z + dz) < (unsigned)Z) m |= 1u << t;
+  }
+  mask[v] = m;
+}
+
 static int g_wgrad_tr_mode = 1;
 extern "C" int nrpn_set_wgrad_transpose_read(int on) { g_wgrad_tr_mode = on ? 1 : 0; return NRPN_OK; }
 
@@ -627,17 +725,21 @@ static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
   if (ks < 1) ks = 1;
   if (ks > 4096) ks = 4096;
   a.ksplit = (int)ks;
-  a.tr_mode = g_wgrad_tr_mode;
+  a.ntiles_n = ntiles_n;
   const size_t lds = 4 * (size_t)WgCfg<T>::KV * WgCfg<T>::RS;
-  static bool attr_done[2][2] = {{false, false}, {false, false}};
-  bool &done = attr_done[sizeof(T) == 2][MODE];
+  const bool tr = g_wgrad_tr_mode != 0;
+  static bool attr_done[2][2][2] = {};
+  bool &done = attr_done[sizeof(T) == 2][MODE][tr];
   if (!done) {
-    NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
+    if (tr) NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_kernel<T, MODE, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_kernel<T, MODE, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
   }
-  dim3 grid((a.wrows + 127) / 128, ntiles_n, (MODE == 0 ? a.taps : 1) * a.ksplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, MODE>), grid, dim3(256), lds, st, a);
+  dim3 grid((unsigned)(((a.wrows + 127) / 128) * ntiles_n * (MODE == 0 ? a.taps : 1) * a.ksplit));
+  if (tr) hipLaunchKernelGGL((conv_wgrad_kernel<T, MODE, true>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<T, MODE, false>), grid, dim3(256), lds, st, a);
   NRPN_LAUNCH_CHECK("conv_wgrad");
   return NRPN_OK;
 }
@@ -697,8 +799,12 @@ extern "C" int nrpn_colsum(const void *dy, long long rows, int c, int dtype, flo
   return NRPN_OK;
 }
 
+extern "C" size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int ksize) {
+  return ksize == 3 ? (size_t)n * gx * gy * gz * 4 : 0;
+}
+
 extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz, int cin,
-                                 int cout, int wrows, int ksize, int dtype, nrpn_stream_t stream) {
+                                 int cout, int wrows, int ksize, int dtype, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_wgrad: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_wgrad: bad dtype %d", dtype);
   const int es = dtype == NRPN_F32 ? 4 : 2;
@@ -710,13 +816,17 @@ extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.kpad = 0;
   hipStream_t st = as_stream(stream);
+  NRPN_REQUIRE(ksize == 1 || workspace, "conv3d_wgrad: k3 needs the tap-mask workspace (nrpn_conv3d_wgrad_workspace_bytes)");
+  NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && a.M * cout * es < (1ll << 31), "conv3d_wgrad: tensors must stay below 2 GiB");
+  a.x_bytes = (unsigned)(a.M * cin * es); a.dy_bytes = (unsigned)(a.M * cout * es);
+  a.vmask = reinterpret_cast<const unsigned *>(workspace);
+  if (ksize == 3)
+    hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz);
   NRPN_HIP(hipMemsetAsync(gw_packed, 0, (size_t)a.taps * wrows * cin * 4, st));
-  int rc;
-  if (dtype == NRPN_F32) rc = launch_wgrad<float, 0>(a, (cin + 127) / 128, st);
-  else rc = launch_wgrad<bf16s, 0>(a, (cin + 127) / 128, st);
-  if (rc) return rc;
-  if (gbias) return nrpn_colsum(dy, a.M, cout, dtype, gbias, stream);
-  return NRPN_OK;
+  a.gbias = gbias;
+  if (gbias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  if (dtype == NRPN_F32) return launch_wgrad<float, 0>(a, (cin + 127) / 128, st);
+  return launch_wgrad<bf16s, 0>(a, (cin + 127) / 128, st);
 }
 
 extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
@@ -736,12 +846,10 @@ extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_p
   a.kpad = ((343 * 4 + ke - 1) / ke) * ke;
   hipStream_t st = as_stream(stream);
   NRPN_HIP(hipMemsetAsync(gw_packed, 0, (size_t)cout * a.kpad * 4, st));
-  int rc;
-  if (dtype == NRPN_F32) rc = launch_wgrad<float, 1>(a, (a.kpad + 127) / 128, st);
-  else rc = launch_wgrad<bf16s, 1>(a, (a.kpad + 127) / 128, st);
-  if (rc) return rc;
-  if (gbias) return nrpn_colsum(dy, a.M, cout, dtype, gbias, stream);
-  return NRPN_OK;
+  a.gbias = gbias;
+  if (gbias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  if (dtype == NRPN_F32) return launch_wgrad<float, 1>(a, (a.kpad + 127) / 128, st);
+  return launch_wgrad<bf16s, 1>(a, (a.kpad + 127) / 128, st);
 }
 
 // =====================================================================================================================

@@ -13,6 +13,10 @@ from . import lib
 from .lib import BF16, CONV_BIAS, CONV_OUT_F32, CONV_RELU, F32, call, query
 
 
+import os as _os
+_SEPARATE_BIAS = bool(int(_os.environ.get('NRPN_SEPARATE_BIAS', '0')))
+
+
 def _s():
     return torch.cuda.current_stream().cuda_stream
 
@@ -419,7 +423,9 @@ class ConvFn(torch.autograd.Function):
         taps = ksize ** 3
         gwp = torch.empty((taps, rows_total, cin), dtype=torch.float32, device=x.device)
         gb = torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None
-        call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), _s())
+        wsb = query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, ksize)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+        call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), _p(ws), _s())
         gws, gbs, row = [], [], 0
         for w in weights:
             gw = torch.empty_like(w, dtype=torch.float32)
