@@ -190,6 +190,8 @@ int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gb
                       int cin, int cout, int wrows, int ksize, int dtype, void *workspace, nrpn_stream_t stream);
 /* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
 int nrpn_set_conv_kstep_bytes(int kb);
+/* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */
+int nrpn_set_conv_lds_dma(int on);
 int nrpn_colsum(const void *dy, long long rows, int c, int dtype, float *out, nrpn_stream_t stream);
 /* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
 int nrpn_set_wgrad_transpose_read(int on);

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) short s4v;
 typedef unsigned short bf16s;  // raw bf16 storage
 
 static int g_conv_kb_value();
+
 template <typename T> struct Mma;
 template <> struct Mma<float> {
   static __device__ __forceinline__ void run(f16v &acc, const f4 &a, const f4 &b) {
@@ -58,6 +59,12 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// 16-byte LDS-DMA: each lane's 16 bytes land at (wave-uniform lds_dst) + 16 * lane; out-of-range lanes deposit zeros
+// (verified on hardware by tools/probe_glds.hip)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, void *lds_dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_dst, 16, voff, 0, 0, 0);
+}
+
 // C/D fragment of the 32x32 MFMA: register r of lane l holds (row, col) = ((r&3) + 8*(r>>2) + 4*(l>>5), l&31)
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -82,7 +89,7 @@ struct ConvArgs {
   float *ws;          // [M][Cout] fp32, zero-filled by the launcher (split-K only)
 };
 
-template <typename T, int BN, int MODE, bool OUTF32, int KB>
+template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
   constexpr int BM = 128;
   constexpr int WAVES_N = (BN == 128) ? 2 : 1;
@@ -162,11 +169,19 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
   unsigned a_voff[A_RPT], b_voff[B_RPT];
 #pragma unroll
-  for (int i = 0; i < A_RPT; ++i) a_voff[i] = (unsigned)(a_off[i] * (long long)sizeof(T)) + ls * 16;
+  for (int i = 0; i < A_RPT; ++i) {
+    // LDS-DMA writes lane l of a wave to (base + 16 l): the physical 16-byte slot is fixed by the lane, so the XOR swizzle
+    // is applied to the SOURCE slot instead (linear destination + inverse-swizzled source + swizzled read)
+    const int r = lr + RSTEP * i;
+    const int src_slot = GLDS ? (ls ^ ((r >> SWZ_SH) & (PPR - 1))) : ls;
+    a_voff[i] = (unsigned)(a_off[i] * (long long)sizeof(T)) + src_slot * 16;
+  }
 #pragma unroll
   for (int i = 0; i < B_RPT; ++i) {
     const int row = n0 + lr + RSTEP * i;
-    b_voff[i] = row < p.wrows ? (unsigned)((long long)row * p.Cin * (long long)sizeof(T)) + ls * 16 : kOOB;
+    const int rb_ = lr + RSTEP * i;
+    const int src_slot = GLDS ? (ls ^ ((rb_ >> SWZ_SH) & (PPR - 1))) : ls;
+    b_voff[i] = row < p.wrows ? (unsigned)((long long)row * p.Cin * (long long)sizeof(T)) + src_slot * 16 : kOOB;
   }
   f4 ra0[A_RPT], rb0[B_RPT];
   // incremental (tap, chunk) walk of the K loop for MODE 0 -- no divisions in the steady state
@@ -221,6 +236,28 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
     }
   };
 
+  // LDS-DMA form of load_step (MODE 0): buffer_load_dwordx4 ... lds straight into LDS buffer `buf`, no staging registers and
+  // no ds_write.  A wave-instruction covers 64 / PPR consecutive tile rows = 1 KiB of LDS at a wave-uniform base.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_glds = [&](int buf) {
+    char *A = lds + buf * (A_BYTES + B_BYTES);
+    char *B = A + A_BYTES;
+    const int c0 = l_chunk * KE;
+    const unsigned shift = (unsigned)((((l_dx * p.Y + l_dy) * p.Z + l_dz) * p.Cin + c0) * (int)sizeof(T));
+    const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * (long long)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < A_RPT; ++i)
+      lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB, ((a_mask[i] >> l_tap) & 1u) ? a_voff[i] + shift : kOOB);
+#pragma unroll
+    for (int i = 0; i < B_RPT; ++i)
+      lds_dma16(wr, B + (wave_u * (64 / PPR) + RSTEP * i) * KB, b_voff[i] + wshift);
+    if (++l_chunk == cpt) {
+      l_chunk = 0;
+      ++l_tap;
+      if (++l_dz > 1) { l_dz = -1; if (++l_dy > 1) { l_dy = -1; ++l_dx; } }
+    }
+  };
+
   auto store_step = [&](int buf, const f4 (&ra)[A_RPT], const f4 (&rb)[B_RPT]) {
     char *A = lds + buf * (A_BYTES + B_BYTES);
     char *B = A + A_BYTES;
@@ -271,21 +308,37 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
   // Software pipeline: while step k is multiplied out of LDS buffer k&1, the loads of step k+1 are in flight into the
   // staging registers and are written to the other buffer after the MFMAs.  The loop is unrolled by two so both LDS
   // buffers are compile-time constants (immediate ds offsets, no address arithmetic in the loop).
-  load_step(ks_begin, ra0, rb0);
-  store_step(0, ra0, rb0);
-  __syncthreads();
   int ks = ks_begin;
-  while (ks < ks_end) {
-    if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
-    compute_step(0);
-    if (ks + 1 < ks_end) store_step(1, ra0, rb0);
+  if (GLDS && MODE == 0) {
+    // 2-buffer LDS-DMA pipeline: the DMA of step k+1 flies while step k is multiplied; __syncthreads() carries the vmcnt(0)
+    issue_glds(0);
     __syncthreads();
-    if (++ks >= ks_end) break;
-    if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
-    compute_step(1);
-    if (ks + 1 < ks_end) store_step(0, ra0, rb0);
+    while (ks < ks_end) {
+      if (ks + 1 < ks_end) issue_glds(1);
+      compute_step(0);
+      __syncthreads();
+      if (++ks >= ks_end) break;
+      if (ks + 1 < ks_end) issue_glds(0);
+      compute_step(1);
+      __syncthreads();
+      ++ks;
+    }
+  } else {
+    load_step(ks_begin, ra0, rb0);
+    store_step(0, ra0, rb0);
     __syncthreads();
-    ++ks;
+    while (ks < ks_end) {
+      if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+      compute_step(0);
+      if (ks + 1 < ks_end) store_step(1, ra0, rb0);
+      __syncthreads();
+      if (++ks >= ks_end) break;
+      if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+      compute_step(1);
+      if (ks + 1 < ks_end) store_step(0, ra0, rb0);
+      __syncthreads();
+      ++ks;
+    }
   }
 
   if (p.ksplit > 1) {   // partial sums; bias / ReLU / cast happen in splitk_epilogue_kernel
@@ -352,6 +405,8 @@ static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes)
   return s < 2 ? 1 : (int)s;
 }
 
+static int g_conv_glds = 1;   // 1: LDS-DMA loads (buffer_load ... lds), 0: register-staged loads
+extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
 static int g_conv_kb = 128;   // K-step bytes of the k1/k3 kernels (64 or 128); tuning knob, see tools/bench_conv.py
 static int g_conv_kb_value() { return g_conv_kb; }
 extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
@@ -364,9 +419,14 @@ template <typename T, int MODE>
 static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const int bn = (a.Cout <= 64) ? 64 : 128;
   dim3 grid((unsigned)(cdiv64(a.M, 128) * ((a.Cout + bn - 1) / bn) * (a.ksplit > 1 ? a.ksplit : 1)));
+  constexpr bool kDma = (MODE == 0);
   // the 128-byte K-step needs Cin*elemsize % 128 == 0; the stem gather keeps the 64-byte step
   const bool wide = MODE == 0 && g_conv_kb == 128 && (a.Cin * (int)sizeof(T)) % 128 == 0;
-#define NRPN_LC(BN_, OF_, KB_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_, KB_>), grid, dim3(256), 0, st, a)
+#define NRPN_LC(BN_, OF_, KB_)                                                                                                  \
+  do {                                                                                                                         \
+    if (kDma && g_conv_glds) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_, KB_, kDma>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_, KB_, false>), grid, dim3(256), 0, st, a);                    \
+  } while (0)
 #define NRPN_LC2(BN_, OF_) do { if (wide) NRPN_LC(BN_, OF_, 128); else NRPN_LC(BN_, OF_, 64); } while (0)
   if (bn == 64) { if (out_f32) NRPN_LC2(64, true); else NRPN_LC2(64, false); }
   else { if (out_f32) NRPN_LC2(128, true); else NRPN_LC2(128, false); }
