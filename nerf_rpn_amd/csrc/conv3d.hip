@@ -519,8 +519,15 @@ struct WgradArgs {
 };
 
 template <typename T> struct WgCfg;
-template <> struct WgCfg<float> { static constexpr int KV = 32, RS = 128 * 4 + 64; };
-template <> struct WgCfg<bf16s> { static constexpr int KV = 64, RS = 128 * 2 + 64; };
+template <> struct WgCfg<float> { static constexpr int KV = 32, RS = 128 * 4; };
+template <> struct WgCfg<bf16s> { static constexpr int KV = 64, RS = 128 * 2; };
+
+// Unpadded [voxel][channel] tile with the 16-byte slot index XOR-ed by (row & 3) << 2: LDS-DMA needs a linear destination
+// (1 KiB = 2-4 whole rows per wave-instruction), and the XOR spreads the four voxel rows a transpose-read lane group touches
+// over all 16 slots of a 256-byte bank row (conflict-free for ds_read_b64_tr_b16, ds_read_b32 and the 16-byte stores).
+__device__ __forceinline__ int wg_off(int row, int byte_in_row, int rs) {
+  return row * rs + ((((byte_in_row >> 4) ^ ((row & 3) << 2))) << 4) + (byte_in_row & 15);
+}
 
 // one 32(channel) x 16-byte K fragment out of a [voxel][channel] LDS tile
 template <typename T, bool TR>
@@ -534,7 +541,7 @@ __device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, i
     const int c = ctile0 + (lane & 31), h = lane >> 5;
     f4 v;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float *>(tile + (kbase + 4 * h + q) * RS + c * 4);
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float *>(tile + wg_off(kbase + 4 * h + q, c * 4, RS));
     return v;
   } else {
     // 16 bytes = 8 bf16 k-values for lane-half h: voxels kbase + 8h .. +7, channel ctile0 + (lane & 31)
@@ -545,8 +552,8 @@ __device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, i
       // 4j + (i >> 2), j = 0..3.  Lane p therefore addresses voxel (p >> 2), channels cbase + 4 (p & 3) .. +3.
       const int p = lane & 15;
       const int cbase = ctile0 + 16 * ((lane >> 4) & 1);
-      const int vb = kbase + 8 * h;
-      const char *a0 = tile + (vb + (p >> 2)) * RS + (cbase + 4 * (p & 3)) * 2;
+      const int row = kbase + 8 * h + (p >> 2);            // row + 4 has the same (row & 3): one offset serves both reads
+      const char *a0 = tile + wg_off(row, (cbase + 4 * (p & 3)) * 2, RS);
       const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0));
       const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0 + 4 * RS));
       typedef __attribute__((ext_vector_type(2))) long long l2v;
@@ -557,7 +564,7 @@ __device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, i
     typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
     u8v r;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const unsigned short *>(tile + (kbase + 8 * h + q) * RS + c * 2);
+    for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const unsigned short *>(tile + wg_off(kbase + 8 * h + q, c * 2, RS));
     return __builtin_bit_cast(f4, r);
   }
 }
@@ -607,7 +614,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
     const int pc = tid + 256 * i;
-    const int row = pc / PIECES_ROW, col = pc % PIECES_ROW;
+    const int row = pc / PIECES_ROW, col = (pc % PIECES_ROW) ^ ((row & 3) << 2);   // logical column of physical slot pc % PIECES_ROW
     const long long v = c_begin * KV + row;
     const int ca = m0 + col * (16 / (int)sizeof(T)), cb = n0 + col * (16 / (int)sizeof(T));
     a_voff[i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * (long long)sizeof(T)) : kOOB;
@@ -667,15 +674,34 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     }
   };
 
-  auto store_chunk = [&](int buf) {
+  // MODE 0: LDS-DMA straight into buffer `buf` (lane l of a wave-instruction lands at base + 16 l = physical slot order)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_dma = [&](int buf) {
+    char *A = lds + buf * 2 * TILE;
+    char *B = A + TILE;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int dst = (64 * wave_u + 256 * i) * 16;
+      lds_dma16(dyr, A + dst, a_voff[i]);
+      const bool in = (m_next[i] >> tap) & 1u;
+      lds_dma16(xr, B + dst, (in && b_voff[i] != kOOB) ? b_voff[i] : kOOB);
+      a_voff[i] = a_voff[i] == kOOB ? kOOB : a_voff[i] + a_step;
+      b_voff[i] = b_voff[i] == kOOB ? kOOB : b_voff[i] + b_step;
+      m_voff[i] += KV * 4;
+      if (use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
+      else m_next[i] = (m_voff[i] < (unsigned)(p.M * 4)) ? 1u : 0u;
+    }
+  };
+
+  auto store_chunk = [&](int buf) {   // register-staged path (stem gather): MODE-1 pieces are in logical column order
     char *A = lds + buf * 2 * TILE;
     char *B = A + TILE;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int pc = tid + 256 * i;
       const int row = pc / PIECES_ROW, col = pc % PIECES_ROW;
-      *reinterpret_cast<f4 *>(A + row * RS + col * 16) = ra[i];
-      *reinterpret_cast<f4 *>(B + row * RS + col * 16) = rb[i];
+      *reinterpret_cast<f4 *>(A + wg_off(row, col * 16, RS)) = ra[i];
+      *reinterpret_cast<f4 *>(B + wg_off(row, col * 16, RS)) = rb[i];
     }
   };
 
@@ -689,18 +715,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 
   const bool do_bias = p.gbias != nullptr && n0 == 0 && tap == ((MODE == 0 && p.taps == 27) ? 13 : 0);
   float bias_acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  load_chunk(c_begin);
-  store_chunk(0);
+  if (MODE == 0) issue_dma(0);
+  else { load_chunk(c_begin); store_chunk(0); }
   __syncthreads();
   int buf = 0;
   for (long long ch = c_begin; ch < c_end; ++ch) {
-    if (ch + 1 < c_end) load_chunk(ch + 1);
+    if (ch + 1 < c_end) { if (MODE == 0) issue_dma(buf ^ 1); else load_chunk(ch + 1); }
     const char *A = lds + buf * 2 * TILE;
     const char *B = A + TILE;
     if (do_bias) {   // thread t owns one 16-byte column group of the dY tile and every (256 / PIECES_ROW)-th voxel row
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) {
-        const f4 v = *reinterpret_cast<const f4 *>(A + (tid / PIECES_ROW + i * (256 / PIECES_ROW)) * RS + (tid % PIECES_ROW) * 16);
+        const f4 v = *reinterpret_cast<const f4 *>(A + (tid / PIECES_ROW + i * (256 / PIECES_ROW)) * RS + (tid % PIECES_ROW) * 16);   // physical slot
         if (sizeof(T) == 4) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) bias_acc[e] += v[e];
@@ -724,7 +750,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], af[i], bfv[j]);
     }
-    if (ch + 1 < c_end) store_chunk(buf ^ 1);
+    if (MODE != 0 && ch + 1 < c_end) store_chunk(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
@@ -733,7 +759,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     constexpr int EPP = 16 / (int)sizeof(T);
 #pragma unroll
     for (int e = 0; e < EPP; ++e) {
-      const int bc = m0 + (tid % PIECES_ROW) * EPP + e;
+      const int bc = m0 + ((tid % PIECES_ROW) ^ (((tid / PIECES_ROW) & 3) << 2)) * EPP + e;   // logical column of this thread's physical slot
       if (bc < p.Cout) atomicAdd(p.gbias + bc, bias_acc[e]);
     }
   }
