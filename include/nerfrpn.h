@@ -186,8 +186,10 @@ int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, i
 /* wgrad: gw_packed f32 [taps][wrows][Cin] (zero-filled by the call, split-K partials are atomically added);
  * optional gbias f32 [Cout] = column sums of dy. */
 size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int ksize);
+/* accumulate_bias != 0: the column sums are ADDED to gbias (e.g. a slot of a flat gradient arena) instead of overwriting. */
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
-                      int cin, int cout, int wrows, int ksize, int dtype, void *workspace, nrpn_stream_t stream);
+                      int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
+                      nrpn_stream_t stream);
 /* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
 int nrpn_set_conv_kstep_bytes(int kb);
 /* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */
@@ -204,7 +206,7 @@ int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *g
 int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz,
                          int cout, int stride, int dtype, int flags, nrpn_stream_t stream);
 int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
-                           int cout, int stride, int dtype, nrpn_stream_t stream);
+                           int cout, int stride, int dtype, int accumulate_bias, nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm3d / ReLU / MaxPool3d / nearest-upsample-add, channels-last.  [a3, a4, a21]
@@ -219,10 +221,10 @@ int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, float *mean, fl
 int nrpn_bn_apply(const void *x, void *y, int64_t rows, int c, int dtype, const float *mean, const float *var,
                   const float *gamma, const float *beta, float eps, int relu, nrpn_stream_t stream);
 /* backward of bn_apply(+relu) in train mode: given x (conv output), y (post-activation, for the ReLU mask) and dy,
- * writes dx and accumulates dgamma/dbeta (f32 [C], overwritten). */
+ * writes dx and dgamma/dbeta (f32 [C], overwritten); acc_dgamma / acc_dbeta (optional) are additionally incremented. */
 int nrpn_bn_backward(const void *x, const void *y, const void *dy, void *dx, int64_t rows, int c, int dtype,
                      const float *mean, const float *var, const float *gamma, float eps, int relu, float *dgamma,
-                     float *dbeta, void *workspace, nrpn_stream_t stream);
+                     float *dbeta, float *acc_dgamma, float *acc_dbeta, void *workspace, nrpn_stream_t stream);
 int nrpn_relu_backward(const void *y, const void *dy, void *dx, int64_t count, int dtype, nrpn_stream_t stream);
 /* MaxPool3d(k, stride s, pad p, ceil_mode) forward writes int8 argmax offsets (window-local) for the backward. */
 int nrpn_pool_out_size(int in, int k, int s, int p, int ceil_mode);

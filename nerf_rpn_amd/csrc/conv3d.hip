@@ -217,13 +217,12 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
           const int ix = a_x[i] * p.stride - 3 + dx, iy = a_y[i] * p.stride - 3 + dy, iz = a_z[i] * p.stride - 3 + dz;
           const bool in = a_ok[i] && tap < p.taps && (unsigned)ix < (unsigned)p.X && (unsigned)iy < (unsigned)p.Y &&
                           (unsigned)iz < (unsigned)p.Z;
-          if (in) {
-            const T *src = xbase + a_nbase[i] + (((long long)ix * p.Y + iy) * p.Z + iz) * 4;
-            if (sizeof(T) == 4) v = ldg16(src);
-            else {
-              const f2 h = *reinterpret_cast<const f2 *>(src);
-              v[2 * q] = h[0]; v[2 * q + 1] = h[1];
-            }
+          const unsigned off = in ? (unsigned)((a_nbase[i] + (((long long)ix * p.Y + iy) * p.Z + iz) * 4) * (long long)sizeof(T)) : kOOB;
+          if (sizeof(T) == 4) v = bufld16(xr, off);
+          else {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u2v;
+            const u2v h = __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0);
+            v[2 * q] = __uint_as_float(h[0]); v[2 * q + 1] = __uint_as_float(h[1]);
           }
         }
         ra[i] = v;
@@ -493,6 +492,11 @@ extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *
   a.OX = (gx + 6 - 7) / stride + 1; a.OY = (gy + 6 - 7) / stride + 1; a.OZ = (gz + 6 - 7) / stride + 1;
   a.M = (long long)n * a.OX * a.OY * a.OZ;
   a.Cin = 4; a.Cout = cout; a.wrows = cout; a.taps = 343; a.stride = stride; a.flags = flags & 3;
+  {
+    const long long xb = (long long)n * gx * gy * gz * 4 * (dtype == NRPN_F32 ? 4 : 2);
+    NRPN_REQUIRE(xb < (1ll << 31), "stem: input must stay below 2 GiB");
+    a.x_bytes = (unsigned)xb; a.w_bytes = 0;
+  }
   if (dtype == NRPN_F32) return launch_conv<float, 1>(a, true, as_stream(stream));
   return launch_conv<bf16s, 1>(a, false, as_stream(stream));
 }
@@ -645,14 +649,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
         const bool vok = v < p.M;
         {
           const int c0 = m0 + col * (16 / (int)sizeof(T));
-          ra[i] = (vok && c0 < p.Cout) ? ldg16(dybase + v * p.Cout + c0) : zero4();
+          ra[i] = bufld16(dyr, (vok && c0 < p.Cout) ? (unsigned)((v * p.Cout + c0) * (long long)sizeof(T)) : kOOB);
         }
         // stem: column = taps [t0, t0 + TPS) x 4 channels of the im2col row of output voxel v
         constexpr int TPS = 16 / (4 * (int)sizeof(T));
         f4 val = zero4();
-        if (vok) {
-          const int oz = (int)(v % p.OZ);
-          const long long t1 = v / p.OZ;
+        {
+          const long long vv = vok ? v : 0;
+          const int oz = (int)(vv % p.OZ);
+          const long long t1 = vv / p.OZ;
           const int oy = (int)(t1 % p.OY);
           const long long t2 = t1 / p.OY;
           const int ox = (int)(t2 % p.OX);
@@ -662,10 +667,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
             const int tp = (n0 / 4) + col * TPS + q;
             const int tx = tp / 49, ty = (tp / 7) % 7, tz = tp % 7;
             const int ix = ox * p.stride - 3 + tx, iy = oy * p.stride - 3 + ty, iz = oz * p.stride - 3 + tz;
-            if (tp < p.taps && (unsigned)ix < (unsigned)p.X && (unsigned)iy < (unsigned)p.Y && (unsigned)iz < (unsigned)p.Z) {
-              const T *src = xbase + nb + (((long long)ix * p.Y + iy) * p.Z + iz) * 4;
-              if (sizeof(T) == 4) val = ldg16(src);
-              else { const f2 h2 = *reinterpret_cast<const f2 *>(src); val[2 * q] = h2[0]; val[2 * q + 1] = h2[1]; }
+            const bool in = vok && tp < p.taps && (unsigned)ix < (unsigned)p.X && (unsigned)iy < (unsigned)p.Y && (unsigned)iz < (unsigned)p.Z;
+            const unsigned off = in ? (unsigned)((nb + (((long long)ix * p.Y + iy) * p.Z + iz) * 4) * (long long)sizeof(T)) : kOOB;
+            if (sizeof(T) == 4) val = bufld16(xr, off);
+            else {
+              typedef __attribute__((ext_vector_type(2))) unsigned int u2v;
+              const u2v h2 = __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0);
+              val[2 * q] = __uint_as_float(h2[0]); val[2 * q + 1] = __uint_as_float(h2[1]);
             }
           }
         }
@@ -890,7 +898,7 @@ extern "C" size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int g
 }
 
 extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz, int cin,
-                                 int cout, int wrows, int ksize, int dtype, void *workspace, nrpn_stream_t stream) {
+                                 int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_wgrad: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_wgrad: bad dtype %d", dtype);
   const int es = dtype == NRPN_F32 ? 4 : 2;
@@ -910,13 +918,13 @@ extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed
     hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz);
   NRPN_HIP(hipMemsetAsync(gw_packed, 0, (size_t)a.taps * wrows * cin * 4, st));
   a.gbias = gbias;
-  if (gbias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  if (gbias && !accumulate_bias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
   if (dtype == NRPN_F32) return launch_wgrad<float, 0>(a, (cin + 127) / 128, st);
   return launch_wgrad<bf16s, 0>(a, (cin + 127) / 128, st);
 }
 
 extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
-                                      int cout, int stride, int dtype, nrpn_stream_t stream) {
+                                      int cout, int stride, int dtype, int accumulate_bias, nrpn_stream_t stream) {
   NRPN_REQUIRE(stride == 1 || stride == 2, "stem wgrad: stride must be 1 or 2 (got %d)", stride);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "stem wgrad: bad dtype %d", dtype);
   const int es = dtype == NRPN_F32 ? 4 : 2;
@@ -931,9 +939,14 @@ extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_p
   const int ke = 64 / es;
   a.kpad = ((343 * 4 + ke - 1) / ke) * ke;
   hipStream_t st = as_stream(stream);
+  {
+    const long long xb = (long long)n * gx * gy * gz * 4 * es, db = a.M * cout * es;
+    NRPN_REQUIRE(xb < (1ll << 31) && db < (1ll << 31), "stem wgrad: tensors must stay below 2 GiB");
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db; a.vmask = nullptr;
+  }
   NRPN_HIP(hipMemsetAsync(gw_packed, 0, (size_t)cout * a.kpad * 4, st));
   a.gbias = gbias;
-  if (gbias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  if (gbias && !accumulate_bias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
   if (dtype == NRPN_F32) return launch_wgrad<float, 1>(a, (a.kpad + 127) / 128, st);
   return launch_wgrad<bf16s, 1>(a, (a.kpad + 127) / 128, st);
 }

@@ -56,6 +56,7 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
 #pragma unroll
       for (int k = 0; k < 4; ++k) is[k] = 1.0f / sqrtf(vv[k] + eps);
     }
+#pragma unroll 4
     for (long long r = r0 + ty; r < r1; r += ty_n) {
       const f4 xv = vec4<T>::ld(x + r * c + tx * 4);
       if (MODE == 0) {
@@ -123,13 +124,15 @@ __global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int 
 }
 
 __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblocks, int c, float *__restrict__ dbeta,
-                                       float *__restrict__ dgamma) {
+                                       float *__restrict__ dgamma, float *__restrict__ acc_beta, float *__restrict__ acc_gamma) {
   const int ch = blockIdx.x * 64 + threadIdx.x;
   double s, q;
   reduce_partials(partial, nblocks, c, ch, s, q);
   if (threadIdx.y != 0 || ch >= c) return;
   dbeta[ch] = (float)s;
   dgamma[ch] = (float)q;
+  if (acc_beta) acc_beta[ch] += (float)s;      // optional: accumulate straight into the flat gradient arena
+  if (acc_gamma) acc_gamma[ch] += (float)q;
 }
 
 extern "C" size_t nrpn_bn_workspace_bytes(int64_t rows, int c) { return (size_t)(cdiv64(rows, kSlab) * 2 * c * 4); }
@@ -222,15 +225,15 @@ __global__ void bn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict
 }
 
 extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, void *dx, int64_t rows, int c, int dtype, const float *mean,
-                                const float *var, const float *gamma, float eps, int relu, float *dgamma, float *dbeta, void *workspace,
-                                nrpn_stream_t stream) {
+                                const float *var, const float *gamma, float eps, int relu, float *dgamma, float *dbeta,
+                                float *acc_dgamma, float *acc_dbeta, void *workspace, nrpn_stream_t stream) {
   if (int rc = check_bn_shape("bn_backward", rows, c)) return rc;
   NRPN_REQUIRE(x && dy && dx && mean && var && gamma && dgamma && dbeta && workspace && (!relu || y), "bn_backward: null pointer");
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
                                        (long long)rows, c, mean, var, eps, relu, (float *)workspace));
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
   const long long groups = rows * (c / 4);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, st, (const T *)x, (const T *)y,
                                        (const T *)dy, (T *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu,

@@ -64,54 +64,70 @@ class FlatTrainer:
         self.lr, self.wd, self.clip, self.betas, self.eps = lr, weight_decay, clip_grad_norm, betas, eps
         self.total_steps = total_steps
         self.step_count = 0
+        # Gradient readiness.  Backward kernels accumulate straight into the arena slots (ops.GradSink) and call notify(i);
+        # gradients that still arrive through autograd fire the post-accumulate hook, which calls the same notify(i).
+        # A parameter can be used several times per step (the RPN head convs run on 4 pyramid levels), so the number of
+        # notifications per step is LEARNED during the first step (all buckets are reduced at the end of that step); from
+        # the second step on, a bucket's all-reduce is launched the moment its last expected notification arrives.
+        self.expected = None
+        self.seen = [0] * len(self.params)
+        for i, p in enumerate(self.params):
+            p._nrpn_sink = ops.GradSink(p.grad, self._make_notify(i))
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
         # buckets in reverse parameter order (gradients arrive roughly back to front)
         self.buckets = []       # (start, end) element ranges of g_arena
+        self.bucket_params = []
         self.bucket_of = {}
-        self.pending = []
         self.handles = []
         if self.world > 1:
-            if dev.type == "cuda":
-                dist.broadcast(self.p_arena, src=0, group=self.group)     # rank 0's weights everywhere (DDP init semantics)
-            else:
-                dist.broadcast(self.p_arena, src=0, group=self.group)
+            dist.broadcast(self.p_arena, src=0, group=self.group)     # rank 0's weights everywhere (DDP init semantics)
             per = max(1, bucket_bytes // 4)
             end = total
-            cur_start = total
-            count = 0
+            members = []
             for i in range(len(self.params) - 1, -1, -1):
                 o, n = self.slices[i]
-                cur_start = o
-                count += 1
+                members.append(i)
                 self.bucket_of[i] = len(self.buckets)
-                if end - cur_start >= per or i == 0:
-                    self.buckets.append((cur_start, end))
-                    self.pending.append(count)
-                    end, count = cur_start, 0
-            self._remaining = list(self.pending)
-            for i, p in enumerate(self.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                if end - o >= per or i == 0:
+                    self.buckets.append((o, end))
+                    self.bucket_params.append(members)
+                    end, members = o, []
+        self.launched = [False] * len(self.buckets)
+
+    def _make_notify(self, i):
+        def notify():
+            self.seen[i] += 1
+            if self.world > 1 and self.expected is not None:
+                b = self.bucket_of[i]
+                if not self.launched[b] and all(self.seen[j] >= self.expected[j] for j in self.bucket_params[b] if self.expected[j] > 0):
+                    self._launch(b)
+        return notify
 
     def _make_hook(self, i):
+        notify = self._make_notify(i)
+
         def hook(_):
-            b = self.bucket_of[i]
-            self._remaining[b] -= 1
-            if self._remaining[b] == 0:
-                s, e = self.buckets[b]
-                self.handles.append(dist.all_reduce(self.g_arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            notify()
         return hook
 
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        self.launched[b] = True
+        self.handles.append(dist.all_reduce(self.g_arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def sync_gradients(self):
-        """Wait for the in-flight bucket all-reduces; buckets whose hooks never fired (unused params) are reduced now."""
-        if self.world == 1:
-            return
-        for b, left in enumerate(self._remaining):
-            if left > 0:
-                s, e = self.buckets[b]
-                self.handles.append(dist.all_reduce(self.g_arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for h in self.handles:
-            h.wait()
-        self.handles = []
-        self._remaining = list(self.pending)
+        """Wait for the in-flight bucket all-reduces; buckets not launched yet (first step, unused parameters) go now."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                if not self.launched[b]:
+                    self._launch(b)
+            for h in self.handles:
+                h.wait()
+            self.handles = []
+            self.launched = [False] * len(self.buckets)
+        if self.expected is None:
+            self.expected = list(self.seen)
+        self.seen = [0] * len(self.params)
 
     def step(self):
         self.sync_gradients()

@@ -339,6 +339,20 @@ class FlattenHeadFn(torch.autograd.Function):
 # ======================================================================================================================
 # conv / norm / pool with autograd
 # ======================================================================================================================
+class GradSink:
+    """Direct gradient destination of a parameter inside a flat gradient arena (set by engine.FlatTrainer as
+    ``param._nrpn_sink``).  Backward kernels accumulate straight into ``slot`` and call ``notify()`` instead of returning a
+    gradient tensor for autograd to add -- this removes one elementwise kernel per parameter per use."""
+    __slots__ = ("slot", "notify")
+
+    def __init__(self, slot, notify):
+        self.slot, self.notify = slot, notify
+
+
+def _sink(t):
+    return getattr(t, "_nrpn_sink", None) if t is not None else None
+
+
 class PackedWeight:
     """GEMM-layout copies of one or more reference-layout conv weights sharing a GEMM (rows_total rows), refreshed when
     the parameters change (tensor._version)."""
@@ -402,6 +416,7 @@ class ConvFn(torch.autograd.Function):
         y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype)
         ctx.save_for_backward(x, y if relu else None, wpd, *weights)
         ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None)
+        ctx.sinks = ([_sink(w) for w in weights], [_sink(b) for b in biases])
         return y
 
     @staticmethod
@@ -421,17 +436,35 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype)
         taps = ksize ** 3
+        wsinks, bsinks = ctx.sinks
         gwp = torch.empty((taps, rows_total, cin), dtype=torch.float32, device=x.device)
-        gb = torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None
+        direct_bias = has_bias and nw == 1 and bsinks[0] is not None
+        gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
         wsb = query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, ksize)
         ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-        call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), _p(ws), _s())
+        call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), int(direct_bias),
+             _p(ws), _s())
         gws, gbs, row = [], [], 0
-        for w in weights:
-            gw = torch.empty_like(w, dtype=torch.float32)
-            call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(gw), 0, _s())
-            gws.append(gw)
-            gbs.append(gb[row:row + w.shape[0]].clone() if has_bias else None)
+        for i, w in enumerate(weights):
+            if wsinks[i] is not None:
+                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(wsinks[i].slot), 1, _s())
+                wsinks[i].notify()
+                gws.append(None)
+            else:
+                gw = torch.empty_like(w, dtype=torch.float32)
+                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(gw), 0, _s())
+                gws.append(gw)
+            if not has_bias:
+                gbs.append(None)
+            elif direct_bias:
+                bsinks[0].notify()
+                gbs.append(None)
+            elif bsinks[i] is not None:
+                bsinks[i].slot.add_(gb[row:row + w.shape[0]])
+                bsinks[i].notify()
+                gbs.append(None)
+            else:
+                gbs.append(gb[row:row + w.shape[0]].clone())
             row += w.shape[0]
         return (dx, None, None, None, None, None, *gws, *gbs)
 
@@ -457,6 +490,7 @@ class StemFn(torch.autograd.Function):
         call("conv3d_stem_fwd", _p(x), _p(wp), _p(b), _p(y), n, gx, gy, gz, cout, stride, _dt(x), CONV_BIAS if b is not None else 0, _s())
         ctx.save_for_backward(x, weight)
         ctx.meta = (stride, bias is not None)
+        ctx.sinks = (_sink(weight), _sink(bias))
         return y
 
     @staticmethod
@@ -468,10 +502,20 @@ class StemFn(torch.autograd.Function):
         cout = weight.shape[0]
         kpad = query("stem_kpad", _dt(x))
         gwp = torch.empty((cout, kpad), dtype=torch.float32, device=x.device)
-        gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
-        call("conv3d_stem_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cout, stride, _dt(x), _s())
-        gw = torch.empty_like(weight, dtype=torch.float32)
-        call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(gw), 0, _s())
+        wsink, bsink = ctx.sinks
+        direct_bias = has_bias and bsink is not None
+        gb = bsink.slot if direct_bias else (torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None)
+        call("conv3d_stem_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cout, stride, _dt(x), int(direct_bias), _s())
+        if wsink is not None:
+            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(wsink.slot), 1, _s())
+            wsink.notify()
+            gw = None
+        else:
+            gw = torch.empty_like(weight, dtype=torch.float32)
+            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(gw), 0, _s())
+        if direct_bias:
+            bsink.notify()
+            gb = None
         return None, gw, gb, None, None
 
 
@@ -496,6 +540,7 @@ class BatchNormFn(torch.autograd.Function):
         call("bn_apply", _p(x), _p(y), rows, c, _dt(x), _p(mean), _p(var), _p(g32), _p(b32), float(eps), int(relu), _s())
         ctx.save_for_backward(x, y, mean, var, g32)
         ctx.meta = (training, eps, relu)
+        ctx.sinks = (_sink(gamma), _sink(beta))
         return y
 
     @staticmethod
@@ -512,8 +557,15 @@ class BatchNormFn(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=dev)
+        gsink, bsink = ctx.sinks
         call("bn_backward", _p(x), _p(y), _p(dy), _p(dx), rows, c, _dt(x), _p(mean), _p(var), _p(g32), float(eps), int(relu), _p(dgamma),
-             _p(dbeta), _p(ws), _s())
+             _p(dbeta), _p(gsink.slot) if gsink is not None else 0, _p(bsink.slot) if bsink is not None else 0, _p(ws), _s())
+        if gsink is not None:
+            gsink.notify()
+            dgamma = None
+        if bsink is not None:
+            bsink.notify()
+            dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
