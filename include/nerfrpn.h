@@ -237,6 +237,12 @@ int nrpn_upsample_add_fwd(void *fine, const void *coarse, int n, int fx, int fy,
                           int dtype, nrpn_stream_t stream);
 int nrpn_upsample_add_bwd(const void *dfine, void *dcoarse, int n, int fx, int fy, int fz, int cx, int cy, int cz,
                           int c, int dtype, int accumulate, nrpn_stream_t stream);
+/* ResNet bottleneck pieces (feature_extractor.py:31-68): strided 1x1x1 conv = voxel subsample (x*s, y*s, z*s) + 1x1x1 GEMM;
+ * backward != 0 scatters a [N,ceil(X/s),..,C] gradient back into a zero-filled [N,X,Y,Z,C].  y = relu?(a + b) is the
+ * residual join (its backward is nrpn_relu_backward on y). */
+int nrpn_subsample3d(const void *src, void *dst, int n, int gx, int gy, int gz, int c, int stride, int backward, int dtype,
+                     nrpn_stream_t stream);
+int nrpn_add_relu(const void *a, const void *b, void *y, int64_t count, int relu, int dtype, nrpn_stream_t stream);
 /* layout / dtype conversion between the reference's [N,C,X,Y,Z] f32 and channels-last f32|bf16 */
 int nrpn_ncdhw_to_ndhwc(const float *src, void *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
 int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);

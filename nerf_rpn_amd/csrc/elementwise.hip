@@ -43,7 +43,11 @@ __global__ void __launch_bounds__(256)
 chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, long long rows, int c,
                     const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu, float *__restrict__ partial) {
   __shared__ float red[2][256][4];
-  const int ct = c / 4;                       // channel groups (<= 256)
+  // channels are tiled over blockIdx.y in chunks of `cw` (<= 1024) so any C that is a multiple of 4 works
+  const int cw = min(c, 1024), coff = blockIdx.y * 1024;
+  x += coff; y = y ? y + coff : y; dy = dy ? dy + coff : dy;
+  if (MODE == 1) { mean += coff; var += coff; }
+  const int ct = min(cw, c - coff) / 4;       // channel groups of this tile (<= 256)
   const int ty_n = 256 / ct;                  // row lanes
   const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
   const long long r0 = (long long)blockIdx.x * kSlab, r1 = min(rows, r0 + kSlab);
@@ -82,7 +86,7 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
     for (int q = 0; q < ty_n; ++q)
 #pragma unroll
       for (int k = 0; k < 4; ++k) { a[k] += red[0][q * ct + threadIdx.x][k]; b[k] += red[1][q * ct + threadIdx.x][k]; }
-    float *out = partial + (long long)blockIdx.x * 2 * c;
+    float *out = partial + (long long)blockIdx.x * 2 * c + coff;
     *reinterpret_cast<f4 *>(out + threadIdx.x * 4) = a;
     *reinterpret_cast<f4 *>(out + c + threadIdx.x * 4) = b;
   }
@@ -138,8 +142,9 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb
 extern "C" size_t nrpn_bn_workspace_bytes(int64_t rows, int c) { return (size_t)(cdiv64(rows, kSlab) * 2 * c * 4); }
 
 static int check_bn_shape(const char *who, int64_t rows, int c) {
-  if (rows <= 0 || c <= 0 || c % 4 != 0 || c > 1024 || 256 % (c / 4) != 0)
-    return nrpn_fail(NRPN_ERR_ARG, "%s: C=%d must be a multiple of 4 with C/4 dividing 256 (rows=%lld)", who, c, (long long)rows);
+  const int tile = c > 1024 ? 1024 : c;
+  if (rows <= 0 || c <= 0 || c % 4 != 0 || c % tile != 0 || 256 % (tile / 4) != 0)
+    return nrpn_fail(NRPN_ERR_ARG, "%s: C=%d must be a multiple of 4 with min(C,1024)/4 dividing 256 and C %% 1024 == 0 above 1024 (rows=%lld)", who, c, (long long)rows);
   return 0;
 }
 
@@ -149,7 +154,7 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
   NRPN_REQUIRE(x && mean && var && workspace, "bn_stats: null pointer");
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 0>), dim3(nb), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
+  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 0>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
                                        (const T *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0,
                                        (float *)workspace));
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
@@ -231,7 +236,7 @@ extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, vo
   NRPN_REQUIRE(x && dy && dx && mean && var && gamma && dgamma && dbeta && workspace && (!relu || y), "bn_backward: null pointer");
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
+  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
                                        (long long)rows, c, mean, var, eps, relu, (float *)workspace));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
   const long long groups = rows * (c / 4);
@@ -468,6 +473,67 @@ extern "C" int nrpn_upsample_add_bwd(const void *dfine, void *dcoarse, int n, in
   DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_bwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)dfine,
                                        (T *)dcoarse, n, fx, fy, fz, cx, cy, cz, c, accumulate));
   NRPN_LAUNCH_CHECK("upsample_add_bwd");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// strided 1x1x1 convolutions of the ResNet bottlenecks = voxel subsample (every s-th voxel per axis) + plain 1x1x1 GEMM;
+// residual join  y = relu(a + b)
+// =====================================================================================================================
+template <typename T, bool FWD>
+__global__ void subsample_kernel(const T *__restrict__ src, T *__restrict__ dst, int n, int gx, int gy, int gz, int ox, int oy, int oz,
+                                 int c, int s) {
+  // FWD: dst[n,ox,oy,oz,c] = src[n, x*s, y*s, z*s, c];  !FWD: dst[n,gx,gy,gz,c] = (x,y,z all multiples of s) ? src[..] : 0
+  const int ct = c / 4;
+  const long long total = (long long)n * (FWD ? (long long)ox * oy * oz : (long long)gx * gy * gz) * ct;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(g % ct) * 4;
+    long long v = g / ct;
+    const int dz = FWD ? oz : gz, dy = FWD ? oy : gy, dx = FWD ? ox : gx;
+    const int z = (int)(v % dz); v /= dz;
+    const int y = (int)(v % dy); v /= dy;
+    const int x = (int)(v % dx);
+    const long long b = v / dx;
+    if (FWD) {
+      vec4<T>::st(dst + (g / ct) * (long long)c + cg, vec4<T>::ld(src + ((((b * gx + x * s) * gy + y * s) * gz + z * s) * (long long)c + cg)));
+    } else {
+      f4 val = {0, 0, 0, 0};
+      if (x % s == 0 && y % s == 0 && z % s == 0) val = vec4<T>::ld(src + ((((b * ox + x / s) * oy + y / s) * oz + z / s) * (long long)c + cg));
+      vec4<T>::st(dst + (g / ct) * (long long)c + cg, val);
+    }
+  }
+}
+
+extern "C" int nrpn_subsample3d(const void *src, void *dst, int n, int gx, int gy, int gz, int c, int stride, int backward, int dtype,
+                                nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && dst && n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && stride >= 1, "subsample3d: bad args");
+  const int ox = (gx - 1) / stride + 1, oy = (gy - 1) / stride + 1, oz = (gz - 1) / stride + 1;
+  const long long total = (long long)n * (backward ? (long long)gx * gy * gz : (long long)ox * oy * oz) * (c / 4);
+  if (backward) { DISPATCH_T(dtype, hipLaunchKernelGGL((subsample_kernel<T, false>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                                                       (const T *)src, (T *)dst, n, gx, gy, gz, ox, oy, oz, c, stride)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((subsample_kernel<T, true>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                                              (const T *)src, (T *)dst, n, gx, gy, gz, ox, oy, oz, c, stride)); }
+  NRPN_LAUNCH_CHECK("subsample3d");
+  return NRPN_OK;
+}
+
+template <typename T>
+__global__ void add_relu_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ y, long long groups, int relu) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long long)gridDim.x * blockDim.x) {
+    const f4 av = vec4<T>::ld(a + g * 4), bv = vec4<T>::ld(b + g * 4);
+    f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = av[k] + bv[k]; if (relu) o[k] = fmaxf(o[k], 0.f); }
+    vec4<T>::st(y + g * 4, o);
+  }
+}
+
+extern "C" int nrpn_add_relu(const void *a, const void *b, void *y, int64_t count, int relu, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(a && b && y && count > 0 && count % 4 == 0, "add_relu: count must be a positive multiple of 4");
+  const long long groups = count / 4;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(add_relu_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream), (const T *)a,
+                                       (const T *)b, (T *)y, groups, relu));
+  NRPN_LAUNCH_CHECK("add_relu");
   return NRPN_OK;
 }
 

@@ -27,7 +27,9 @@ def conv3d(mod, x, relu=False, out_f32=False):
         if relu:
             raise NotImplementedError("stem is always followed by BatchNorm in this model family")
         return y
-    if k not in (1, 3) or mod.stride[0] != 1 or mod.padding[0] != k // 2:
+    if k == 1 and mod.stride[0] > 1 and mod.padding[0] == 0:
+        x = ops.SubsampleFn.apply(x, mod.stride[0])      # strided 1x1x1 conv = subsample + 1x1x1 GEMM
+    elif k not in (1, 3) or mod.stride[0] != 1 or mod.padding[0] != k // 2:
         raise NotImplementedError(f"Conv3d k={k} stride={mod.stride} padding={mod.padding} has no HIP kernel yet")
     return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, relu, out_f32, 1, mod.weight, mod.bias)
 

@@ -617,6 +617,54 @@ class UpsampleAddFn(torch.autograd.Function):
         return d, dc
 
 
+class SubsampleFn(torch.autograd.Function):
+    """Every s-th voxel per axis (the spatial part of a stride-s 1x1x1 convolution)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        _chk(x)
+        n, gx, gy, gz, c = x.shape
+        o = [(g - 1) // s + 1 for g in (gx, gy, gz)]
+        y = torch.empty((n, o[0], o[1], o[2], c), dtype=x.dtype, device=x.device)
+        call("subsample3d", _p(x), _p(y), n, gx, gy, gz, c, s, 0, _dt(x), _s())
+        ctx.meta = (x.shape, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, s = ctx.meta
+        dy = dy.contiguous()
+        n, gx, gy, gz, c = shape
+        dx = torch.empty(shape, dtype=dy.dtype, device=dy.device)
+        call("subsample3d", _p(dy), _p(dx), n, gx, gy, gz, c, s, 1, _dt(dy), _s())
+        return dx, None
+
+
+class AddReluFn(torch.autograd.Function):
+    """y = relu(a + b): the residual join of a bottleneck (reference feature_extractor.py:63-66)."""
+
+    @staticmethod
+    def forward(ctx, a, b, relu):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        y = torch.empty_like(a)
+        call("add_relu", _p(a), _p(b), _p(y), a.numel(), int(relu), _dt(a), _s())
+        ctx.relu = relu
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            g = torch.empty_like(dy)
+            call("relu_backward", _p(y), _p(dy), _p(g), dy.numel(), _dt(dy), _s())
+        else:
+            g = dy
+        return g, g, None
+
+
 class _ToChannelsLast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dtype):

@@ -82,3 +82,65 @@ class RPNHead(nn.Module):
             logits.append(self.cls_logits(t))
             deltas.append(self.bbox_pred(t))
         return logits, deltas
+
+
+class Bottleneck(nn.Module):
+    """feature_extractor.py:31-68 (stride on the first 1x1x1 conv)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv3d(inplanes, planes, 1, stride=stride, bias=False)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = nn.Conv3d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm3d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        r = x if self.downsample is None else self.downsample(x)
+        return F.relu(y + r)
+
+
+class ResNetFPN(nn.Module):
+    """ResNet_FPN_256(Bottleneck, layers, 4, is_max_pool); feature_extractor.py:145-235."""
+
+    def __init__(self, layers=(3, 4, 6, 3), is_max_pool=True):
+        super().__init__()
+        self.out_channels = 256
+        self.is_max_pool = is_max_pool
+        self.conv1 = nn.Conv3d(4, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm3d(64)
+        self.layers = nn.ModuleList()
+        inp = 64
+        for i, depth in enumerate(layers):
+            planes, stride = 64 * 2 ** i, (1 if i == 0 else 2)
+            ds = None
+            if stride != 1 or inp != planes * 4:
+                ds = nn.Sequential(nn.Conv3d(inp, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm3d(planes * 4))
+            blocks = [Bottleneck(inp, planes, stride, ds)]
+            inp = planes * 4
+            blocks += [Bottleneck(inp, planes) for _ in range(1, depth)]
+            self.layers.append(nn.Sequential(*blocks))
+        self.smooths = nn.ModuleList(nn.Conv3d(256, 256, 3, padding=1) for _ in range(len(layers) - 1))
+        self.latlayers = nn.ModuleList(nn.Conv3d(4 * 64 * 2 ** i, 256, 1) for i in range(len(layers) - 1, -1, -1))
+
+    def forward(self, x):
+        c = F.relu(self.bn1(self.conv1(x)))
+        if self.is_max_pool:
+            c = F.max_pool3d(c, 3, 2, 1)
+        taps = []
+        for stage in self.layers:
+            c = stage(c)
+            taps.append(c)
+        p = [self.latlayers[0](taps[-1])]
+        for i in range(len(self.latlayers) - 1):
+            lat = self.latlayers[i + 1](taps[-2 - i])
+            p.append(F.interpolate(p[i], size=lat.shape[2:], mode="nearest") + lat)
+        for i, sm in enumerate(self.smooths):
+            p[i + 1] = sm(p[i + 1])
+        return p[::-1]

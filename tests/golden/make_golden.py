@@ -26,7 +26,7 @@ from oracle import anchors as OA, boxes as OB, coders as OC, geometry as OG, net
 from model import anchor as R_anchor, utils as R_utils, rpn as R_rpn  # noqa: E402
 from model.coder import AABBCoder, MidpointOffsetCoder  # noqa: E402
 from model.coder import misc as R_misc  # noqa: E402
-from model.feature_extractor import VGG_FPN  # noqa: E402
+from model.feature_extractor import VGG_FPN, ResNet_FPN_256, Bottleneck  # noqa: E402
 from model.nerf_rpn import NeRFRegionProposalNetwork  # noqa: E402
 from model.rotated_iou import oriented_iou_loss as R_iou, box_intersection_2d as R_b2d  # noqa: E402
 import run_rpn as R_run  # noqa: E402
@@ -198,7 +198,8 @@ def gen_nms():
 
 
 def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
-    bb = VGG_FPN("EF", 4, True, resolution)
+    bb = ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True) if kw.get("backbone") == "resnet" \
+        else VGG_FPN("EF", 4, True, resolution)
     hd = R_anchor.RPNHead(256, 13, 4, rotate=rotated)
     seeded_state(bb, 1); seeded_state(hd, 2)
     return NeRFRegionProposalNetwork(bb, ref_anchor_gen(), hd, rpn_pre_nms_top_n_train=2500, rpn_pre_nms_top_n_test=kw.get("pre", 2500),
@@ -208,7 +209,7 @@ def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
 
 
 def build_oracle(rotated, resolution, reg_loss="smooth_l1", **kw):
-    bb = ON.VGGFPN("EF", 4, resolution)
+    bb = ON.ResNetFPN() if kw.get("backbone") == "resnet" else ON.VGGFPN("EF", 4, resolution)
     hd = ON.RPNHead(256, 13, 4, rotated)
     seeded_state(bb, 1); seeded_state(hd, 2)
     return OR.Detector(bb, OR.RPN(hd, rotated=rotated, reg_loss_type=reg_loss, pre_nms_top_n=kw.get("pre", 2500),
@@ -230,8 +231,12 @@ def gen_eval():
     cases = [("eval_aabb_s2", False, 160, [(48, 48, 48)], {}),
              ("eval_obb_s2", True, 160, [(48, 40, 32)], {}),
              ("eval_obb_s1_cfg0", True, 64, [(16, 16, 16)], {"pre": 600}),       # BASELINE config[0] at 16^3
-             ("eval_aabb_batch2", False, 160, [(48, 48, 32), (40, 32, 32)], {})]
+             ("eval_aabb_batch2", False, 160, [(48, 48, 32), (40, 32, 32)], {}),
+             ("eval_resnet_obb", True, 160, [(64, 56, 48)], {"backbone": "resnet"})]
+    only = os.environ.get("GOLDEN_ONLY")
     for name, rot, res, shapes, kw in cases:
+        if only and only not in name:
+            continue
         ref = build_ref(rot, res, **kw).eval()
         orc = build_oracle(rot, res, **kw)
         orc.backbone.eval()
@@ -239,7 +244,7 @@ def gen_eval():
         with torch.no_grad():
             (feats, props, lvls), _, scores = ref([x.clone() for x in xs])
             (ofeats, oprops, olvls), _, oscores, aux = orc([x.clone() for x in xs])
-        arrs = {"shapes": shapes, "rotated": rot, "resolution": res, "pre": kw.get("pre", 2500)}
+        arrs = {"shapes": shapes, "rotated": rot, "resolution": res, "pre": kw.get("pre", 2500), "backbone": kw.get("backbone", "vgg")}
         for i, (f, of) in enumerate(zip(feats, ofeats)):
             close(of, f, 5e-4, f"{name} feat{i}")
             idx, val = subsample(f)
@@ -254,15 +259,20 @@ def gen_eval():
 
 def gen_train():
     print("end-to-end train")
-    cases = [("train_aabb", False, "smooth_l1", [(48, 48, 48)]),
+    cases = [("train_resnet_aabb", False, "smooth_l1", [(64, 56, 48)]),
+             ("train_aabb", False, "smooth_l1", [(48, 48, 48)]),
              ("train_obb", True, "smooth_l1", [(48, 40, 32)]),
              ("train_obb_iou", True, "iou", [(48, 40, 32)]),
              ("train_obb_giou", True, "giou", [(48, 40, 32)]),
              ("train_obb_diou", True, "diou", [(48, 40, 32)]),
              ("train_aabb_batch2", False, "smooth_l1", [(48, 48, 32), (40, 32, 32)])]
+    only = os.environ.get("GOLDEN_ONLY")
     for name, rot, loss, shapes in cases:
-        ref = build_ref(rot, 160, loss).train()
-        orc = build_oracle(rot, 160, loss)
+        if only and only not in name:
+            continue
+        bk = {"backbone": "resnet"} if "resnet" in name else {}
+        ref = build_ref(rot, 160, loss, **bk).train()
+        orc = build_oracle(rot, 160, loss, **bk)
         orc.backbone.train(); orc.rpn.head.train()
         xs = [scene(s, 200 + i) for i, s in enumerate(shapes)]
         g = torch.Generator().manual_seed(77)
@@ -281,7 +291,7 @@ def gen_train():
         _, olosses, _, aux = orc([x.clone() for x in xs], [t.clone() for t in gts], training=True)
         ototal = olosses["loss_objectness"] + 5.0 * olosses["loss_rpn_box_reg"] + 0.0 * olosses["loss_rpn_box_reg_2d"]
         ototal.backward()
-        arrs = {"shapes": shapes, "rotated": rot, "reg_loss_type": loss, "seed": 1234}
+        arrs = {"shapes": shapes, "rotated": rot, "reg_loss_type": loss, "seed": 1234, "backbone": bk.get("backbone", "vgg")}
         for k in losses:
             e = close(olosses[k], losses[k], 2e-5 * max(1.0, abs(losses[k].item())), f"{name} {k}")
             arrs[k] = losses[k]
@@ -289,7 +299,7 @@ def gen_train():
         # the same algorithm evaluated in float64 (oracle == reference in fp32, so this is the reference algorithm's exact
         # value): lets the GPU tests judge cancellation-prone gradients (BN biases, stem weights) against the truth and
         # against the fp32 reference's own rounding error instead of against an arbitrary tolerance.
-        o64 = build_oracle(rot, 160, loss)
+        o64 = build_oracle(rot, 160, loss, **bk)
         o64.backbone.double().train(); o64.rpn.head.double()
         ppos, pneg = aux["sampled"]["pos"], aux["sampled"]["neg"]
         o64.rpn.sampler_hook = lambda labels: (ppos, pneg)
