@@ -1,0 +1,186 @@
+"""Scene loading with the reference's dataset class names and ``__getitem__`` contract
+(reference nerf_rpn/datasets.py:14-330): ``(rgbsigma [4,W,L,H] float32, boxes [G,6|7] | None, scene_name)``.
+
+Host-side I/O only (npz / npy / csv -> torch CPU tensors); the arithmetic of the hot path starts when the trainer moves the
+grid to the GPU.  ``density_to_alpha`` keeps the reference formula alpha = clip(1 - exp(-exp(sigma) / 100), 0, 1)
+(datasets.py:165-167; ScanNet variant with a ReLU activation, :227-231)."""
+import os
+import random
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def density_to_alpha(density):
+    return np.clip(1.0 - np.exp(-np.exp(density) / 100.0), 0.0, 1.0)
+
+
+def density_to_alpha_relu(density):
+    return np.clip(1.0 - np.exp(-np.clip(density, a_min=0, a_max=None) / 100.0), 0.0, 1.0)
+
+
+def _grid_from_npz(path, normalize_density):
+    with np.load(path) as f:
+        g = f["rgbsigma"]
+        if normalize_density:
+            g[..., -1] = density_to_alpha(g[..., -1])
+        t = torch.from_numpy(np.transpose(g, (3, 0, 1, 2)))          # (W,L,H,C) -> (C,W,L,H)
+        if t.dtype == torch.uint8:
+            t = t.float() / 255.0
+    return t
+
+
+def rotate_and_scale_scene(rgbsigma, boxes, angle, scale):
+    """In-plane rotation by ``angle`` and isotropic scaling of a scene and its OBBs (datasets.py:291-329)."""
+    assert boxes is None or boxes.shape[1] == 7
+    xform = torch.tensor([[np.cos(angle), -np.sin(angle), 0], [np.sin(angle), np.cos(angle), 0], [0, 0, 1]], dtype=torch.float) * scale
+    res = rgbsigma.shape[1:]
+    axes = [torch.linspace(-1, 1, r) * r / 2 for r in res]
+    grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(-1, 3) @ xform.T
+    grid = grid[..., [2, 1, 0]].reshape(res[0], res[1], res[2], 3)
+    for k, r in enumerate((res[2], res[1], res[0])):
+        grid[..., k] = grid[..., k] / (r / 2)
+    rgbsigma = F.grid_sample(rgbsigma.unsqueeze(0), grid.unsqueeze(0), align_corners=True).squeeze(0)
+    if boxes is not None:
+        boxes = boxes.clone()
+        boxes[:, 6] = boxes[:, 6] - angle
+        boxes[:, 3:6] = boxes[:, 3:6] / scale
+        center = torch.tensor(res).unsqueeze(0) / 2
+        boxes[:, :3] = (boxes[:, :3] - center) @ (xform.to(boxes.dtype) / (scale * scale)) + center
+    return rgbsigma, boxes
+
+
+class BaseDataset(torch.utils.data.Dataset):
+    def __init__(self, dataset_type: str = None, features_path: str = None, boxes_path: str = None,
+                 scene_list: Optional[List[str]] = None, normalize_density: bool = True, flip_prob: float = 0.0,
+                 rotate_prob: float = 0.0, rot_scale_prob: float = 0.0, z_up: bool = True) -> None:
+        super().__init__()
+        self.dataset_type = dataset_type
+        self.features_path, self.boxes_path = features_path, boxes_path
+        self.scene_list = scene_list
+        self.normalize_density = normalize_density
+        self.flip_prob, self.rotate_prob, self.rot_scale_prob = flip_prob, rotate_prob, rot_scale_prob
+        self.z_up = z_up
+        self.scene_data = []
+
+    density_to_alpha = staticmethod(density_to_alpha)
+
+    def load_single_scene(self, scene: str):
+        boxes = None if self.boxes_path is None else torch.from_numpy(np.load(os.path.join(self.boxes_path, scene + ".npy")))
+        return scene, _grid_from_npz(os.path.join(self.features_path, scene + ".npz"), self.normalize_density), boxes
+
+    def load_scene_data(self, preload: bool = False):
+        if self.scene_list is None:
+            self.scene_list = [f.split(".")[0] for f in os.listdir(self.features_path) if f.endswith(".npz")]
+        kept = []
+        for scene in self.scene_list:
+            if not os.path.isfile(os.path.join(self.features_path, scene + ".npz")):
+                print(f"{scene} does not have a feature file")
+                continue
+            if self.boxes_path is not None and np.load(os.path.join(self.boxes_path, scene + ".npy")).shape[0] == 0:
+                print(f"{scene} does not have any boxes")
+                continue
+            kept.append(scene)
+        self.scene_list = kept
+        if preload:
+            self.scene_data = [self.load_single_scene(s) for s in self.scene_list]
+
+    def __getitem__(self, index: int):
+        if self.scene_data:
+            scene, rgbsigma, boxes = self.scene_data[index]
+        else:
+            scene = self.scene_list[index]
+            _, rgbsigma, boxes = self.load_single_scene(scene)
+        if self.flip_prob > 0 or self.rotate_prob > 0 or self.rot_scale_prob > 0:
+            rgbsigma, boxes = self.augment_rpn_inputs(rgbsigma, boxes, self.flip_prob, self.rotate_prob, self.rot_scale_prob, self.z_up)
+        return rgbsigma, boxes, scene
+
+    def __len__(self) -> int:
+        return len(self.scene_list)
+
+    @staticmethod
+    def augment_rpn_inputs(rgbsigma: Tensor, boxes: Tensor, flip_prob: float, rotate_prob: float, rot_scale_prob: float,
+                           z_up: bool = True) -> Tuple[Tensor, Tensor]:
+        """90-degree rotation, axis flips, small rotation+scale (datasets.py:109-163); consumes python's ``random``."""
+        for name, p in (("flip_prob", flip_prob), ("rotate_prob", rotate_prob), ("rotate_and_scale_prob", rot_scale_prob)):
+            if p < 0 or p > 1:
+                raise ValueError(f"{name} must be between 0 and 1, but got {p}")
+        if boxes is not None:
+            assert (z_up and boxes.shape[1] == 7) or boxes.shape[1] == 6, "z_up must be True when boxes are in (x, y, z, w, l, h, t) format"
+        if random.random() < rotate_prob:
+            a, b = (1, 2) if z_up else (1, 3)
+            rgbsigma = torch.flip(torch.transpose(rgbsigma, a, b), [a if z_up else 3])
+            if boxes is not None:
+                boxes = boxes.clone()
+                if boxes.shape[1] == 6:
+                    if z_up:
+                        boxes[:, [0, 1, 3, 4]] = boxes[:, [1, 0, 4, 3]]
+                        boxes[:, [0, 3]] = rgbsigma.shape[1] - boxes[:, [3, 0]]
+                    else:
+                        boxes[:, [0, 2, 3, 5]] = boxes[:, [2, 0, 5, 3]]
+                        boxes[:, [2, 5]] = rgbsigma.shape[3] - boxes[:, [5, 2]]
+                else:
+                    boxes[:, [0, 1, 3, 4]] = boxes[:, [1, 0, 4, 3]]
+                    boxes[:, 0] = rgbsigma.shape[1] - boxes[:, 0]
+        for axis in ([0, 1] if z_up else [0, 2]):
+            if random.random() < flip_prob:
+                rgbsigma = rgbsigma.flip(dims=[axis + 1])
+                if boxes is not None:
+                    boxes = boxes.clone()
+                    if boxes.shape[1] == 6:
+                        boxes[:, [axis, axis + 3]] = rgbsigma.shape[axis + 1] - boxes[:, [axis + 3, axis]]
+                    else:
+                        boxes[:, axis] = rgbsigma.shape[axis + 1] - boxes[:, axis]
+                        boxes[:, -1] = -boxes[:, -1]
+        if boxes is not None and boxes.shape[1] == 7 and random.random() < rot_scale_prob:
+            rgbsigma, boxes = rotate_and_scale_scene(rgbsigma, boxes, random.uniform(-np.pi / 18, np.pi / 18), random.uniform(0.9, 1.1))
+        return rgbsigma, boxes
+
+    @staticmethod
+    def collate_fn(batch):
+        return [b[0] for b in batch], [b[1] for b in batch], [b[2] for b in batch]
+
+
+class Front3DRPNDataset(BaseDataset):
+    def __init__(self, features_path, boxes_path, scene_list=None, normalize_density=True, flip_prob=0.0, rotate_prob=0.0,
+                 rot_scale_prob=0.0, preload=False):
+        super().__init__("3dfront", features_path, boxes_path, scene_list, normalize_density, flip_prob, rotate_prob, rot_scale_prob)
+        self.load_scene_data(preload=preload)
+
+
+class HypersimRPNDataset(BaseDataset):
+    def __init__(self, features_path, boxes_path, scene_list=None, normalize_density=True, flip_prob=0.0, rotate_prob=0.0,
+                 rot_scale_prob=0.0, preload=False):
+        super().__init__("hypersim", features_path, boxes_path, scene_list, normalize_density, flip_prob, rotate_prob, rot_scale_prob)
+        self.load_scene_data(preload=preload)
+
+
+class ScanNetRPNDataset(BaseDataset):
+    def __init__(self, scene_list, features_path, boxes_path, flip_prob=0.0, rotate_prob=0.0, rot_scale_prob=0.0):
+        super().__init__("hypersim", features_path, boxes_path, scene_list, False, flip_prob, rotate_prob, rot_scale_prob, z_up=True)
+        self.load_scene_data(preload=True)
+        for scene in self.scene_data:
+            g = scene[1]
+            g[-1, ...] = torch.as_tensor(density_to_alpha_relu(g[-1].numpy()))
+
+    density_to_alpha = staticmethod(density_to_alpha_relu)
+
+
+class GeneralRPNDataset(BaseDataset):
+    def __init__(self, csv_path, normalize_density: bool = True) -> None:
+        super().__init__("general")
+        import pandas as pd
+        self.df = pd.read_csv(csv_path, dtype=str)
+        self.normalize_density = normalize_density
+        self.scene_list = []
+        for row in self.df.itertuples():
+            self.scene_list.append(row.scene)
+            assert os.path.isfile(row.rgbsigma_path), f"{row.rgbsigma_path} does not exist"
+            boxes = None
+            if row.boxes_path != "None":
+                assert os.path.isfile(row.boxes_path), f"{row.boxes_path} does not exist"
+                boxes = torch.from_numpy(np.load(row.boxes_path))
+            self.scene_data.append((row.scene, _grid_from_npz(row.rgbsigma_path, normalize_density), boxes))

@@ -20,7 +20,7 @@ import _refshim  # noqa: E402
 _refshim.install()
 
 from fixture_init import seeded_state  # noqa: E402
-from oracle import anchors as OA, boxes as OB, coders as OC, geometry as OG, nets as ON, rpn as OR  # noqa: E402
+from oracle import anchors as OA, boxes as OB, coders as OC, geometry as OG, metrics as OM, nets as ON, rpn as OR  # noqa: E402
 
 # reference modules
 from model import anchor as R_anchor, utils as R_utils, rpn as R_rpn  # noqa: E402
@@ -197,6 +197,86 @@ def gen_nms():
     save("nms", thr=0.3, **out)
 
 
+def gen_metrics():
+    print("metrics")
+    import eval as R_eval
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    for tag, maker in (("aabb", rand_aabb), ("obb", rand_obb)):
+        props, scores, gts = [], [], []
+        for sc in range(3):
+            gt = maker(6 + sc, g, 8, 40, 5, 14)
+            jit = gt.repeat_interleave(12, dim=0).clone()
+            jit[:, :3] += torch.randn(jit.shape[0], 3, generator=g) * 2.0
+            if tag == "aabb":
+                jit[:, 3:] = jit[:, :3] + (gt.repeat_interleave(12, 0)[:, 3:] - gt.repeat_interleave(12, 0)[:, :3]) * (0.8 + 0.4 * torch.rand(jit.shape[0], 3, generator=g))
+            else:
+                jit[:, 6] += torch.randn(jit.shape[0], generator=g) * 0.15
+            far = maker(30, g, 0, 60, 4, 12)
+            p = torch.cat([jit, far])
+            props.append(p); scores.append(torch.rand(p.shape[0], generator=g)); gts.append(gt)
+        r50 = R_eval.evaluate_box_proposals_recall(props, scores, gts, thresholds=torch.tensor([0.5]), limit=40)
+        r25 = R_eval.evaluate_box_proposals_recall(props, scores, gts, thresholds=torch.tensor([0.25]), limit=None)
+        ar = R_eval.evaluate_box_proposals_recall(props, scores, gts, thresholds=torch.arange(0.25, 1.0, 0.05), limit=100)
+        ap50 = R_eval.evaluate_box_proposals_ap(props, scores, gts, iou_thresh=0.5)
+        ap25 = R_eval.evaluate_box_proposals_ap(props, scores, gts, iou_thresh=0.25, top_k=50)
+        close(OM.recall(props, scores, gts, torch.tensor([0.5]), 40)["ar"], r50["ar"], 1e-6, "r50")
+        close(OM.recall(props, scores, gts, torch.arange(0.25, 1.0, 0.05), 100)["recalls"], ar["recalls"], 1e-6, "ar")
+        close(OM.average_precision(props, scores, gts, 0.5)["ap"], ap50["ap"], 1e-6, "ap50")
+        close(OM.average_precision(props, scores, gts, 0.25, 50)["ap"], ap25["ap"], 1e-6, "ap25")
+        for i in range(3):
+            out[f"{tag}_props{i}"], out[f"{tag}_scores{i}"], out[f"{tag}_gt{i}"] = props[i], scores[i], gts[i]
+        out.update({f"{tag}_r50": r50["ar"], f"{tag}_r25": r25["ar"], f"{tag}_ar": ar["ar"], f"{tag}_ar_recalls": ar["recalls"],
+                    f"{tag}_gt_overlaps": ar["gt_overlaps"], f"{tag}_ap50": ap50["ap"], f"{tag}_ap25": ap25["ap"], f"{tag}_num_pos": r50["num_pos"]})
+        print("   ", tag, "R50", float(r50["ar"]), "AR", float(ar["ar"]), "AP50", float(ap50["ap"]), "AP25", float(ap25["ap"]))
+    save("metrics", **out)
+
+
+def gen_cli():
+    print("cli + datasets")
+    import argparse, json, tempfile
+    import datasets as R_ds
+
+    class Captured(Exception):
+        pass
+
+    def grab(self, *a, **k):
+        raise Captured(self)
+    orig = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = grab
+    try:
+        R_run.parse_args()
+    except Captured as c:
+        parser = c.args[0]
+    finally:
+        argparse.ArgumentParser.parse_args = orig
+    flags = []
+    for a in parser._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        flags.append(dict(options=a.option_strings, dest=a.dest, default=a.default, choices=list(a.choices) if a.choices else None,
+                          type=a.type.__name__ if a.type else None, action=type(a).__name__))
+    json.dump(flags, open(os.path.join(HERE, "cli_flags.json"), "w"), indent=1)
+    print("   ", len(flags), "flags")
+    # datasets: deterministic synthetic scene files -> what the reference loader returns
+    rng = np.random.default_rng(3)
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(d + "/f"); os.makedirs(d + "/b")
+        g32 = (rng.random((12, 10, 8, 4), dtype=np.float32) * 10 - 5).astype(np.float32)
+        g8 = (rng.random((9, 8, 7, 4)) * 255).astype(np.uint8)
+        np.savez(d + "/f/s0.npz", rgbsigma=g32); np.savez(d + "/f/s1.npz", rgbsigma=g8)
+        b = np.array([[3., 2, 1, 4, 3, 2, 0.3], [6, 5, 4, 2, 2, 3, -0.8]], dtype=np.float32)
+        np.save(d + "/b/s0.npy", b); np.save(d + "/b/s1.npy", b[:1])
+        ds = R_ds.Front3DRPNDataset(d + "/f", d + "/b", scene_list=["s0", "s1"], normalize_density=True)
+        x0, b0, n0 = ds[0]
+        x1, b1, n1 = ds[1]
+        import random
+        random.seed(5)
+        xa, ba = R_ds.BaseDataset.augment_rpn_inputs(x0.clone(), b0.clone(), 1.0, 1.0, 1.0, True)
+        sn = R_ds.ScanNetRPNDataset.density_to_alpha(np.linspace(-3, 400, 9))
+    save("datasets", g32=g32, g8=g8, boxes=b, x0=x0, x1=x1, aug_x=xa, aug_boxes=ba, scannet_alpha=sn)
+
+
 def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
     bb = ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True) if kw.get("backbone") == "resnet" \
         else VGG_FPN("EF", 4, True, resolution)
@@ -336,6 +416,6 @@ def gen_train():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "eval", "train"]
+    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "eval", "train"]
     for w in which:
         globals()["gen_" + w]()

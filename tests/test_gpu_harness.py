@@ -1,0 +1,52 @@
+"""GPU: metrics on the HIP IoU kernels vs golden values captured from the reference, and the command line end to end
+(train one epoch on two tiny synthetic scenes, checkpoint, eval with proposal dump + eval.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_metrics_match_reference(golden, dev):
+    from nerf_rpn_amd.eval import evaluate_box_proposals_ap, evaluate_box_proposals_recall
+    g = golden("metrics")
+    for tag in ("aabb", "obb"):
+        P = [torch.from_numpy(g[f"{tag}_props{i}"]).to(dev) for i in range(3)]
+        S = [torch.from_numpy(g[f"{tag}_scores{i}"]).to(dev) for i in range(3)]
+        G = [torch.from_numpy(g[f"{tag}_gt{i}"]).to(dev) for i in range(3)]
+        r50 = evaluate_box_proposals_recall(P, S, G, thresholds=torch.tensor([0.5]), limit=40)
+        r25 = evaluate_box_proposals_recall(P, S, G, thresholds=torch.tensor([0.25]), limit=None)
+        ar = evaluate_box_proposals_recall(P, S, G, thresholds=torch.arange(0.25, 1.0, 0.05), limit=100)
+        assert abs(r50["ar"].item() - float(g[f"{tag}_r50"])) < 1e-6 and r50["num_pos"] == int(g[f"{tag}_num_pos"])
+        assert abs(r25["ar"].item() - float(g[f"{tag}_r25"])) < 1e-6
+        assert torch.allclose(ar["recalls"], torch.from_numpy(g[f"{tag}_ar_recalls"]), atol=1e-6)
+        assert torch.allclose(ar["gt_overlaps"], torch.from_numpy(g[f"{tag}_gt_overlaps"]), atol=1e-5)
+        assert abs(evaluate_box_proposals_ap(P, S, G, iou_thresh=0.5)["ap"].item() - float(g[f"{tag}_ap50"])) < 1e-6
+        assert abs(evaluate_box_proposals_ap(P, S, G, iou_thresh=0.25, top_k=50)["ap"].item() - float(g[f"{tag}_ap25"])) < 1e-6
+
+
+def test_command_line_train_eval_roundtrip(tmp_path, dev):
+    from nerf_rpn_amd.run_rpn import main
+    rng = np.random.default_rng(0)
+    f, b = tmp_path / "features", tmp_path / "boxes"
+    os.makedirs(f); os.makedirs(b)
+    for s in ("a", "b"):
+        np.savez(f / f"{s}.npz", rgbsigma=(rng.random((32, 32, 24, 4), dtype=np.float32) * 4 - 2))
+        np.save(b / f"{s}.npy", np.array([[12., 12, 10, 8, 6, 6, 0.2], [20, 18, 12, 10, 8, 6, -0.5]], dtype=np.float32))
+    split = tmp_path / "split.npz"
+    np.savez(split, train_scenes=np.array(["a", "b"]), val_scenes=np.array(["a"]), test_scenes=np.array(["a", "b"]))
+    common = ["--dataset_name", "front3d", "--features_path", str(f), "--boxes_path", str(b), "--dataset_split", str(split),
+              "--backbone_type", "vgg_EF", "--rotated_bbox", "--normalize_density", "--save_path", str(tmp_path / "out"),
+              "--rpn_pre_nms_top_n_test", "500", "--rpn_post_nms_top_n_test", "300"]
+    main(["--mode", "train", "--num_epochs", "1", "--batch_size", "1", "--lr", "1e-4", "--log_interval", "1"] + common)
+    ck = torch.load(tmp_path / "out" / "model_best.pt", map_location="cpu")
+    assert set(ck) == {"epoch", "backbone_state_dict", "rpn_head_state_dict", "train_args"} and ck["epoch"] == 1
+    assert len(ck["backbone_state_dict"]) == 135 and len(ck["rpn_head_state_dict"]) == 12
+    main(["--mode", "eval", "--checkpoint", str(tmp_path / "out" / "model_best.pt"), "--output_proposals"] + common)
+    z = np.load(tmp_path / "out" / "proposals" / "a.npz")
+    assert set(z.files) == {"proposal", "score"} and z["proposal"].shape[1] == 7 and z["proposal"].dtype == np.float32
+    js = json.load(open(tmp_path / "out" / "eval.json"))
+    assert {"recall_50_top_300", "recall_25_top_300", "recall_ar_top_300", "ap_50", "ap_25"} <= set(js)

@@ -1,0 +1,58 @@
+"""CPU: the harness around the hot path -- command-line flags identical to the reference's, dataset loaders returning what
+the reference's return on the same files, oracle metrics against golden values."""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+
+
+def test_cli_flags_match_reference():
+    from nerf_rpn_amd.run_rpn import build_parser
+    ref = json.load(open(os.path.join(GOLDEN, "cli_flags.json")))
+    mine = {a.dest: a for a in build_parser()._actions if a.option_strings and a.dest != "help"}
+    for f in ref:
+        a = mine.pop(f["dest"])
+        assert a.option_strings == f["options"], f["dest"]
+        assert a.default == f["default"], (f["dest"], a.default, f["default"])
+        assert (list(a.choices) if a.choices else None) == f["choices"], f["dest"]
+        assert (a.type.__name__ if a.type else None) == f["type"], f["dest"]
+        assert type(a).__name__ == f["action"], f["dest"]
+    assert sorted(mine) == ["dtype", "fix_obb_clip"]          # the only additions
+    from nerf_rpn_amd.run_rpn import parse_gpu_ids
+    assert parse_gpu_ids("0-3") == [0, 1, 2, 3] and parse_gpu_ids("0,2,5-6") == [0, 2, 5, 6] and parse_gpu_ids("") == []
+
+
+def test_datasets_match_reference(tmp_path, golden):
+    from nerf_rpn_amd import datasets as D
+    g = golden("datasets")
+    os.makedirs(tmp_path / "f"); os.makedirs(tmp_path / "b")
+    np.savez(tmp_path / "f" / "s0.npz", rgbsigma=g["g32"]); np.savez(tmp_path / "f" / "s1.npz", rgbsigma=g["g8"])
+    np.save(tmp_path / "b" / "s0.npy", g["boxes"]); np.save(tmp_path / "b" / "s1.npy", g["boxes"][:1])
+    ds = D.Front3DRPNDataset(str(tmp_path / "f"), str(tmp_path / "b"), scene_list=["s0", "s1"], normalize_density=True)
+    x0, b0, n0 = ds[0]
+    x1, b1, n1 = ds[1]
+    assert n0 == "s0" and tuple(x0.shape) == (4, 12, 10, 8) and x0.dtype == torch.float32
+    assert torch.equal(x0, torch.from_numpy(g["x0"])) and torch.equal(x1, torch.from_numpy(g["x1"]))
+    random.seed(5)
+    xa, ba = D.BaseDataset.augment_rpn_inputs(x0.clone(), b0.clone(), 1.0, 1.0, 1.0, True)
+    assert torch.allclose(xa, torch.from_numpy(g["aug_x"]), atol=1e-6) and torch.allclose(ba, torch.from_numpy(g["aug_boxes"]), atol=1e-6)
+    assert np.allclose(D.ScanNetRPNDataset.density_to_alpha(np.linspace(-3, 400, 9)), g["scannet_alpha"])
+    rs, bs, ns = D.BaseDataset.collate_fn([ds[0], ds[1]])
+    assert len(rs) == 2 and ns == ["s0", "s1"]
+
+
+def test_oracle_metrics(golden):
+    from oracle import metrics as OM
+    g = golden("metrics")
+    for tag in ("aabb", "obb"):
+        P = [torch.from_numpy(g[f"{tag}_props{i}"]) for i in range(3)]
+        S = [torch.from_numpy(g[f"{tag}_scores{i}"]) for i in range(3)]
+        G = [torch.from_numpy(g[f"{tag}_gt{i}"]) for i in range(3)]
+        assert abs(OM.recall(P, S, G, torch.tensor([0.5]), 40)["ar"].item() - float(g[f"{tag}_r50"])) < 1e-6
+        assert abs(OM.recall(P, S, G, torch.arange(0.25, 1.0, 0.05), 100)["ar"].item() - float(g[f"{tag}_ar"])) < 1e-6
+        assert abs(OM.average_precision(P, S, G, 0.5)["ap"].item() - float(g[f"{tag}_ap50"])) < 1e-6
+        assert abs(OM.average_precision(P, S, G, 0.25, 50)["ap"].item() - float(g[f"{tag}_ap25"])) < 1e-6
