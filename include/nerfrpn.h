@@ -249,6 +249,40 @@ int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxel
 int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtype, int dst_dtype, nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Swin-3D backbone pieces, channels-last tokens [N,X,Y,Z,C].  [a6]  (feature_extractor.py:382-789)
+ *   Every token-wise Linear is nrpn_conv3d_fwd with ksize 1; window partition / cyclic shift / padding are index
+ *   arithmetic inside the attention kernels.
+ * ---------------------------------------------------------------------------------------------- */
+/* patch_partition gather (feature_extractor.py:700-710): [N,X,Y,Z,4] -> [N,X/p,Y/p,Z/p,4p^3], inner order (c,dx,dy,dz)
+ * = the flattened Conv3d(4,E,k=p,s=p) weight, so the patch embedding is a 1x1x1 GEMM on weight.view(E, 4p^3). */
+int nrpn_patchify(const void *x, void *y, int n, int gx, int gy, int gz, int patch, int dtype, nrpn_stream_t stream);
+/* nn.LayerNorm(C) over rows tokens; mean / rstd (f32 [rows]) are saved for the backward, which overwrites dgamma/dbeta. */
+int nrpn_layernorm_fwd(const void *x, void *y, const float *gamma, const float *beta, float *mean, float *rstd, int64_t rows,
+                       int c, float eps, int dtype, nrpn_stream_t stream);
+int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *mean, const float *rstd,
+                       float *dgamma, float *dbeta, int64_t rows, int c, int dtype, nrpn_stream_t stream);
+/* exact (erf) GELU; backward != 0: out = dy * gelu'(x) */
+int nrpn_gelu(const void *x, const void *dy, void *out, int64_t count, int backward, int dtype, nrpn_stream_t stream);
+/* y = (a ? a : 0) + scale[n] * b : residual join with the StochasticDepth("row") factor (scale == NULL: 1) */
+int nrpn_scale_add(const void *a, const void *b, const float *scale, void *y, int n, int64_t per_sample, int dtype,
+                   nrpn_stream_t stream);
+/* PatchMerging gather (feature_extractor.py:396-421): [N,X,Y,Z,C] -> [N,ceil(X/2),ceil(Y/2),ceil(Z/2),8C] (odd sizes zero
+ * padded), block order x0..x7 of the reference; backward != 0 maps a [.., 8C] gradient back to [N,X,Y,Z,C]. */
+int nrpn_patch_merge(const void *src, void *dst, int n, int gx, int gy, int gz, int c, int backward, int dtype,
+                     nrpn_stream_t stream);
+/* shifted_window_attention core (feature_extractor.py:424-530) for window 4x4x4, head_dim 32 (C == 32*heads):
+ * qkv [N,X,Y,Z,3C] (output of the qkv Linear on the un-padded tokens), qkv_bias f32 [3C] (the value padded tokens take,
+ * may be NULL), bias_table f32 [343,heads], rel_index i32 [64*64]; shift != 0 selects the shifted-window variant
+ * (shift 2 on every axis longer than one window, -100 mask between regions).  out [N,X,Y,Z,C] feeds the proj Linear.
+ * Backward overwrites dqkv [N,X,Y,Z,3C], dtable f32 [343,heads] and dbias_pad f32 [3C] (gradient reaching the qkv bias
+ * through padded tokens; may be NULL). */
+int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, void *out,
+                         int n, int gx, int gy, int gz, int c, int heads, int shift, int dtype, nrpn_stream_t stream);
+int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index,
+                         const void *dout, void *dqkv, float *dtable, float *dbias_pad, int n, int gx, int gy, int gz, int c,
+                         int heads, int shift, int dtype, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 arena.  [a21]  (clip_grad_norm_ + AdamW, run_rpn.py:345-349,390-395)
  *   grad_scale folds the 1/world_size of the data-parallel mean into both kernels (sum all-reduce, no extra pass).
  *   sumsq: f32 device scalar = sum((g*grad_scale)^2) (zeroed by nrpn_grad_sumsq); step applies g *= grad_scale * min(1, max_norm/(sqrt(sumsq)+1e-6)),

@@ -1,0 +1,477 @@
+// Swin-3D building blocks for gfx950 (reference nerf_rpn/model/feature_extractor.py:382-789): patch embedding gather,
+// LayerNorm, exact GELU, residual join with per-sample stochastic-depth scale, patch-merging gather, and shifted-window
+// multi-head attention (4x4x4 windows, head_dim 32) forward + backward.
+//
+// Tokens stay in the channels-last activation layout [N][X][Y][Z][C]; every token-wise Linear (qkv, proj, MLP, reduction)
+// is the 1x1x1 MFMA GEMM of conv3d.hip.  Window partition, cyclic shift, zero padding to a window multiple and their
+// inverses are pure index arithmetic inside the attention kernels -- nothing is rolled, padded or permuted in memory.
+// The attention matmuls are 64x32x64 per (window, head) ("attention GEMMs are tiny"): one wavefront per
+// (window, head), one lane per query token, K/V staged in LDS and broadcast-read, softmax in registers.
+#include "common.h"
+
+typedef unsigned short bf16s;
+typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+
+#define DISPATCH_T(dtype, ...)                                 \
+  if ((dtype) == NRPN_F32) { typedef float T; __VA_ARGS__; }   \
+  else { typedef bf16s T; __VA_ARGS__; }
+
+static inline int ew_blocks(long long work) { long long b = (work + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+// =====================================================================================================================
+// patch embedding gather: [N,X,Y,Z,4] -> [N,X/p,Y/p,Z/p, 4*p^3] with inner order (c, dx, dy, dz) = the flattened
+// Conv3d(4, E, k=p, s=p) weight, so the conv becomes a 1x1x1 GEMM on the weight viewed as [E, 4 p^3]
+// =====================================================================================================================
+template <typename T>
+__global__ void patchify_kernel(const T *__restrict__ x, T *__restrict__ y, int n, int gx, int gy, int gz, int ox, int oy, int oz, int p) {
+  const int per = 4 * p * p * p;
+  const long long total = (long long)n * ox * oy * oz * per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int k = (int)(i % per);
+    long long v = i / per;
+    const int dz = k % p; k /= p;
+    const int dy = k % p; k /= p;
+    const int dx = k % p;
+    const int c = k / p;
+    const int z = (int)(v % oz); v /= oz;
+    const int yy = (int)(v % oy); v /= oy;
+    const int xx = (int)(v % ox);
+    const long long b = v / ox;
+    y[i] = x[(((b * gx + xx * p + dx) * gy + yy * p + dy) * gz + z * p + dz) * 4 + c];
+  }
+}
+
+extern "C" int nrpn_patchify(const void *x, void *y, int n, int gx, int gy, int gz, int patch, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(x && y && n > 0 && patch >= 1 && gx >= patch && gy >= patch && gz >= patch, "patchify: bad args");
+  const int ox = gx / patch, oy = gy / patch, oz = gz / patch;
+  const long long total = (long long)n * ox * oy * oz * 4 * patch * patch * patch;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y, n,
+                                       gx, gy, gz, ox, oy, oz, patch));
+  NRPN_LAUNCH_CHECK("patchify");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// LayerNorm over the channel dimension: one wavefront per token row
+// =====================================================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ mean,
+                                                            float *__restrict__ rstd, long long rows, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+    const T *xr = x + r * c;
+    float s = 0.f;
+    for (int k = lane; k < c; k += 64) s += elem<T>::ld(xr + k);
+    const float m = wave_sum(s) / (float)c;
+    float q = 0.f;
+    for (int k = lane; k < c; k += 64) { const float d = elem<T>::ld(xr + k) - m; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
+    for (int k = lane; k < c; k += 64) elem<T>::st(y + r * c + k, (elem<T>::ld(xr + k) - m) * rs * gamma[k] + beta[k]);
+    if (lane == 0) { mean[r] = m; rstd[r] = rs; }
+  }
+}
+
+// dx per row; dgamma / dbeta: per-lane partial sums over the block's rows, one atomic per channel per block
+template <typename T, int MAXK>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ dx,
+                                                            const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, long long rows, int c) {
+  const int lane = threadIdx.x & 63;
+  float ag[MAXK], ab[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+    const float m = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      const int k = lane + 64 * j;
+      if (k < c) {
+        const float g = elem<T>::ld(dy + r * c + k) * gamma[k];
+        const float xh = (elem<T>::ld(x + r * c + k) - m) * rs;
+        s1 += g; s2 += g * xh;
+      }
+    }
+    s1 = wave_sum(s1) / (float)c;
+    s2 = wave_sum(s2) / (float)c;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      const int k = lane + 64 * j;
+      if (k < c) {
+        const float d = elem<T>::ld(dy + r * c + k);
+        const float xh = (elem<T>::ld(x + r * c + k) - m) * rs;
+        elem<T>::st(dx + r * c + k, rs * (d * gamma[k] - s1 - xh * s2));
+        ag[j] += d * xh;
+        ab[j] += d;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    const int k = lane + 64 * j;
+    if (k < c) { atomicAdd(dgamma + k, ag[j]); atomicAdd(dbeta + k, ab[j]); }
+  }
+}
+
+extern "C" int nrpn_layernorm_fwd(const void *x, void *y, const float *gamma, const float *beta, float *mean, float *rstd, int64_t rows,
+                                  int c, float eps, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(x && y && gamma && beta && mean && rstd && rows > 0 && c > 0, "layernorm_fwd: bad args");
+  const int blocks = (int)min((long long)4096, (long long)((rows + 3) / 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(blocks), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y, gamma, beta,
+                                       mean, rstd, (long long)rows, c, eps));
+  NRPN_LAUNCH_CHECK("layernorm_fwd");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *mean, const float *rstd,
+                                  float *dgamma, float *dbeta, int64_t rows, int c, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(x && dy && dx && gamma && mean && rstd && dgamma && dbeta && rows > 0 && c > 0 && c <= 64 * 48,
+               "layernorm_bwd: bad args (C <= 3072)");
+  hipStream_t st = as_stream(stream);
+  NRPN_HIP(hipMemsetAsync(dgamma, 0, (size_t)c * 4, st));
+  NRPN_HIP(hipMemsetAsync(dbeta, 0, (size_t)c * 4, st));
+  const int blocks = (int)min((long long)1024, (long long)((rows + 3) / 4));
+#define NRPN_LNB(K_) DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T, K_>), dim3(blocks), dim3(256), 0, st, (const T *)x, \
+    (const T *)dy, (T *)dx, gamma, mean, rstd, dgamma, dbeta, (long long)rows, c))
+  if (c <= 64 * 4) { NRPN_LNB(4); } else if (c <= 64 * 12) { NRPN_LNB(12); } else if (c <= 64 * 24) { NRPN_LNB(24); } else { NRPN_LNB(48); }
+#undef NRPN_LNB
+  NRPN_LAUNCH_CHECK("layernorm_bwd");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// exact GELU (nn.GELU default) and the residual join y = a + s[n] * b (s = stochastic-depth row scale, or 1)
+// =====================================================================================================================
+template <typename T, bool BWD>
+__global__ void gelu_kernel(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ out, long long count) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    const float v = elem<T>::ld(x + i);
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+    if (!BWD) elem<T>::st(out + i, v * cdf);
+    else elem<T>::st(out + i, elem<T>::ld(dy + i) * (cdf + v * 0.39894228040143268f * expf(-0.5f * v * v)));
+  }
+}
+
+extern "C" int nrpn_gelu(const void *x, const void *dy, void *out, int64_t count, int backward, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(x && out && count > 0 && (!backward || dy), "gelu: bad args");
+  if (backward) { DISPATCH_T(dtype, hipLaunchKernelGGL((gelu_kernel<T, true>), dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream),
+                                                       (const T *)x, (const T *)dy, (T *)out, (long long)count)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((gelu_kernel<T, false>), dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), (const T *)x,
+                                              (const T *)nullptr, (T *)out, (long long)count)); }
+  NRPN_LAUNCH_CHECK("gelu");
+  return NRPN_OK;
+}
+
+template <typename T>
+__global__ void scale_add_kernel(const T *__restrict__ a, const T *__restrict__ b, const float *__restrict__ scale, T *__restrict__ y,
+                                 long long per_sample, long long count) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    const float s = scale ? scale[i / per_sample] : 1.0f;
+    elem<T>::st(y + i, (a ? elem<T>::ld(a + i) : 0.f) + s * elem<T>::ld(b + i));
+  }
+}
+
+extern "C" int nrpn_scale_add(const void *a, const void *b, const float *scale, void *y, int n, int64_t per_sample, int dtype,
+                              nrpn_stream_t stream) {
+  NRPN_REQUIRE(b && y && n > 0 && per_sample > 0, "scale_add: bad args");
+  const long long count = (long long)n * per_sample;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(scale_add_kernel<T>, dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), (const T *)a, (const T *)b,
+                                       scale, (T *)y, (long long)per_sample, count));
+  NRPN_LAUNCH_CHECK("scale_add");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// patch merging gather: [N,X,Y,Z,C] -> [N,ceil(X/2),ceil(Y/2),ceil(Z/2), 8C], block q = (x&1) + 2 (y&1) + 4 (z&1);
+// odd sizes read zeros (reference F.pad).  The backward is the same index map read the other way.
+// =====================================================================================================================
+template <typename T, bool FWD>
+__global__ void merge_kernel(const T *__restrict__ src, T *__restrict__ dst, int n, int gx, int gy, int gz, int ox, int oy, int oz, int c) {
+  const long long total = FWD ? (long long)n * ox * oy * oz * 8 * c : (long long)n * gx * gy * gz * c;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (FWD) {
+      const int ch = (int)(i % c);
+      long long v = i / c;
+      const int q = (int)(v % 8); v /= 8;
+      const int z = (int)(v % oz); v /= oz;
+      const int y = (int)(v % oy); v /= oy;
+      const int x = (int)(v % ox);
+      const long long b = v / ox;
+      const int sx = 2 * x + (q & 1), sy = 2 * y + ((q >> 1) & 1), sz = 2 * z + (q >> 2);
+      const bool in = sx < gx && sy < gy && sz < gz;
+      elem<T>::st(dst + i, in ? elem<T>::ld(src + (((b * gx + sx) * gy + sy) * gz + sz) * (long long)c + ch) : 0.f);
+    } else {
+      const int ch = (int)(i % c);
+      long long v = i / c;
+      const int z = (int)(v % gz); v /= gz;
+      const int y = (int)(v % gy); v /= gy;
+      const int x = (int)(v % gx);
+      const long long b = v / gx;
+      const int q = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
+      elem<T>::st(dst + i, elem<T>::ld(src + ((((b * ox + x / 2) * oy + y / 2) * oz + z / 2) * 8 + q) * (long long)c + ch));
+    }
+  }
+}
+
+extern "C" int nrpn_patch_merge(const void *src, void *dst, int n, int gx, int gy, int gz, int c, int backward, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && dst && n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0, "patch_merge: bad args");
+  const int ox = (gx + 1) / 2, oy = (gy + 1) / 2, oz = (gz + 1) / 2;
+  const long long total = backward ? (long long)n * gx * gy * gz * c : (long long)n * ox * oy * oz * 8 * c;
+  if (backward) { DISPATCH_T(dtype, hipLaunchKernelGGL((merge_kernel<T, false>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                                                       (const T *)src, (T *)dst, n, gx, gy, gz, ox, oy, oz, c)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((merge_kernel<T, true>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)src,
+                                              (T *)dst, n, gx, gy, gz, ox, oy, oz, c)); }
+  NRPN_LAUNCH_CHECK("patch_merge");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// shifted-window attention, window 4x4x4 (64 tokens), head_dim 32
+// =====================================================================================================================
+constexpr int WS = 4, WT = 64, HD = 32;
+
+struct AttnGeom {
+  int n, gx, gy, gz;      // token grid
+  int px, py, pz;         // padded to a multiple of the window
+  int sx, sy, sz;         // cyclic shift (0 or 2), already zeroed where the window covers the padded axis
+  int heads, C;
+};
+
+// token `t` of window `w` -> original coordinate; returns false for a padded (zero) token
+__device__ __forceinline__ bool attn_token(const AttnGeom &g, int w, int t, long long &row, int &region) {
+  const int nwz = g.pz / WS, nwy = g.py / WS, nwx = g.px / WS;
+  const int wz = w % nwz, wy = (w / nwz) % nwy, wx = (w / (nwz * nwy)) % nwx, b = w / (nwz * nwy * nwx);
+  const int rx = wx * WS + t / 16, ry = wy * WS + (t / 4) % 4, rz = wz * WS + t % 4;      // position in the rolled frame
+  const int ox = (rx + g.sx) % g.px, oy = (ry + g.sy) % g.py, oz = (rz + g.sz) % g.pz;   // original (padded) position
+  // region ids of the reference's slice loops; an axis that is not shifted ends up with one id (its last slice covers it all)
+  const int ax = g.sx == 0 ? 2 : (rx < g.px - WS ? 0 : (rx < g.px - g.sx ? 1 : 2));
+  const int ay = g.sy == 0 ? 2 : (ry < g.py - WS ? 0 : (ry < g.py - g.sy ? 1 : 2));
+  const int az = g.sz == 0 ? 2 : (rz < g.pz - WS ? 0 : (rz < g.pz - g.sz ? 1 : 2));
+  region = (ax * 3 + ay) * 3 + az;
+  row = (((long long)b * g.gx + ox) * g.gy + oy) * g.gz + oz;
+  return ox < g.gx && oy < g.gy && oz < g.gz;
+}
+
+// forward: out[row, head*32 + d] = softmax(q k^T * scale + bias + mask) v
+template <typename T>
+__global__ void __launch_bounds__(64) window_attn_fwd_kernel(const T *__restrict__ qkv, const float *__restrict__ qkv_bias,
+                                                             const float *__restrict__ bias_table, const int *__restrict__ rel_index,
+                                                             T *__restrict__ out, AttnGeom g) {
+  __shared__ float K[WT][HD + 1], V[WT][HD + 1];
+  __shared__ int reg[WT];
+  const int w = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
+  const bool shifted = (g.sx + g.sy + g.sz) > 0;
+  long long row;
+  int region;
+  const bool real = attn_token(g, w, i, row, region);
+  const float scale = 0.17677669529663687f;   // 32^-0.5
+  float q[HD];
+  const int C = g.C, off = head * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    const float bq = qkv_bias ? qkv_bias[off + d] : 0.f, bk = qkv_bias ? qkv_bias[C + off + d] : 0.f, bv = qkv_bias ? qkv_bias[2 * C + off + d] : 0.f;
+    q[d] = (real ? elem<T>::ld(qkv + row * 3 * C + off + d) : bq) * scale;
+    K[i][d] = real ? elem<T>::ld(qkv + row * 3 * C + C + off + d) : bk;
+    V[i][d] = real ? elem<T>::ld(qkv + row * 3 * C + 2 * C + off + d) : bv;
+  }
+  reg[i] = region;
+  __syncthreads();
+  float s[WT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < WT; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) a += q[d] * K[j][d];
+    a += bias_table[rel_index[i * WT + j] * g.heads + head];
+    if (shifted && reg[j] != region) a += -100.0f;
+    s[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < WT; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+  const float inv = 1.0f / den;
+  if (real) {
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+      float o = 0.f;
+#pragma unroll
+      for (int j = 0; j < WT; ++j) o += s[j] * V[j][d];
+      elem<T>::st(out + row * C + off + d, o * inv);
+    }
+  }
+}
+
+// backward: recompute P, then dV = P^T dO, dS = P (dP - rowdot), dq = scale dS K, dK = dS^T (scale q), dbias_table += dS
+template <typename T>
+__global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T *__restrict__ qkv, const float *__restrict__ qkv_bias,
+                                                             const float *__restrict__ bias_table, const int *__restrict__ rel_index,
+                                                             const T *__restrict__ dout, T *__restrict__ dqkv, float *__restrict__ dtable,
+                                                             float *__restrict__ dbias_pad, AttnGeom g) {
+  __shared__ float K[WT][HD + 1], V[WT][HD + 1], Q[WT][HD + 1], DO[WT][HD + 1];
+  __shared__ float M[WT][WT + 1];
+  __shared__ float tab[343];
+  __shared__ int reg[WT];
+  const int w = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
+  const bool shifted = (g.sx + g.sy + g.sz) > 0;
+  long long row;
+  int region;
+  const bool real = attn_token(g, w, i, row, region);
+  const float scale = 0.17677669529663687f;
+  const int C = g.C, off = head * HD;
+  for (int k = i; k < 343; k += 64) tab[k] = 0.f;
+  float q[HD], dO[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    const float bq = qkv_bias ? qkv_bias[off + d] : 0.f, bk = qkv_bias ? qkv_bias[C + off + d] : 0.f, bv = qkv_bias ? qkv_bias[2 * C + off + d] : 0.f;
+    q[d] = (real ? elem<T>::ld(qkv + row * 3 * C + off + d) : bq) * scale;
+    K[i][d] = real ? elem<T>::ld(qkv + row * 3 * C + C + off + d) : bk;
+    V[i][d] = real ? elem<T>::ld(qkv + row * 3 * C + 2 * C + off + d) : bv;
+    dO[d] = real ? elem<T>::ld(dout + row * C + off + d) : 0.f;     // outputs of padded queries are discarded
+    Q[i][d] = q[d];
+    DO[i][d] = dO[d];
+  }
+  reg[i] = region;
+  __syncthreads();
+  {
+    float p[WT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) a += q[d] * K[j][d];
+      a += bias_table[rel_index[i * WT + j] * g.heads + head];
+      if (shifted && reg[j] != region) a += -100.0f;
+      p[j] = a;
+      mx = fmaxf(mx, a);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) { p[j] = expf(p[j] - mx); den += p[j]; }
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) M[i][j] = p[j] * inv;     // P
+  }
+  __syncthreads();
+  // dV_i = sum_r P[r][i] dO_r   (lane i now acts as key/value token i)
+  {
+    float dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dv[d] = 0.f;
+#pragma unroll 2
+    for (int r = 0; r < WT; ++r) {
+      const float pr = M[r][i];
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dv[d] += pr * DO[r][d];
+    }
+    if (real) {
+#pragma unroll
+      for (int d = 0; d < HD; ++d) elem<T>::st(dqkv + row * 3 * C + 2 * C + off + d, dv[d]);
+    } else if (dbias_pad) {   // padded tokens carry the bias vectors as k and v: their gradient goes to the qkv bias
+#pragma unroll
+      for (int d = 0; d < HD; ++d) atomicAdd(dbias_pad + 2 * C + off + d, dv[d]);
+    }
+  }
+  // rowdot_i = sum_j dP_ij P_ij
+  float rowdot = 0.f;
+#pragma unroll 2
+  for (int j = 0; j < WT; ++j) {
+    float dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dp += dO[d] * V[j][d];
+    rowdot += dp * M[i][j];
+  }
+  __syncthreads();
+  // dS row of query i (overwrites P row i), dq, bias-table gradient
+  {
+    float dq[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < WT; ++j) {
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dp += dO[d] * V[j][d];
+      const float ds = M[i][j] * (dp - rowdot);
+      M[i][j] = ds;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dq[d] += ds * K[j][d];
+      atomicAdd(&tab[rel_index[i * WT + j]], ds);
+    }
+    if (real) {
+#pragma unroll
+      for (int d = 0; d < HD; ++d) elem<T>::st(dqkv + row * 3 * C + off + d, dq[d] * scale);
+    }
+  }
+  __syncthreads();
+  // dK_i = sum_r dS[r][i] * (scale q_r)
+  {
+    float dk[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dk[d] = 0.f;
+#pragma unroll 2
+    for (int r = 0; r < WT; ++r) {
+      const float dsr = M[r][i];
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dk[d] += dsr * Q[r][d];
+    }
+    if (real) {
+#pragma unroll
+      for (int d = 0; d < HD; ++d) elem<T>::st(dqkv + row * 3 * C + C + off + d, dk[d]);
+    } else if (dbias_pad) {
+#pragma unroll
+      for (int d = 0; d < HD; ++d) atomicAdd(dbias_pad + C + off + d, dk[d]);
+    }
+  }
+  for (int k = i; k < 343; k += 64)
+    if (tab[k] != 0.f) atomicAdd(dtable + k * g.heads + head, tab[k]);
+}
+
+static int fill_geom(AttnGeom &g, int n, int gx, int gy, int gz, int c, int heads, int shift) {
+  if (n <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || heads <= 0 || c != heads * HD)
+    return nrpn_fail(NRPN_ERR_ARG, "window_attn: C (%d) must equal heads (%d) * 32", c, heads);
+  g.n = n; g.gx = gx; g.gy = gy; g.gz = gz; g.heads = heads; g.C = c;
+  g.px = (gx + WS - 1) / WS * WS; g.py = (gy + WS - 1) / WS * WS; g.pz = (gz + WS - 1) / WS * WS;
+  g.sx = (shift && WS < g.px) ? WS / 2 : 0;
+  g.sy = (shift && WS < g.py) ? WS / 2 : 0;
+  g.sz = (shift && WS < g.pz) ? WS / 2 : 0;
+  return 0;
+}
+
+extern "C" int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, void *out,
+                                    int n, int gx, int gy, int gz, int c, int heads, int shift, int dtype, nrpn_stream_t stream) {
+  AttnGeom g;
+  if (int rc = fill_geom(g, n, gx, gy, gz, c, heads, shift)) return rc;
+  NRPN_REQUIRE(qkv && bias_table && rel_index && out, "window_attn_fwd: null pointer");
+  dim3 grid((unsigned)(n * (g.px / WS) * (g.py / WS) * (g.pz / WS)), (unsigned)heads);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_fwd_kernel<T>, grid, dim3(64), 0, as_stream(stream), (const T *)qkv, qkv_bias, bias_table,
+                                       rel_index, (T *)out, g));
+  NRPN_LAUNCH_CHECK("window_attn_fwd");
+  return NRPN_OK;
+}
+
+extern "C" int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, const void *dout,
+                                    void *dqkv, float *dtable, float *dbias_pad, int n, int gx, int gy, int gz, int c, int heads, int shift,
+                                    int dtype, nrpn_stream_t stream) {
+  AttnGeom g;
+  if (int rc = fill_geom(g, n, gx, gy, gz, c, heads, shift)) return rc;
+  NRPN_REQUIRE(qkv && bias_table && rel_index && dout && dqkv && dtable, "window_attn_bwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  NRPN_HIP(hipMemsetAsync(dtable, 0, (size_t)343 * heads * 4, st));
+  if (dbias_pad) NRPN_HIP(hipMemsetAsync(dbias_pad, 0, (size_t)3 * c * 4, st));
+  dim3 grid((unsigned)(n * (g.px / WS) * (g.py / WS) * (g.pz / WS)), (unsigned)heads);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_bwd_kernel<T>, grid, dim3(64), 0, st, (const T *)qkv, qkv_bias, bias_table, rel_index,
+                                       (const T *)dout, (T *)dqkv, dtable, dbias_pad, g));
+  NRPN_LAUNCH_CHECK("window_attn_bwd");
+  return NRPN_OK;
+}

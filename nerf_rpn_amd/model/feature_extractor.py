@@ -2,8 +2,10 @@
 reference nerf_rpn/model/feature_extractor.py (VGG_FPN :288-377); input [N,4,W,L,H] fp32, output 4 maps [N,256,.,.,.]
 (channels-last-backed views).  ``compute_dtype`` (fp32 for parity, bf16 for throughput) is an extra attribute.
 
-ResNet_FPN_256 + Bottleneck: feature_extractor.py:31-68, 145-235.  Swin family: not built yet (row a6 -- later rounds)."""
-from typing import Dict, List, Union, cast
+ResNet_FPN_256 + Bottleneck: feature_extractor.py:31-68, 145-235.  SwinTransformer_FPN (+ ShiftedWindowAttention,
+SwinTransformerBlock, PatchMerging): feature_extractor.py:382-789."""
+from functools import partial
+from typing import Callable, Dict, List, Optional, Union, cast
 
 import torch
 from torch import nn
@@ -177,4 +179,187 @@ def _unbuilt(name):
 ResNet_FPN_64 = _unbuilt("ResNet_FPN_64")
 ResNetSimplified_64 = _unbuilt("ResNetSimplified_64")
 ResNetSimplified_256 = _unbuilt("ResNetSimplified_256")
-SwinTransformer_FPN = _unbuilt("SwinTransformer_FPN")
+
+
+# ======================================================================================================================
+# Swin-3D (reference feature_extractor.py:382-789).  Tokens are channels-last [B,H,W,D,C] -- the activation layout of the
+# whole HIP path -- so the reference's Permute modules are no-ops here; they stay in the containers to keep state-dict keys.
+# ======================================================================================================================
+def linear(mod, x, relu=False):
+    """nn.Linear on the last dimension of a channels-last token tensor = the 1x1x1 MFMA GEMM."""
+    return ops.ConvFn.apply(x, hip_nn._pack_of(mod), mod.out_features, relu, False, 1, mod.weight, mod.bias)
+
+
+def layer_norm(mod, x):
+    return ops.LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps)
+
+
+class Permute(nn.Module):
+    """Parameter-free placeholder of torchvision.ops.misc.Permute (keeps ``patch_partition.2`` as the LayerNorm key)."""
+
+    def __init__(self, dims):
+        super().__init__()
+        self.dims = dims
+
+    def forward(self, x):
+        return torch.permute(x, self.dims)
+
+
+class StochasticDepth(nn.Module):
+    """torchvision.ops.StochasticDepth(p, "row"): per-sample Bernoulli(1-p)/(1-p) scale of a residual branch while training.
+    ``scale()`` returns the per-sample factor (None = identity); the multiply is fused into the residual-join kernel."""
+
+    def __init__(self, p: float, mode: str = "row"):
+        super().__init__()
+        if mode != "row":
+            raise NotImplementedError("only StochasticDepth('row') is used by the Swin backbone")
+        self.p, self.mode = p, mode
+
+    def scale(self, x):
+        if not self.training or self.p == 0.0:
+            return None
+        keep = 1.0 - self.p
+        noise = torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep)
+        return noise / keep if keep > 0.0 else noise
+
+
+class ShiftedWindowAttention(nn.Module):
+    """Window multi-head self attention with relative position bias (reference :533-613), window 4x4x4, head_dim 32."""
+
+    def __init__(self, dim, window_size, shift_size, num_heads, qkv_bias=True, proj_bias=True, attention_dropout=0.0, dropout=0.0):
+        super().__init__()
+        if len(window_size) != 3 or len(shift_size) != 3:
+            raise ValueError("window_size and shift_size must be of length 3")
+        if list(window_size) != [4, 4, 4] or dim != 32 * num_heads or list(shift_size) not in ([0, 0, 0], [2, 2, 2]):
+            raise NotImplementedError("the HIP attention kernel is specialised for window 4x4x4, shift 0|2, head_dim 32 "
+                                      "(swin_t / swin_s / swin_l of run_rpn.py)")
+        if attention_dropout != 0.0 or dropout != 0.0:
+            raise NotImplementedError("dropout is 0 in every NeRF-RPN configuration and has no HIP path")
+        self.window_size, self.shift_size, self.num_heads = list(window_size), list(shift_size), num_heads
+        self.attention_dropout, self.dropout = attention_dropout, dropout
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        w = self.window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * w[0] - 1) * (2 * w[1] - 1) * (2 * w[2] - 1), num_heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        c = torch.stack(torch.meshgrid(torch.arange(w[0]), torch.arange(w[1]), torch.arange(w[2]), indexing="ij")).flatten(1)
+        rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] = (rel[:, :, 0] + w[0] - 1) * (2 * w[2] - 1) * (2 * w[1] - 1)
+        rel[:, :, 1] = (rel[:, :, 1] + w[1] - 1) * (2 * w[2] - 1)
+        rel[:, :, 2] = rel[:, :, 2] + w[2] - 1
+        self.register_buffer("relative_position_index", rel.sum(-1).flatten())     # int64 [4096], checkpoint-compatible
+
+    def _index32(self):
+        idx = self.__dict__.get("_nrpn_idx32")
+        if idx is None or idx.device != self.relative_position_index.device:
+            idx = self.relative_position_index.to(torch.int32).contiguous()
+            self.__dict__["_nrpn_idx32"] = idx
+        return idx
+
+    def forward(self, x):
+        """x: [B,H,W,D,C] channels-last tokens."""
+        qkv = linear(self.qkv, x)
+        ctx = ops.WindowAttnFn.apply(qkv, self.qkv.bias, self.relative_position_bias_table, self._index32(), self.num_heads,
+                                     sum(self.shift_size) > 0)
+        return linear(self.proj, ctx)
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio=4.0, dropout=0.0, attention_dropout=0.0,
+                 stochastic_depth_prob=0.0, norm_layer: Callable[..., nn.Module] = nn.LayerNorm,
+                 attn_layer: Callable[..., nn.Module] = ShiftedWindowAttention):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = attn_layer(dim, window_size, shift_size, num_heads, attention_dropout=attention_dropout, dropout=dropout)
+        self.stochastic_depth = StochasticDepth(stochastic_depth_prob, "row")
+        self.norm2 = norm_layer(dim)
+        hidden = int(dim * mlp_ratio)
+        # torchvision MLP container layout: Linear, GELU, Dropout, Linear, Dropout  (state-dict keys mlp.0.*, mlp.3.*)
+        self.mlp = nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden, dim), nn.Dropout(dropout))
+        for m in self.mlp.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.normal_(m.bias, std=1e-6)
+
+    def forward(self, x):
+        a = self.attn(layer_norm(self.norm1, x))
+        x = ops.ScaleAddFn.apply(x, a, self.stochastic_depth.scale(x))
+        h = ops.GeluFn.apply(linear(self.mlp[0], layer_norm(self.norm2, x)))
+        m = linear(self.mlp[3], h)
+        return ops.ScaleAddFn.apply(x, m, self.stochastic_depth.scale(x))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim, norm_layer: Callable[..., nn.Module] = nn.LayerNorm, expand_dim: bool = True):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(8 * dim, dim * 2 if expand_dim else dim, bias=False)
+        self.norm = norm_layer(8 * dim)
+
+    def forward(self, x):
+        return linear(self.reduction, layer_norm(self.norm, ops.PatchMergeFn.apply(x)))
+
+
+class SwinTransformer_FPN(nn.Module):
+    """3D Swin Transformer + FPN (reference :692-789): patch embedding (k4 s4 conv as gather + GEMM), LayerNorm, 4 stages of
+    shifted-window blocks with patch merging between them, FPN over the 4 stage outputs."""
+
+    def __init__(self, patch_size: List[int], embed_dim: int, depths: List[int], num_heads: List[int], window_size: List[int],
+                 mlp_ratio: float = 4.0, dropout: float = 0.0, attention_dropout: float = 0.0, stochastic_depth_prob: float = 0.1,
+                 norm_layer: Optional[Callable[..., nn.Module]] = partial(nn.LayerNorm, eps=1e-5),
+                 block: Optional[Callable[..., nn.Module]] = SwinTransformerBlock,
+                 downsample_layer: Callable[..., nn.Module] = PatchMerging, expand_dim: bool = True, out_channels: int = 256,
+                 input_dim: int = 4):
+        super().__init__()
+        if input_dim != 4 or len(set(patch_size)) != 1:
+            raise NotImplementedError("the HIP patch embedding is specialised for 4-channel grids and cubic patches")
+        self.out_channels = out_channels
+        self.compute_dtype = torch.float32
+        self.patch_size = patch_size[0]
+        self.patch_partition = nn.Sequential(
+            nn.Conv3d(input_dim, embed_dim, kernel_size=tuple(patch_size), stride=tuple(patch_size)),
+            Permute([0, 2, 3, 4, 1]),
+            norm_layer(embed_dim),
+        )
+        self.stages = nn.ModuleList()
+        total_stage_blocks = sum(depths)
+        stage_block_id = 0
+        fpn_in_channels = []
+        for i_stage in range(len(depths)):
+            stage: List[nn.Module] = []
+            dim = embed_dim * 2 ** i_stage if expand_dim else embed_dim
+            fpn_in_channels.append(dim)
+            if i_stage > 0:
+                stage.append(downsample_layer(fpn_in_channels[-2], norm_layer, expand_dim))
+            for i_layer in range(depths[i_stage]):
+                sd_prob = stochastic_depth_prob * float(stage_block_id) / (total_stage_blocks - 1)
+                stage.append(block(dim, num_heads[i_stage], window_size=window_size,
+                                   shift_size=[0 if i_layer % 2 == 0 else w // 2 for w in window_size], mlp_ratio=mlp_ratio,
+                                   dropout=dropout, attention_dropout=attention_dropout, stochastic_depth_prob=sd_prob,
+                                   norm_layer=norm_layer))
+                stage_block_id += 1
+            self.stages.append(nn.Sequential(*stage))
+        self.fpn_neck = FPN(fpn_in_channels, out_channels, len(fpn_in_channels))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward_cl(self, x):
+        """x: channels-last [N,W,L,H,4] in compute dtype -> 4 channels-last maps."""
+        embed = self.patch_partition[0]
+        x = ops.ConvFn.apply(ops.patchify(x, self.patch_size), hip_nn._pack_of(embed), embed.out_channels, False, False, 1,
+                             embed.weight, embed.bias)
+        x = layer_norm(self.patch_partition[2], x)
+        feats = []
+        for stage in self.stages:
+            for mod in stage:
+                x = mod(x)
+            feats.append(x)
+        return self.fpn_neck.forward_cl(feats)
+
+    def forward(self, X):
+        x = ops.to_channels_last(X, self.compute_dtype)
+        return tuple(hip_nn.as_ncdhw(o) for o in self.forward_cl(x))

@@ -362,12 +362,12 @@ class PackedWeight:
         self.fwd = None
         self.dgrad = None
 
-    def get(self, weights, dtype, rows_total, need_dgrad):
+    def get(self, weights, dtype, rows_total, need_dgrad, cin=None):
         key = tuple((w.data_ptr(), w._version) for w in weights) + (dtype, rows_total, need_dgrad)
         if key == self.key:
             return self.fwd, self.dgrad
-        cin = weights[0].shape[1]
-        taps = weights[0][0, 0].numel()
+        cin = weights[0].shape[1] if cin is None else cin     # nn.Linear [out,in] and a flattened patch conv are taps == 1
+        taps = weights[0][0].numel() // cin
         dev = weights[0].device
         padded = rows_total != sum(w.shape[0] for w in weights)
         alloc = torch.zeros if padded else torch.empty
@@ -404,9 +404,9 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, pack, rows_total, relu, out_f32, nw, *wb):
         weights, biases = wb[:nw], wb[nw:]
         _chk(x)
-        ksize = weights[0].shape[2]
+        ksize = weights[0].shape[2] if weights[0][0].numel() != x.shape[-1] else 1
         need_dgrad = x.requires_grad
-        wp, wpd = pack.get(weights, x.dtype, rows_total, need_dgrad)
+        wp, wpd = pack.get(weights, x.dtype, rows_total, need_dgrad, x.shape[-1])
         bias = None
         if biases[0] is not None:
             bias = torch.cat([b.detach().float() for b in biases]) if nw > 1 else biases[0].detach().float().contiguous()
@@ -663,6 +663,157 @@ class AddReluFn(torch.autograd.Function):
         else:
             g = dy
         return g, g, None
+
+
+# ======================================================================================================================
+# Swin-3D pieces (csrc/swin.hip)
+# ======================================================================================================================
+def patchify(x, patch):
+    """[N,X,Y,Z,4] -> [N,X/p,Y/p,Z/p,4p^3] (the network input carries no gradient, so this is not an autograd node)."""
+    x = x.contiguous()
+    _chk(x)
+    n, gx, gy, gz, c = x.shape
+    if c != 4:
+        raise lib.NrpnError("patchify expects the 4-channel rgb-sigma grid")
+    y = torch.empty((n, gx // patch, gy // patch, gz // patch, 4 * patch ** 3), dtype=x.dtype, device=x.device)
+    call("patchify", _p(x), _p(y), n, gx, gy, gz, patch, _dt(x), _s())
+    return y
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(C) on the last dimension of a channels-last token tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        _chk(x)
+        c = x.shape[-1]
+        rows = x.numel() // c
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        call("layernorm_fwd", _p(x), _p(y), _p(g32), _p(b32), _p(mean), _p(rstd), rows, c, float(eps), _dt(x), _s())
+        ctx.save_for_backward(x, g32, mean, rstd)
+        ctx.sinks = (_sink(gamma), _sink(beta))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        c = x.shape[-1]
+        dx = torch.empty_like(x)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        call("layernorm_bwd", _p(x), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(dg), _p(db), x.numel() // c, c, _dt(x), _s())
+        gs, bs = ctx.sinks
+        if gs is not None:
+            gs.slot.add_(dg)
+            gs.notify()
+            dg = None
+        if bs is not None:
+            bs.slot.add_(db)
+            bs.notify()
+            db = None
+        return dx, dg, db, None
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _chk(x)
+        y = torch.empty_like(x)
+        call("gelu", _p(x), None, _p(y), x.numel(), 0, _dt(x), _s())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        call("gelu", _p(x), _p(dy), _p(dx), x.numel(), 1, _dt(x), _s())
+        return dx
+
+
+class ScaleAddFn(torch.autograd.Function):
+    """y = a + scale[n] * b -- residual join with the StochasticDepth('row') factor (scale None: plain add)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        y = torch.empty_like(a)
+        call("scale_add", _p(a), _p(b), _p(scale), _p(y), a.shape[0], a[0].numel(), _dt(a), _s())
+        ctx.save_for_backward(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        if scale is None:
+            return dy, dy, None
+        db = torch.empty_like(dy)
+        call("scale_add", None, _p(dy), _p(scale), _p(db), dy.shape[0], dy[0].numel(), _dt(dy), _s())
+        return dy, db, None
+
+
+class PatchMergeFn(torch.autograd.Function):
+    """[N,X,Y,Z,C] -> [N,ceil(X/2),ceil(Y/2),ceil(Z/2),8C], reference PatchMerging gather order (feature_extractor.py:403-419)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _chk(x)
+        n, gx, gy, gz, c = x.shape
+        y = torch.empty((n, (gx + 1) // 2, (gy + 1) // 2, (gz + 1) // 2, 8 * c), dtype=x.dtype, device=x.device)
+        call("patch_merge", _p(x), _p(y), n, gx, gy, gz, c, 0, _dt(x), _s())
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        n, gx, gy, gz, c = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        call("patch_merge", _p(dy), _p(dx), n, gx, gy, gz, c, 1, _dt(dy), _s())
+        return dx
+
+
+class WindowAttnFn(torch.autograd.Function):
+    """Shifted-window attention core between the qkv and proj Linears (reference feature_extractor.py:424-530), window
+    4x4x4, head_dim 32.  ``qkv_bias`` is what zero-padded tokens turn into after the qkv Linear."""
+
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, table, rel_index, heads, shift):
+        qkv = qkv.contiguous()
+        _chk(qkv, table, rel_index)
+        n, gx, gy, gz, c3 = qkv.shape
+        c = c3 // 3
+        qb = qkv_bias.detach().float().contiguous() if qkv_bias is not None else None
+        t32 = table.detach().float().contiguous()
+        out = torch.empty((n, gx, gy, gz, c), dtype=qkv.dtype, device=qkv.device)
+        call("window_attn_fwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(out), n, gx, gy, gz, c, heads, int(shift), _dt(qkv), _s())
+        ctx.save_for_backward(qkv, qb, t32, rel_index)
+        ctx.meta = (heads, int(shift), any(g % 4 for g in (gx, gy, gz)))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, qb, t32, rel_index = ctx.saved_tensors
+        heads, shift, padded = ctx.meta
+        dout = dout.contiguous()
+        n, gx, gy, gz, c3 = qkv.shape
+        c = c3 // 3
+        dqkv = torch.empty_like(qkv)
+        dtable = torch.empty_like(t32)
+        dpad = torch.empty(c3, dtype=torch.float32, device=qkv.device) if (padded and qb is not None) else None
+        call("window_attn_bwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(dout), _p(dqkv), _p(dtable), _p(dpad), n, gx, gy, gz, c, heads,
+             shift, _dt(qkv), _s())
+        return dqkv, dpad, dtable, None, None, None
 
 
 class _ToChannelsLast(torch.autograd.Function):

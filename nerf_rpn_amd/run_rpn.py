@@ -154,8 +154,14 @@ class Trainer:
             self.backbone = ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True)
         elif t in ('vgg_AF', 'vgg_EF'):
             self.backbone = VGG_FPN(t[-2:], 4, True, self.args.resolution)
-        else:
-            self.backbone = SwinTransformer_FPN()      # raises NotImplementedError until the Swin kernels land
+        else:       # run_rpn.py:281-292
+            swin = {'swin_t': {'embed_dim': 96, 'depths': [2, 2, 6, 2], 'num_heads': [3, 6, 12, 24]},
+                    'swin_s': {'embed_dim': 96, 'depths': [2, 2, 18, 2], 'num_heads': [3, 6, 12, 24]},
+                    'swin_b': {'embed_dim': 128, 'depths': [2, 2, 18, 2], 'num_heads': [3, 6, 12, 24]},
+                    'swin_l': {'embed_dim': 192, 'depths': [2, 2, 18, 2], 'num_heads': [6, 12, 24, 48]}}[t]
+            self.backbone = SwinTransformer_FPN(patch_size=[4, 4, 4], embed_dim=swin['embed_dim'], depths=swin['depths'],
+                                                num_heads=swin['num_heads'], window_size=[4, 4, 4], stochastic_depth_prob=0.1,
+                                                expand_dim=True)
 
     def init_datasets(self):
         a = self.args

@@ -144,3 +144,148 @@ class ResNetFPN(nn.Module):
         for i, sm in enumerate(self.smooths):
             p[i + 1] = sm(p[i + 1])
         return p[::-1]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Swin-3D (feature_extractor.py:382-789).  Written with explicit pad / roll / window partition on [B,H,W,D,C] tokens.
+# ----------------------------------------------------------------------------------------------------------------------
+def window_attention(x, qkv_w, qkv_b, proj_w, proj_b, table, index, heads, shift, ws=4):
+    """shifted_window_attention (feature_extractor.py:382-500) for a cubic window ``ws`` and shift in {0, ws // 2}."""
+    B, H, W, D, C = x.shape
+    pad = [(ws - s % ws) % ws for s in (H, W, D)]
+    x = F.pad(x, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+    pH, pW, pD = x.shape[1:4]
+    sh = [0 if ws >= p else shift for p in (pH, pW, pD)]          # :425-430
+    if sum(sh) > 0:
+        x = torch.roll(x, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
+    nW = (pH // ws) * (pW // ws) * (pD // ws)
+
+    def partition(t):     # [.., pH, pW, pD, c] -> [.. * nW, ws^3, c]
+        lead, c = t.shape[:-4], t.shape[-1]
+        t = t.reshape(*lead, pH // ws, ws, pW // ws, ws, pD // ws, ws, c)
+        n = len(lead)
+        t = t.permute(*range(n), n, n + 2, n + 4, n + 1, n + 3, n + 5, n + 6)
+        return t.reshape(-1, ws ** 3, c)
+
+    xw = partition(x)
+    qkv = F.linear(xw, qkv_w, qkv_b).reshape(xw.shape[0], ws ** 3, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (C // heads) ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    attn = attn + table[index].view(ws ** 3, ws ** 3, -1).permute(2, 0, 1).unsqueeze(0)
+    if sum(sh) > 0:       # :463-479
+        region = x.new_zeros((pH, pW, pD))
+        count = 0
+        for h in ((0, -ws), (-ws, -sh[0]), (-sh[0], None)):
+            for w in ((0, -ws), (-ws, -sh[1]), (-sh[1], None)):
+                for d in ((0, -ws), (-ws, -sh[2]), (-sh[2], None)):
+                    region[h[0]:h[1], w[0]:w[1], d[0]:d[1]] = count
+                    count += 1
+        r = partition(region[..., None])[..., 0]                 # [nW, ws^3]
+        mask = r.unsqueeze(1) - r.unsqueeze(2)
+        mask = torch.where(mask != 0, torch.full_like(mask, -100.0), torch.zeros_like(mask))
+        attn = (attn.view(B, nW, heads, ws ** 3, ws ** 3) + mask[None, :, None]).view(-1, heads, ws ** 3, ws ** 3)
+    attn = F.softmax(attn, dim=-1)
+    y = (attn @ v).transpose(1, 2).reshape(xw.shape[0], ws ** 3, C)
+    y = F.linear(y, proj_w, proj_b)
+    y = y.view(B, pH // ws, pW // ws, pD // ws, ws, ws, ws, C).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, pH, pW, pD, C)
+    if sum(sh) > 0:
+        y = torch.roll(y, shifts=(sh[0], sh[1], sh[2]), dims=(1, 2, 3))
+    return y[:, :H, :W, :D].contiguous()
+
+
+class WindowAttention(nn.Module):
+    """ShiftedWindowAttention (feature_extractor.py:533-613)."""
+
+    def __init__(self, dim, heads, shift, ws=4):
+        super().__init__()
+        self.heads, self.shift, self.ws = heads, shift, ws
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 3, heads))
+        a = torch.arange(ws)
+        c = torch.stack(torch.meshgrid(a, a, a, indexing="ij")).flatten(1)
+        rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0) + (ws - 1)
+        self.register_buffer("relative_position_index",
+                             (rel[..., 0] * (2 * ws - 1) ** 2 + rel[..., 1] * (2 * ws - 1) + rel[..., 2]).flatten())
+
+    def forward(self, x):
+        return window_attention(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
+                                self.relative_position_bias_table, self.relative_position_index, self.heads, self.shift, self.ws)
+
+
+class SwinBlock(nn.Module):
+    """SwinTransformerBlock (feature_extractor.py:616-653); ``drop`` = StochasticDepth('row') probability.
+    ``noise_hook(shape) -> tensor`` lets a test inject the per-sample keep mask instead of drawing it."""
+
+    def __init__(self, dim, heads, shift, drop=0.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn = WindowAttention(dim, heads, shift)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-5)
+        self.mlp = nn.Sequential(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Dropout(0.0), nn.Linear(4 * dim, dim), nn.Dropout(0.0))
+        self.drop = drop
+        self.noise_hook = None
+
+    def _sd(self, y):
+        if not self.training or self.drop == 0.0:
+            return y
+        keep = 1.0 - self.drop
+        shape = [y.shape[0]] + [1] * (y.ndim - 1)
+        noise = self.noise_hook(shape) if self.noise_hook else torch.empty(shape).bernoulli_(keep)
+        return y * (noise / keep if keep > 0 else noise)
+
+    def forward(self, x):
+        x = x + self._sd(self.attn(self.norm1(x)))
+        return x + self._sd(self.mlp(self.norm2(x)))
+
+
+class PatchMerge(nn.Module):
+    """PatchMerging (feature_extractor.py:656-690)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Linear(8 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(8 * dim, eps=1e-5)
+
+    def forward(self, x):
+        H, W, D = x.shape[1:4]
+        x = F.pad(x, (0, 0, 0, D % 2, 0, W % 2, 0, H % 2))
+        parts = [x[:, i::2, j::2, k::2] for k in (0, 1) for j in (0, 1) for i in (0, 1)]     # x0..x7 of :672-680
+        return self.reduction(self.norm(torch.cat(parts, -1)))
+
+
+class _Permute(nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self.dims = dims
+
+    def forward(self, x):
+        return x.permute(*self.dims)
+
+
+class SwinFPN(nn.Module):
+    """SwinTransformer_FPN(patch 4, window 4, expand_dim) (feature_extractor.py:692-789)."""
+
+    def __init__(self, embed_dim=96, depths=(2, 2, 18, 2), heads=(3, 6, 12, 24), stochastic_depth_prob=0.1):
+        super().__init__()
+        self.out_channels = 256
+        self.patch_partition = nn.Sequential(nn.Conv3d(4, embed_dim, 4, stride=4), _Permute([0, 2, 3, 4, 1]),
+                                             nn.LayerNorm(embed_dim, eps=1e-5))
+        self.stages = nn.ModuleList()
+        total, bid = sum(depths), 0
+        for i, depth in enumerate(depths):
+            dim = embed_dim * 2 ** i
+            mods = [PatchMerge(dim // 2)] if i > 0 else []
+            for j in range(depth):
+                mods.append(SwinBlock(dim, heads[i], 0 if j % 2 == 0 else 2, stochastic_depth_prob * bid / (total - 1)))
+                bid += 1
+            self.stages.append(nn.Sequential(*mods))
+        self.fpn_neck = FPN([embed_dim * 2 ** i for i in range(len(depths))], 256)
+
+    def forward(self, x):
+        x = self.patch_partition(x)
+        feats = []
+        for stage in self.stages:
+            x = stage(x)
+            feats.append(x.permute(0, 4, 1, 2, 3).contiguous())
+        return self.fpn_neck(feats)

@@ -26,7 +26,7 @@ from oracle import anchors as OA, boxes as OB, coders as OC, geometry as OG, met
 from model import anchor as R_anchor, utils as R_utils, rpn as R_rpn  # noqa: E402
 from model.coder import AABBCoder, MidpointOffsetCoder  # noqa: E402
 from model.coder import misc as R_misc  # noqa: E402
-from model.feature_extractor import VGG_FPN, ResNet_FPN_256, Bottleneck  # noqa: E402
+from model.feature_extractor import VGG_FPN, ResNet_FPN_256, Bottleneck, SwinTransformer_FPN  # noqa: E402
 from model.nerf_rpn import NeRFRegionProposalNetwork  # noqa: E402
 from model.rotated_iou import oriented_iou_loss as R_iou, box_intersection_2d as R_b2d  # noqa: E402
 import run_rpn as R_run  # noqa: E402
@@ -277,9 +277,16 @@ def gen_cli():
     save("datasets", g32=g32, g8=g8, boxes=b, x0=x0, x1=x1, aug_x=xa, aug_boxes=ba, scannet_alpha=sn)
 
 
+SWIN_S = dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24])      # run_rpn.py:283
+
+
 def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
-    bb = ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True) if kw.get("backbone") == "resnet" \
-        else VGG_FPN("EF", 4, True, resolution)
+    if kw.get("backbone") == "swin":
+        bb = SwinTransformer_FPN(patch_size=[4, 4, 4], window_size=[4, 4, 4], stochastic_depth_prob=kw.get("sd", 0.1), expand_dim=True,
+                                 **SWIN_S)
+    else:
+        bb = ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True) if kw.get("backbone") == "resnet" \
+            else VGG_FPN("EF", 4, True, resolution)
     hd = R_anchor.RPNHead(256, 13, 4, rotate=rotated)
     seeded_state(bb, 1); seeded_state(hd, 2)
     return NeRFRegionProposalNetwork(bb, ref_anchor_gen(), hd, rpn_pre_nms_top_n_train=2500, rpn_pre_nms_top_n_test=kw.get("pre", 2500),
@@ -289,7 +296,10 @@ def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
 
 
 def build_oracle(rotated, resolution, reg_loss="smooth_l1", **kw):
-    bb = ON.ResNetFPN() if kw.get("backbone") == "resnet" else ON.VGGFPN("EF", 4, resolution)
+    if kw.get("backbone") == "swin":
+        bb = ON.SwinFPN(SWIN_S["embed_dim"], SWIN_S["depths"], SWIN_S["num_heads"], kw.get("sd", 0.1))
+    else:
+        bb = ON.ResNetFPN() if kw.get("backbone") == "resnet" else ON.VGGFPN("EF", 4, resolution)
     hd = ON.RPNHead(256, 13, 4, rotated)
     seeded_state(bb, 1); seeded_state(hd, 2)
     return OR.Detector(bb, OR.RPN(hd, rotated=rotated, reg_loss_type=reg_loss, pre_nms_top_n=kw.get("pre", 2500),
@@ -312,7 +322,11 @@ def gen_eval():
              ("eval_obb_s2", True, 160, [(48, 40, 32)], {}),
              ("eval_obb_s1_cfg0", True, 64, [(16, 16, 16)], {"pre": 600}),       # BASELINE config[0] at 16^3
              ("eval_aabb_batch2", False, 160, [(48, 48, 32), (40, 32, 32)], {}),
-             ("eval_resnet_obb", True, 160, [(64, 56, 48)], {"backbone": "resnet"})]
+             ("eval_resnet_obb", True, 160, [(64, 56, 48)], {"backbone": "resnet"}),
+             # swin_s: token grids 20x14x12 -> 10x7x6 -> 5x4x3 -> 3x2x2: window padding on every stage, a stage whose
+             # shift applies to one axis only (padded 8x4x4), and odd sizes in the patch merging
+             ("eval_swin_obb", True, 160, [(80, 56, 48)], {"backbone": "swin"}),
+             ("eval_swin_aabb_batch2", False, 160, [(64, 64, 48), (48, 40, 40)], {"backbone": "swin"})]
     only = os.environ.get("GOLDEN_ONLY")
     for name, rot, res, shapes, kw in cases:
         if only and only not in name:
@@ -339,7 +353,8 @@ def gen_eval():
 
 def gen_train():
     print("end-to-end train")
-    cases = [("train_resnet_aabb", False, "smooth_l1", [(64, 56, 48)]),
+    cases = [("train_swin_obb", True, "smooth_l1", [(80, 56, 48)]),      # stochastic depth 0 (the draw is RNG-stream specific)
+             ("train_resnet_aabb", False, "smooth_l1", [(64, 56, 48)]),
              ("train_aabb", False, "smooth_l1", [(48, 48, 48)]),
              ("train_obb", True, "smooth_l1", [(48, 40, 32)]),
              ("train_obb_iou", True, "iou", [(48, 40, 32)]),
@@ -350,7 +365,7 @@ def gen_train():
     for name, rot, loss, shapes in cases:
         if only and only not in name:
             continue
-        bk = {"backbone": "resnet"} if "resnet" in name else {}
+        bk = {"backbone": "resnet"} if "resnet" in name else ({"backbone": "swin", "sd": 0.0} if "swin" in name else {})
         ref = build_ref(rot, 160, loss, **bk).train()
         orc = build_oracle(rot, 160, loss, **bk)
         orc.backbone.train(); orc.rpn.head.train()

@@ -14,12 +14,15 @@ def T(a, dev=None):
     return t.to(dev) if dev is not None else t
 
 
-def build(rotated, resolution, dev, reg_loss="smooth_l1", pre=2500, post=2500, backbone="vgg"):
+def build(rotated, resolution, dev, reg_loss="smooth_l1", pre=2500, post=2500, backbone="vgg", sd=0.1):
     from nerf_rpn_amd.model import VGG_FPN, RPNHead, NeRFRegionProposalNetwork, AnchorGenerator3D
-    from nerf_rpn_amd.model.feature_extractor import ResNet_FPN_256, Bottleneck
+    from nerf_rpn_amd.model.feature_extractor import ResNet_FPN_256, Bottleneck, SwinTransformer_FPN
     from nerf_rpn_amd import ops
     if backbone == "resnet":
         bb = ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True)
+    elif backbone == "swin":
+        bb = SwinTransformer_FPN(patch_size=[4, 4, 4], embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24],
+                                 window_size=[4, 4, 4], stochastic_depth_prob=sd, expand_dim=True)
     else:
         bb = VGG_FPN("EF", 4, True, resolution)
     hd = RPNHead(256, 13, 4, rotate=rotated)
@@ -36,7 +39,8 @@ def scene(shape, seed):
     return torch.rand(4, *[int(s) for s in shape], generator=torch.Generator().manual_seed(seed))
 
 
-@pytest.mark.parametrize("name", ["eval_aabb_s2", "eval_obb_s2", "eval_obb_s1_cfg0", "eval_aabb_batch2", "eval_resnet_obb"])
+@pytest.mark.parametrize("name", ["eval_aabb_s2", "eval_obb_s2", "eval_obb_s1_cfg0", "eval_aabb_batch2", "eval_resnet_obb",
+                                  "eval_swin_obb", "eval_swin_aabb_batch2"])
 def test_eval_matches_reference(name, golden, dev):
     g = golden(name)
     m = build(bool(g["rotated"]), int(g["resolution"]), dev, pre=int(g["pre"]), backbone=str(g.get("backbone", "vgg"))).eval()
@@ -77,11 +81,11 @@ def test_eval_matches_reference(name, golden, dev):
 
 
 @pytest.mark.parametrize("name", ["train_aabb", "train_obb", "train_obb_iou", "train_obb_giou", "train_obb_diou", "train_aabb_batch2",
-                                  "train_resnet_aabb"])
+                                  "train_resnet_aabb", "train_swin_obb"])
 def test_train_matches_reference(name, golden, dev):
     g = golden(name)
     rot = bool(g["rotated"])
-    m = build(rot, 160, dev, str(g["reg_loss_type"]), backbone=str(g.get("backbone", "vgg"))).train()
+    m = build(rot, 160, dev, str(g["reg_loss_type"]), backbone=str(g.get("backbone", "vgg")), sd=0.0).train()
     xs = [scene(s, 200 + i).to(dev) for i, s in enumerate(g["shapes"])]
     gts = [T(g[f"gt{i}"], dev) for i in range(len(xs))]
     pos, neg = T(g["pos_idx"], dev), T(g["neg_idx"], dev)
