@@ -351,6 +351,30 @@ def gen_eval():
         save(name, **arrs)
 
 
+def record_grads(arrs, rp, op, p64):
+    """Store the reference gradients (full if small, 256 samples otherwise), their fp64 counterparts and the reference's own
+    fp32 rounding error; returns the worst oracle-vs-reference relative error."""
+    worst = 0.0
+    for k, p in rp.items():
+        gr, go = p.grad, op[k].grad
+        # conv biases feeding a train-mode BatchNorm have a mathematically-zero gradient (pure
+        # rounding noise ~1e-6 in both implementations), hence the absolute floor.
+        rel = max(0.0, (gr - go).abs().max().item() - 2e-5) / (gr.abs().max().item() + 1e-12)
+        worst = max(worst, rel)
+        arrs["gnorm/" + k] = gr.norm()
+        g64 = p64[k].grad
+        arrs["err32/" + k] = (gr.double() - g64).abs().max()
+        arrs["gmax64/" + k] = g64.abs().max()
+        if gr.numel() <= 512:
+            arrs["grad/" + k] = gr
+            arrs["grad64/" + k] = g64
+        else:
+            idx, val = subsample(gr, 256)
+            arrs["gidx/" + k], arrs["gval/" + k] = idx, val
+            arrs["gval64/" + k] = g64.reshape(-1)[idx]
+    return worst
+
+
 def gen_train():
     print("end-to-end train")
     cases = [("train_swin_obb", True, "smooth_l1", [(80, 56, 48)]),      # stochastic depth 0 (the draw is RNG-stream specific)
@@ -404,24 +428,7 @@ def gen_train():
         arrs["labels"] = torch.cat(aux["labels"]).to(torch.int8)
         rp = dict(ref.backbone.named_parameters()); rp.update({"head." + k: v for k, v in ref.rpn.head.named_parameters()})
         op = dict(orc.backbone.named_parameters()); op.update({"head." + k: v for k, v in orc.rpn.head.named_parameters()})
-        worst = 0.0
-        for k, p in rp.items():
-            gr, go = p.grad, op[k].grad
-            # conv biases feeding a train-mode BatchNorm have a mathematically-zero gradient (pure
-            # rounding noise ~1e-6 in both implementations), hence the absolute floor.
-            rel = max(0.0, (gr - go).abs().max().item() - 2e-5) / (gr.abs().max().item() + 1e-12)
-            worst = max(worst, rel)
-            arrs["gnorm/" + k] = gr.norm()
-            g64 = p64[k].grad
-            arrs["err32/" + k] = (gr.double() - g64).abs().max()
-            arrs["gmax64/" + k] = g64.abs().max()
-            if gr.numel() <= 512:
-                arrs["grad/" + k] = gr
-                arrs["grad64/" + k] = g64
-            else:
-                idx, val = subsample(gr, 256)
-                arrs["gidx/" + k], arrs["gval/" + k] = idx, val
-                arrs["gval64/" + k] = g64.reshape(-1)[idx]
+        worst = record_grads(arrs, rp, op, p64)
         assert worst < 2e-3, (name, worst)
         for i, t in enumerate(gts):
             arrs[f"gt{i}"] = t
@@ -430,7 +437,113 @@ def gen_train():
         save(name, **arrs)
 
 
+def fcos_args(rot, **kw):
+    """argparse defaults of run_fcos.py:30-131 with the flags of train_fcos.sh / test_fcos.sh."""
+    import argparse
+    a = dict(num_convs=4, norm_reg_targets=True, centerness_on_reg=True, rotated_bbox=rot, pre_nms_thresh=0.0, pre_nms_top_n=2500,
+             nms_thresh=0.3, fpn_post_nms_top_n=2500, min_size=0.0, center_sampling_radius=1.5, iou_loss_type="iou",
+             use_additional_l1_loss=False, proj2d_loss_weight=0.0)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+def build_fcos(rot, backbone, **kw):
+    """(reference FCOSOverNeRF, oracle FCOS) with identical seeded weights."""
+    from model.fcos.fcos import FCOSOverNeRF
+    from oracle import fcos as OF
+    args = fcos_args(rot, **kw)
+    if backbone == "swin":
+        rb = SwinTransformer_FPN(patch_size=[4, 4, 4], window_size=[4, 4, 4], stochastic_depth_prob=0, expand_dim=True, **SWIN_S)
+        ob = ON.SwinFPN(SWIN_S["embed_dim"], SWIN_S["depths"], SWIN_S["num_heads"], 0.0)
+    else:
+        rb, ob = VGG_FPN("EF", 4, True, 160), ON.VGGFPN("EF", 4, 160)
+    seeded_state(rb, 1); seeded_state(ob, 1)
+    ref = FCOSOverNeRF(args, rb, [4, 8, 16, 32])
+    seeded_state(ref.fcos_module.head, 2, bias_jitter=0.5)
+    for l, sc in enumerate(ref.fcos_module.head.scales):
+        sc.scale.data.fill_(0.8 + 0.15 * l)
+    oh = OF.FCOSHead(256, args.num_convs, [4, 8, 16, 32], args.norm_reg_targets, args.centerness_on_reg, rot)
+    oh.load_state_dict(ref.fcos_module.head.state_dict())
+    orc = OF.FCOS(ob, oh, [4, 8, 16, 32], rot, args.center_sampling_radius, args.iou_loss_type, args.norm_reg_targets,
+                  args.use_additional_l1_loss, args.proj2d_loss_weight, args.pre_nms_thresh, args.pre_nms_top_n, args.nms_thresh,
+                  args.fpn_post_nms_top_n, args.min_size)
+    return ref, orc
+
+
+def gen_fcos():
+    print("FCOS end-to-end")
+    only = os.environ.get("GOLDEN_ONLY")
+    evals = [("fcos_eval_aabb_vgg", False, "vgg", [(64, 56, 48)], {}),
+             ("fcos_eval_obb_swin", True, "swin", [(80, 56, 48)], {}),
+             ("fcos_eval_obb_batch2", True, "vgg", [(64, 48, 48), (48, 40, 32)], {"pre_nms_top_n": 300, "fpn_post_nms_top_n": 400})]
+    for name, rot, bbk, shapes, kw in evals:
+        if only and only not in name:
+            continue
+        ref, orc = build_fcos(rot, bbk, **kw)
+        ref.eval(); orc.backbone.eval()
+        xs = [scene(s, 300 + i) for i, s in enumerate(shapes)]
+        with torch.no_grad():
+            boxes, _, scores = ref([x.clone() for x in xs])
+            oboxes, _, oscores, aux = orc([x.clone() for x in xs])
+        arrs = {"shapes": shapes, "rotated": rot, "backbone": bbk, "pre_nms_top_n": kw.get("pre_nms_top_n", 2500),
+                "fpn_post_nms_top_n": kw.get("fpn_post_nms_top_n", 2500)}
+        for key in ("box_cls", "box_reg", "centerness"):
+            for l, t in enumerate(aux[key]):
+                idx, val = subsample(t, 1024)
+                arrs[f"{key}{l}_idx"], arrs[f"{key}{l}_val"] = idx, val
+        for i in range(len(xs)):
+            assert boxes[i].shape == oboxes[i].shape, (name, boxes[i].shape, oboxes[i].shape)
+            close(oboxes[i], boxes[i], 2e-3, f"{name} boxes"); close(oscores[i], scores[i], 1e-5, f"{name} scores")
+            arrs[f"boxes{i}"], arrs[f"scores{i}"] = boxes[i], scores[i]
+            print(f"   {name}[{i}]: {boxes[i].shape[0]} boxes, score range {scores[i].min():.4f}..{scores[i].max():.4f}, levels",
+                  torch.bincount(boxes[i][:, 0].long(), minlength=4).tolist())
+        save(name, **arrs)
+
+    trains = [("fcos_train_aabb_vgg", False, "vgg", [(64, 56, 48)], {}),
+              ("fcos_train_aabb_giou_batch2", False, "vgg", [(64, 48, 48), (48, 40, 32)], {"iou_loss_type": "giou"}),
+              ("fcos_train_obb_swin", True, "swin", [(80, 56, 48)], {}),
+              ("fcos_train_obb_l1_proj", True, "vgg", [(64, 56, 48)], {"iou_loss_type": "linear_iou", "use_additional_l1_loss": True,
+                                                                     "proj2d_loss_weight": 0.5}),
+              ("fcos_train_obb_diou", True, "vgg", [(64, 56, 48)], {"iou_loss_type": "diou"}),
+              ("fcos_train_obb_smoothl1", True, "vgg", [(64, 56, 48)], {"iou_loss_type": "smooth_l1"})]
+    for name, rot, bbk, shapes, kw in trains:
+        if only and only not in name:
+            continue
+        ref, orc = build_fcos(rot, bbk, **kw)
+        ref.train(); orc.backbone.train()
+        xs = [scene(s, 400 + i) for i, s in enumerate(shapes)]
+        g = torch.Generator().manual_seed(78)
+        gts = [(rand_obb(6, g, 10, min(s) - 10, 6, 36) if rot else rand_aabb(6, g, 4, min(s) - 14, 6, 40)) for s in shapes]
+        _, losses, _ = ref([x.clone() for x in xs], [t.clone() for t in gts])
+        (losses["loss_cls"] + losses["loss_reg"] + losses["loss_centerness"]).backward()
+        _, olosses, _, aux = orc([x.clone() for x in xs], [t.clone() for t in gts], training=True)
+        (olosses["loss_cls"] + olosses["loss_reg"] + olosses["loss_centerness"]).backward()
+        arrs = {"shapes": shapes, "rotated": rot, "backbone": bbk, "iou_loss_type": kw.get("iou_loss_type", "iou"),
+                "use_additional_l1_loss": kw.get("use_additional_l1_loss", False), "proj2d_loss_weight": kw.get("proj2d_loss_weight", 0.0)}
+        for k in losses:
+            close(olosses[k], losses[k], 2e-5 * max(1.0, abs(losses[k].item())), f"{name} {k}")
+            arrs[k] = losses[k]
+        arrs["labels"], arrs["reg_targets"], arrs["pos"] = aux["labels"].to(torch.int8), aux["reg_targets"], aux["pos"]
+        _, o64 = build_fcos(rot, bbk, **kw)
+        o64.backbone.double().train(); o64.head.double()
+        _, l64, _, _ = o64([x.double() for x in xs], [t.double() for t in gts], training=True)
+        (l64["loss_cls"] + l64["loss_reg"] + l64["loss_centerness"]).backward()
+        name_of = lambda bb, hd: {**dict(bb.named_parameters()), **{"head." + k: v for k, v in hd.named_parameters()}}
+        rp, op, p64 = name_of(ref.backbone, ref.fcos_module.head), name_of(orc.backbone, orc.head), name_of(o64.backbone, o64.head)
+        unused = [k for k, p in rp.items() if p.grad is None]
+        for k in unused:
+            rp.pop(k); op.pop(k); p64.pop(k)
+        arrs["unused"] = ",".join(unused)
+        worst = record_grads(arrs, rp, op, p64)
+        assert worst < 2e-3, (name, worst)
+        for i, t in enumerate(gts):
+            arrs[f"gt{i}"] = t
+        print(f"   {name}: losses", {k: round(v.item(), 6) for k, v in losses.items()}, "pos", int(aux["pos"].numel()),
+              "worst rel grad err oracle-vs-ref", f"{worst:.2e}", "unused", unused)
+        save(name, **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "eval", "train"]
+    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "eval", "train", "fcos"]
     for w in which:
         globals()["gen_" + w]()
