@@ -283,6 +283,56 @@ int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bi
                          int heads, int shift, int dtype, nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * FCOS variant of the path.  [a23]  (model/fcos/fcos.py, inference.py, loss.py, utils.py)
+ *   Flattened location order everywhere: level-major, then scene, then voxel (x, y, z; z fastest) -- the order of
+ *   box_cls[l].permute(0,2,3,4,1).reshape(-1) concatenated over levels (loss.py:506-518).  Locations are index
+ *   arithmetic: idx * stride + stride / 2 (fcos.py:233-250).  dims: host int32 [levels*3]; strides: host int32 [levels];
+ *   ori_sizes: host f32 [n*3] un-padded scene sizes (NULL = no padding mask, as the reference does for batch 1).
+ * ---------------------------------------------------------------------------------------------- */
+/* nn.GroupNorm(groups, C) (+ fused ReLU) on channels-last [n, rows, C] (tower norm, fcos.py:57,69); mean/rstd f32 [n*groups]
+ * are saved for the backward, which overwrites dgamma/dbeta.  workspace: nrpn_groupnorm_workspace_bytes(n, c, groups). */
+size_t nrpn_groupnorm_workspace_bytes(int n, int c, int groups);
+int nrpn_groupnorm_fwd(const void *x, void *y, const float *gamma, const float *beta, float *mean, float *rstd, int n,
+                       int64_t rows, int c, int groups, float eps, int relu, int dtype, void *workspace, nrpn_stream_t stream);
+int nrpn_groupnorm_bwd(const void *x, const void *y, const void *dy, void *dx, const float *gamma, const float *mean,
+                       const float *rstd, float *dgamma, float *dbeta, int n, int64_t rows, int c, int groups, int relu, int dtype,
+                       void *workspace, nrpn_stream_t stream);
+/* Head epilogue for one level (fcos.py:104-128).  cls_out / box_out: f32 [rows, wrows] outputs of the fused 3x3x3 GEMMs
+ * (cls_out col 0 = cls_logits, col 1 = centerness when !ctr_on_reg; box_out cols 0..reg_dim-1 = bbox_pred, col reg_dim =
+ * centerness when ctr_on_reg).  reg = norm_reg ? [relu(scale*raw[:6]) * stride_mul, scale*raw[6:]] : exp(scale*raw).
+ * The backward overwrites d_cls_out / d_box_out and ACCUMULATES d_scale (f32 scalar). */
+int nrpn_fcos_head_out_f32(const float *cls_out, const float *box_out, int wrows, const float *scale, float stride_mul,
+                           int norm_reg, int reg_dim, int ctr_on_reg, int64_t rows, float *logits, float *reg, float *ctr,
+                           nrpn_stream_t stream);
+int nrpn_fcos_head_out_bwd_f32(const float *box_out, int wrows, const float *scale, float stride_mul, int norm_reg, int reg_dim,
+                               int ctr_on_reg, int64_t rows, const float *d_logits, const float *d_reg, const float *d_ctr,
+                               float *d_cls_out, float *d_box_out, float *d_scale, nrpn_stream_t stream);
+/* Per-GT summary [count, 8] = footprint AABB (6) + midpoint offsets alpha, beta of encode_fcos_obb (utils.py:65-105);
+ * width 6 (AABB GT) copies the box and zeroes alpha/beta. */
+int nrpn_fcos_gt_summary_f32(const float *gt, int count, int width, float *summary, nrpn_stream_t stream);
+/* FCOSLossComputation.prepare_targets (loss.py:270-437): per location the smallest-volume GT among those passing centre
+ * sampling (radius * stride; radius <= 0: inside the box) and the level's size range; labels i8 {1, 0, -1 = padding},
+ * reg_targets f32 [total, reg_dim] (first 6 / stride when norm_reg), num_pos = number of label-1 locations.
+ * gt_offsets: host int32 [n+1] rows of `summary` per scene. */
+int nrpn_fcos_targets_f32(const float *summary, const int32_t *gt_offsets, int n, int levels, const int32_t *dims,
+                          const int32_t *strides, const float *ori_sizes, float radius, int norm_reg, int reg_dim, int8_t *labels,
+                          float *reg_targets, int32_t *num_pos, nrpn_stream_t stream);
+/* torchvision sigmoid_focal_loss(alpha, gamma=2, reduction='sum') over labels >= 0 (loss.py:541-545): loss_sum f32 scalar
+ * (overwritten) and, when dlogits != NULL, d loss_sum / d logit per element. */
+int nrpn_fcos_focal_f32(const float *logits, const int8_t *labels, int64_t count, float alpha, float *loss_sum, float *dlogits,
+                        nrpn_stream_t stream);
+/* FCOSPostProcessor.forward_for_single_feature_map, all levels at once (inference.py:56-88): score = sigmoid(cls) *
+ * sigmoid(ctr) where the location is un-padded and sigmoid(cls) > pre_nms_thresh, else -1. */
+int nrpn_fcos_scores_f32(const float *logits, const float *ctr, int n, int levels, const int32_t *dims, const int32_t *strides,
+                         const float *ori_sizes, float pre_nms_thresh, float *scores, nrpn_stream_t stream);
+/* Decode the top-k candidates of every (level, scene) segment (inference.py:108-133): idx i32 [levels*n*seg_len] location
+ * index inside the segment (< 0: empty slot), score = cls*ctr.  AABB: loc -/+ reg clipped to the scene (ori_sizes required);
+ * OBB: decode_fcos_obb (utils.py:12-62).  out_scores = sqrt(score), or -1 for empty slots / boxes below min_size. */
+int nrpn_fcos_decode_f32(const int32_t *idx, const float *score, int64_t count, int64_t seg_len, const float *reg, int n,
+                         int levels, const int32_t *dims, const int32_t *strides, const float *ori_sizes, int reg_dim,
+                         float min_size, float *boxes, float *out_scores, float *out_levels, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 arena.  [a21]  (clip_grad_norm_ + AdamW, run_rpn.py:345-349,390-395)
  *   grad_scale folds the 1/world_size of the data-parallel mean into both kernels (sum all-reduce, no extra pass).
  *   sumsq: f32 device scalar = sum((g*grad_scale)^2) (zeroed by nrpn_grad_sumsq); step applies g *= grad_scale * min(1, max_norm/(sqrt(sumsq)+1e-6)),

@@ -816,6 +816,190 @@ class WindowAttnFn(torch.autograd.Function):
         return dqkv, dpad, dtable, None, None, None
 
 
+# ======================================================================================================================
+# FCOS pieces (csrc/fcos.hip)
+# ======================================================================================================================
+class GroupNormFn(torch.autograd.Function):
+    """nn.GroupNorm(groups, C) (+ fused ReLU) on a channels-last [N,X,Y,Z,C] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        x = x.contiguous()
+        _chk(x)
+        n, c = x.shape[0], x.shape[-1]
+        rows = x[0].numel() // c
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+        ws = torch.empty(query("groupnorm_workspace_bytes", n, c, groups), dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        call("groupnorm_fwd", _p(x), _p(y), _p(g32), _p(b32), _p(mean), _p(rstd), n, rows, c, groups, float(eps), int(relu), _dt(x), _p(ws), _s())
+        ctx.save_for_backward(x, y if relu else None, g32, mean, rstd)
+        ctx.meta = (groups, relu)
+        ctx.sinks = (_sink(gamma), _sink(beta))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, g32, mean, rstd = ctx.saved_tensors
+        groups, relu = ctx.meta
+        dy = dy.contiguous()
+        n, c = x.shape[0], x.shape[-1]
+        dx = torch.empty_like(x)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(query("groupnorm_workspace_bytes", n, c, groups), dtype=torch.uint8, device=x.device)
+        call("groupnorm_bwd", _p(x), _p(y), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(dg), _p(db), n, x[0].numel() // c, c, groups,
+             int(relu), _dt(x), _p(ws), _s())
+        gs, bs = ctx.sinks
+        if gs is not None:
+            gs.slot.add_(dg)
+            gs.notify()
+            dg = None
+        if bs is not None:
+            bs.slot.add_(db)
+            bs.notify()
+            db = None
+        return dx, dg, db, None, None, None
+
+
+class FcosHeadOutFn(torch.autograd.Function):
+    """Head epilogue of one pyramid level: fused-GEMM outputs [rows, wrows] f32 -> (logits [rows], reg [rows, D], ctr [rows])
+    with Scale / ReLU / stride (reference fcos.py:104-128)."""
+
+    @staticmethod
+    def forward(ctx, cls_out, box_out, scale, stride_mul, norm_reg, reg_dim, ctr_on_reg):
+        _chk(cls_out, box_out)
+        wrows = cls_out.shape[-1]
+        rows = cls_out.numel() // wrows
+        sc = scale.detach().float().contiguous()
+        dev = cls_out.device
+        logits = torch.empty(rows, dtype=torch.float32, device=dev)
+        reg = torch.empty((rows, reg_dim), dtype=torch.float32, device=dev)
+        ctr = torch.empty(rows, dtype=torch.float32, device=dev)
+        call("fcos_head_out_f32", _p(cls_out), _p(box_out), wrows, _p(sc), float(stride_mul), int(norm_reg), reg_dim, int(ctr_on_reg), rows,
+             _p(logits), _p(reg), _p(ctr), _s())
+        ctx.save_for_backward(box_out, sc)
+        ctx.meta = (wrows, rows, float(stride_mul), int(norm_reg), reg_dim, int(ctr_on_reg), cls_out.shape)
+        return logits, reg, ctr
+
+    @staticmethod
+    def backward(ctx, d_logits, d_reg, d_ctr):
+        box_out, sc = ctx.saved_tensors
+        wrows, rows, stride_mul, norm_reg, reg_dim, ctr_on_reg, shape = ctx.meta
+        d_cls = torch.empty(shape, dtype=torch.float32, device=box_out.device)
+        d_box = torch.empty(shape, dtype=torch.float32, device=box_out.device)
+        d_scale = torch.zeros(1, dtype=torch.float32, device=box_out.device)
+        dl = d_logits.contiguous() if d_logits is not None else None
+        dr = d_reg.contiguous() if d_reg is not None else None
+        dc = d_ctr.contiguous() if d_ctr is not None else None
+        call("fcos_head_out_bwd_f32", _p(box_out), wrows, _p(sc), stride_mul, norm_reg, reg_dim, ctr_on_reg, rows, _p(dl), _p(dr), _p(dc),
+             _p(d_cls), _p(d_box), _p(d_scale), _s())
+        return d_cls, d_box, d_scale, None, None, None, None
+
+
+class FcosGeometry:
+    """Host description of the flattened FCOS location list (level-major, then scene, then voxel)."""
+
+    def __init__(self, n, dims, strides):
+        import ctypes
+        self.n, self.levels = int(n), len(dims)
+        self.dims = [tuple(int(v) for v in d) for d in dims]
+        self.strides = [int(s) for s in strides]
+        self.counts = [d[0] * d[1] * d[2] for d in self.dims]            # locations per scene per level
+        self.total = self.n * sum(self.counts)
+        self._dims = (ctypes.c_int32 * (3 * self.levels))(*[v for d in self.dims for v in d])
+        self._strides = (ctypes.c_int32 * self.levels)(*self.strides)
+        self.segment_offsets = [0]
+        for c in self.counts:
+            for _ in range(self.n):
+                self.segment_offsets.append(self.segment_offsets[-1] + c)
+
+    def args(self):
+        import ctypes
+        return self.n, self.levels, ctypes.addressof(self._dims), ctypes.addressof(self._strides)
+
+    @staticmethod
+    def sizes(ori_sizes):
+        import ctypes
+        if ori_sizes is None:
+            return None, 0
+        buf = (ctypes.c_float * (3 * len(ori_sizes)))(*[float(v) for s in ori_sizes for v in s])
+        return buf, ctypes.addressof(buf)
+
+
+def fcos_gt_summary(gt):
+    gt = _f32(gt).contiguous()
+    _chk(gt)
+    out = torch.empty((gt.shape[0], 8), dtype=torch.float32, device=gt.device)
+    if gt.shape[0]:
+        call("fcos_gt_summary_f32", _p(gt), gt.shape[0], gt.shape[1], _p(out), _s())
+    return out
+
+
+def fcos_targets(geom, targets, ori_sizes, radius, norm_reg, reg_dim, device):
+    """labels int8 [total] in {1,0,-1}, reg_targets f32 [total, reg_dim], num_pos int32 [1] (reference loss.py:270-437)."""
+    import ctypes
+    summ = [fcos_gt_summary(t) for t in targets]
+    offs = [0]
+    for t in targets:
+        offs.append(offs[-1] + t.shape[0])
+    summary = torch.cat(summ) if offs[-1] else None
+    host = (ctypes.c_int32 * len(offs))(*offs)
+    labels = torch.empty(geom.total, dtype=torch.int8, device=device)
+    reg_t = torch.empty((geom.total, reg_dim), dtype=torch.float32, device=device)
+    npos = torch.empty(1, dtype=torch.int32, device=device)
+    keep, sizes = FcosGeometry.sizes(ori_sizes)
+    n, levels, dims, strides = geom.args()
+    call("fcos_targets_f32", _p(summary), ctypes.addressof(host), n, levels, dims, strides, sizes, float(radius), int(norm_reg), reg_dim,
+         _p(labels), _p(reg_t), _p(npos), _s())
+    return labels, reg_t, npos
+
+
+class FocalLossFn(torch.autograd.Function):
+    """sum of sigmoid focal loss (alpha, gamma 2) over the locations with label >= 0; the gradient is produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, alpha):
+        logits = logits.contiguous()
+        _chk(logits, labels)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        grad = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        call("fcos_focal_f32", _p(logits), _p(labels), logits.numel(), float(alpha), _p(out), _p(grad), _s())
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def fcos_scores(geom, logits, ctr, ori_sizes, thresh):
+    _chk(logits, ctr)
+    scores = torch.empty(geom.total, dtype=torch.float32, device=logits.device)
+    keep, sizes = FcosGeometry.sizes(ori_sizes)
+    n, levels, dims, strides = geom.args()
+    call("fcos_scores_f32", _p(logits), _p(ctr), n, levels, dims, strides, sizes, float(thresh), _p(scores), _s())
+    return scores
+
+
+def fcos_decode(geom, idx, score, reg, ori_sizes, reg_dim, min_size):
+    """idx / score: [levels*n, k] from segmented_topk -> boxes [levels*n*k, 6|7], sqrt scores (-1 = dropped), levels (f32)."""
+    _chk(idx, score, reg)
+    count, k = idx.numel(), idx.shape[1]
+    w = 7 if reg_dim == 8 else 6
+    dev = reg.device
+    boxes = torch.empty((count, w), dtype=torch.float32, device=dev)
+    out_s = torch.empty(count, dtype=torch.float32, device=dev)
+    out_l = torch.empty(count, dtype=torch.float32, device=dev)
+    keep, sizes = FcosGeometry.sizes(ori_sizes)
+    n, levels, dims, strides = geom.args()
+    call("fcos_decode_f32", _p(idx), _p(score), count, k, _p(reg), n, levels, dims, strides, sizes, reg_dim, float(min_size), _p(boxes),
+         _p(out_s), _p(out_l), _s())
+    return boxes, out_s, out_l
+
+
 class _ToChannelsLast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dtype):

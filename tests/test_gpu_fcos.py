@@ -1,0 +1,203 @@
+"""GPU parity of the FCOS variant (csrc/fcos.hip + nerf_rpn_amd/model/fcos) against the oracle (oracle/fcos.py, pinned to the
+reference's model/fcos/*.py) on identical inputs, and end to end against golden vectors captured from the reference."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fixture_init import seeded_state
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-12)).item()
+
+
+def fcos_args(rot, **kw):
+    a = dict(num_convs=4, norm_reg_targets=True, centerness_on_reg=True, rotated_bbox=rot, pre_nms_thresh=0.0, pre_nms_top_n=2500,
+             nms_thresh=0.3, fpn_post_nms_top_n=2500, min_size=0.0, center_sampling_radius=1.5, iou_loss_type="iou",
+             use_additional_l1_loss=False, proj2d_loss_weight=0.0)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+def build(rot, backbone, dev, **kw):
+    from nerf_rpn_amd.model.feature_extractor import VGG_FPN, SwinTransformer_FPN
+    from nerf_rpn_amd.model.fcos import FCOSOverNeRF
+    if backbone == "swin":
+        bb = SwinTransformer_FPN(patch_size=[4, 4, 4], embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=[4, 4, 4],
+                                 stochastic_depth_prob=0, expand_dim=True)
+    else:
+        bb = VGG_FPN("EF", 4, True, 160)
+    seeded_state(bb, 1)
+    m = FCOSOverNeRF(fcos_args(rot, **kw), bb, [4, 8, 16, 32])
+    seeded_state(m.fcos_module.head, 2, bias_jitter=0.5)
+    for l, sc in enumerate(m.fcos_module.head.scales):
+        sc.scale.data.fill_(0.8 + 0.15 * l)
+    return m.to(dev)
+
+
+def scene(shape, seed):
+    return torch.rand(4, *[int(s) for s in shape], generator=torch.Generator().manual_seed(seed))
+
+
+def test_groupnorm_matches_torch(dev):
+    from nerf_rpn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for shape, groups, relu in [((2, 6, 5, 4, 256), 32, True), ((1, 9, 7, 3, 256), 32, False), ((3, 4, 4, 4, 64), 8, True)]:
+        x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dev).requires_grad_()
+        w = (torch.rand(shape[-1], generator=g) + 0.5).to(dev).requires_grad_()
+        b = (torch.randn(shape[-1], generator=g) * 0.3).to(dev).requires_grad_()
+        dy = torch.randn(shape, generator=g).to(dev)
+        y = ops.GroupNormFn.apply(x, w, b, groups, 1e-5, relu)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), dy)
+        yr = F.group_norm(x.permute(0, 4, 1, 2, 3), groups, w, b, 1e-5)
+        yr = (F.relu(yr) if relu else yr).permute(0, 2, 3, 4, 1)
+        rx, rw, rb = torch.autograd.grad(yr, (x, w, b), dy)
+        assert rel(y, yr) < 5e-6 and rel(gx, rx) < 2e-5 and rel(gw, rw) < 2e-5 and rel(gb, rb) < 2e-5, (shape, rel(y, yr), rel(gx, rx))
+
+
+@pytest.mark.parametrize("rot,ctr_on_reg,training", [(False, True, True), (True, True, False), (True, False, True)])
+def test_head_matches_oracle_on_identical_features(rot, ctr_on_reg, training, dev):
+    """FCOSHead forward + backward (towers, GroupNorm, fused final GEMMs, Scale / ReLU / stride epilogue) vs the oracle."""
+    from nerf_rpn_amd.model.fcos import FCOSHead
+    from oracle import fcos as OF
+    hd = FCOSHead(256, 4, [4, 8, 16, 32], True, ctr_on_reg, rot)
+    seeded_state(hd, 2, bias_jitter=0.5)
+    for l, sc in enumerate(hd.scales):
+        sc.scale.data.fill_(0.8 + 0.15 * l)
+    orc = OF.FCOSHead(256, 4, [4, 8, 16, 32], True, ctr_on_reg, rot)
+    orc.load_state_dict(hd.state_dict())
+    hd = hd.to(dev).train(training)
+    orc.train(training)
+    g = torch.Generator().manual_seed(3)
+    feats = [torch.randn(2, 256, *s, generator=g) for s in ((10, 8, 6), (5, 4, 3), (3, 2, 2), (2, 1, 1))]
+    fo = [f.clone().requires_grad_() for f in feats]
+    fg = [f.to(dev).requires_grad_() for f in feats]
+    oo, og = orc(fo), hd(fg)
+    flat_o = [t for grp in oo for t in grp]
+    flat_g = [t for grp in og for t in grp]
+    for a, r in zip(flat_g, flat_o):
+        assert a.shape == r.shape and rel(a, r) < 2e-5, (a.shape, rel(a, r))
+    dys = [torch.randn(t.shape, generator=g) * (torch.rand(t.shape, generator=g) < 0.2) for t in flat_o]
+    used_o = [p for n, p in orc.named_parameters() if "scales.4" not in n]
+    used_g = [p for n, p in hd.named_parameters() if "scales.4" not in n]
+    go = torch.autograd.grad(flat_o, fo + used_o, dys)
+    gg = torch.autograd.grad(flat_g, fg + used_g, [d.to(dev) for d in dys])
+    names = [f"feat{i}" for i in range(4)] + [n for n, _ in orc.named_parameters() if "scales.4" not in n]
+    for n, a, r in zip(names, gg, go):
+        assert rel(a, r) < 1e-4, (n, rel(a, r))
+
+
+@pytest.mark.parametrize("name", ["fcos_train_aabb_vgg", "fcos_train_aabb_giou_batch2", "fcos_train_obb_l1_proj"])
+def test_targets_match_reference(name, golden, dev):
+    """labels (exact) and regression targets of every location against the reference's prepare_targets."""
+    from nerf_rpn_amd import ops
+    g = golden(name)
+    rot = bool(g["rotated"])
+    shapes = [tuple(int(v) for v in s) for s in g["shapes"]]
+    big = [max(s[d] for s in shapes) for d in range(3)]
+    m = build(rot, "vgg", dev)
+    with torch.no_grad():
+        feats = m.backbone(torch.zeros(1, 4, *big, device=dev))
+    geom = ops.FcosGeometry(len(shapes), [f.shape[-3:] for f in feats], [4, 8, 16, 32])
+    gts = [T(g[f"gt{i}"], dev) for i in range(len(shapes))]
+    labels, reg_t, npos = ops.fcos_targets(geom, gts, shapes if len(shapes) > 1 else None, 1.5, True, 8 if rot else 6, dev)
+    keep = labels >= 0
+    assert torch.equal(labels[keep].cpu(), T(g["labels"]))
+    assert int(npos.item()) == int((T(g["labels"]) > 0).sum())
+    ref = T(g["reg_targets"])
+    pos = T(g["pos"])
+    got = reg_t[keep].cpu()
+    assert torch.allclose(got[pos], ref[pos], atol=2e-5, rtol=1e-5), (got[pos] - ref[pos]).abs().max()
+
+
+@pytest.mark.parametrize("name", ["fcos_eval_aabb_vgg", "fcos_eval_obb_swin", "fcos_eval_obb_batch2"])
+def test_eval_matches_reference(name, golden, dev):
+    g = golden(name)
+    rot = bool(g["rotated"])
+    m = build(rot, str(g["backbone"]), dev, pre_nms_top_n=int(g["pre_nms_top_n"]), fpn_post_nms_top_n=int(g["fpn_post_nms_top_n"])).eval()
+    xs = [scene(s, 300 + i).to(dev) for i, s in enumerate(g["shapes"])]
+    with torch.no_grad():
+        boxes, losses, scores = m(xs)
+    assert losses == {}
+    for i in range(len(xs)):
+        rp, rs = T(g[f"boxes{i}"]), T(g[f"scores{i}"])
+        gp, gs = boxes[i].cpu(), scores[i].cpu()
+        # Random-weight heads emit many zero distances after the ReLU, i.e. OBBs of width ~1e-6 whose IoU is 0/0-like: the
+        # reference's own NMS decisions on those flip between CPUs (the oracle run on the GPU box's host keeps 293 of scene 1
+        # in fcos_eval_obb_batch2, the build container 296).  Hence a small allowance on the count and on unmatched rows.
+        allow = max(5, rp.shape[0] // 50)
+        assert abs(gp.shape[0] - rp.shape[0]) <= allow, (name, gp.shape, rp.shape)
+        # score-descending lists; near-tied scores may swap and an IoU within 1e-6 of the NMS threshold may flip a decision
+        # (cf. test_gpu_e2e.py): match every reference row to a row of equal level / score / box.
+        near = (gs[None, :] - rs[:, None]).abs() <= 3e-6
+        diff = (gp[None, :, 1:] - rp[:, None, 1:]).abs()
+        tol = 3e-3 + 2e-4 * rp[:, 1:].abs()[:, None, :]
+        ok = ((diff <= tol).all(dim=2) & near & (gp[None, :, 0] == rp[:, None, 0])).any(dim=1)
+        assert (~ok).sum() <= allow, (name, i, int((~ok).sum()), rp.shape[0])
+
+
+@pytest.mark.parametrize("name", ["fcos_train_aabb_vgg", "fcos_train_aabb_giou_batch2", "fcos_train_obb_swin", "fcos_train_obb_l1_proj",
+                                  "fcos_train_obb_diou", "fcos_train_obb_smoothl1"])
+def test_train_matches_reference(name, golden, dev):
+    g = golden(name)
+    rot = bool(g["rotated"])
+    m = build(rot, str(g["backbone"]), dev, iou_loss_type=str(g["iou_loss_type"]), use_additional_l1_loss=bool(g["use_additional_l1_loss"]),
+              proj2d_loss_weight=float(g["proj2d_loss_weight"])).train()
+    xs = [scene(s, 400 + i).to(dev) for i, s in enumerate(g["shapes"])]
+    gts = [T(g[f"gt{i}"], dev) for i in range(len(xs))]
+    _, losses, _ = m(xs, gts)
+    aux = m.fcos_module.loss_evaluator.last_aux
+    assert torch.equal(aux["labels"][aux["labels"] >= 0].cpu(), T(g["labels"]))
+    for k in ("loss_cls", "loss_reg", "loss_centerness"):
+        ref = float(g[k])
+        assert abs(losses[k].item() - ref) < 2e-4 * max(1.0, abs(ref)), (name, k, losses[k].item(), ref)
+    (losses["loss_cls"] + losses["loss_reg"] + losses["loss_centerness"]).backward()
+    params = dict(m.backbone.named_parameters())
+    params.update({"head." + k: v for k, v in m.fcos_module.head.named_parameters()})
+    unused = set(str(g["unused"]).split(","))
+    flat_ref, flat_got = [], []
+    # same acceptance rule as tests/test_gpu_e2e.py::test_train_matches_reference: each tensor within max(10 % of its scale,
+    # 4 x the reference's own fp32 rounding error measured against float64) and the global direction within cos > 0.995
+    for k, p in params.items():
+        if k in unused:
+            continue
+        assert p.grad is not None, k
+        if "grad/" + k in g:
+            ref, got = T(g["grad/" + k]), p.grad.cpu()
+        else:
+            ref, got = T(g["gval/" + k]), p.grad.reshape(-1)[T(g["gidx/" + k], dev)].cpu()
+        scale = float(g["gmax64/" + k])
+        err = (got - ref).abs().max().item()
+        allowed = max(0.1 * scale, 4.0 * float(g["err32/" + k])) + 5e-5
+        assert err <= allowed, (name, k, err, allowed, scale)
+        if scale > 1e-6:
+            flat_ref.append(ref.reshape(-1) / scale)
+            flat_got.append(got.reshape(-1) / scale)
+    a, b = torch.cat(flat_ref).double(), torch.cat(flat_got).double()
+    assert (a @ b / (a.norm() * b.norm())).item() > 0.995, name
+
+
+def test_empty_targets_and_bf16(dev):
+    """a scene without GT (all-background focal loss, zero regression terms) and the bf16 compute path run and stay finite."""
+    m = build(True, "vgg", dev).train()
+    x = scene((48, 40, 32), 1).to(dev)
+    _, losses, _ = m([x], [torch.zeros(0, 7, device=dev)])
+    assert losses["loss_reg"].item() == 0 and losses["loss_centerness"].item() == 0 and losses["loss_cls"].item() > 0
+    sum(losses.values()).backward()
+    m.set_compute_dtype(torch.bfloat16)
+    gt = torch.tensor([[24., 20., 16., 20., 12., 10., 0.3]], device=dev)
+    _, l16, _ = m([x], [gt])
+    m.set_compute_dtype(torch.float32)
+    _, l32, _ = m([x], [gt])
+    for k in l32:
+        assert torch.isfinite(l16[k]) and abs(l16[k].item() - l32[k].item()) < 0.1 * max(1.0, abs(l32[k].item())), (k, l16[k], l32[k])
