@@ -359,11 +359,11 @@ def _make_logger(name, args, to_console=True):
     return logger
 
 
-def main_worker(proc, nprocs, args, gpu_ids, init_method):
+def main_worker(proc, nprocs, args, gpu_ids, init_method, trainer_cls=None):
     torch.cuda.set_device(gpu_ids[proc])
     dist.init_process_group(backend='nccl', init_method=init_method, world_size=nprocs, rank=proc,
                             device_id=torch.device('cuda', gpu_ids[proc]))
-    trainer = Trainer(args, proc, nprocs, gpu_ids[proc], _make_logger(f'worker_{proc}', args))
+    trainer = (trainer_cls or Trainer)(args, proc, nprocs, gpu_ids[proc], _make_logger(f'worker_{proc}', args))
     dist.barrier()
     if args.mode == 'train':
         trainer.train_loop()
@@ -381,19 +381,20 @@ def parse_gpu_ids(spec):
     return ids
 
 
-def main(argv=None):
-    args = parse_args(argv)
+def main(argv=None, trainer_cls=None, args=None):
+    trainer_cls = trainer_cls or Trainer
+    args = args if args is not None else parse_args(argv)
     logging.basicConfig(level=logging.INFO, format='[%(asctime)s %(levelname)s] %(message)s')
     gpu_ids = parse_gpu_ids(args.gpus)
     if len(gpu_ids) <= 1:
         if len(gpu_ids) == 1:
             torch.cuda.set_device(gpu_ids[0])
-        trainer = Trainer(args, logger=_make_logger('worker_0', args, to_console=False) if args.log_to_file else None)
+        trainer = trainer_cls(args, logger=_make_logger('worker_0', args, to_console=False) if args.log_to_file else None)
         {'train': trainer.train_loop, 'eval': lambda: trainer.eval(trainer.test_set), 'benchmark': trainer.benchmark}[args.mode]()
     else:
         init_method = f'tcp://127.0.0.1:{np.random.randint(20000, 40000)}'
         logging.info(f'Using {len(gpu_ids)} processes for data parallelism, GPUs: {gpu_ids}')
-        mp.spawn(main_worker, nprocs=len(gpu_ids), args=(len(gpu_ids), args, gpu_ids, init_method), join=True)
+        mp.spawn(main_worker, nprocs=len(gpu_ids), args=(len(gpu_ids), args, gpu_ids, init_method, trainer_cls), join=True)
 
 
 if __name__ == '__main__':

@@ -50,3 +50,53 @@ def test_command_line_train_eval_roundtrip(tmp_path, dev):
     assert set(z.files) == {"proposal", "score"} and z["proposal"].shape[1] == 7 and z["proposal"].dtype == np.float32
     js = json.load(open(tmp_path / "out" / "eval.json"))
     assert {"recall_50_top_300", "recall_25_top_300", "recall_ar_top_300", "ap_50", "ap_25"} <= set(js)
+
+
+def test_fcos_command_line_train_eval_roundtrip(tmp_path, dev):
+    """run_fcos.py drop-in: one epoch with the reference's train_fcos.sh flags (swin_t for speed), checkpoint keys, eval with
+    proposal files in the FCOS key layout (proposals / scores / level_indices) and eval.json."""
+    from nerf_rpn_amd.run_fcos import main
+    rng = np.random.default_rng(1)
+    f, b = tmp_path / "features", tmp_path / "boxes"
+    os.makedirs(f); os.makedirs(b)
+    for s in ("a", "b"):
+        np.savez(f / f"{s}.npz", rgbsigma=(rng.random((40, 32, 24, 4), dtype=np.float32) * 4 - 2))
+        np.save(b / f"{s}.npy", np.array([[14., 12, 10, 12, 8, 8, 0.2], [24, 18, 12, 14, 10, 8, -0.5]], dtype=np.float32))
+    split = tmp_path / "split.npz"
+    np.savez(split, train_scenes=np.array(["a", "b"]), val_scenes=np.array(["a"]), test_scenes=np.array(["a", "b"]))
+    common = ["--dataset", "front3d", "--features_path", str(f), "--boxes_path", str(b), "--dataset_split", str(split),
+              "--backbone_type", "swin_t", "--rotated_bbox", "--normalize_density", "--save_path", str(tmp_path / "out"),
+              "--norm_reg_targets", "--centerness_on_reg", "--nms_thresh", "0.3", "--pre_nms_top_n", "400", "--fpn_post_nms_top_n", "300"]
+    main(["--mode", "train", "--num_epochs", "1", "--batch_size", "2", "--lr", "3e-4", "--weight_decay", "1e-3", "--log_interval", "1",
+          "--center_sampling_radius", "1.5", "--iou_loss_type", "iou"] + common)
+    ck = torch.load(tmp_path / "out" / "model_best.pt", map_location="cpu")
+    assert set(ck) == {"epoch", "backbone_state_dict", "fcos_state_dict", "train_args"} and ck["epoch"] == 1
+    assert any(k.startswith("head.cls_tower.0.") for k in ck["fcos_state_dict"]) and "head.scales.4.scale" in ck["fcos_state_dict"]
+    main(["--mode", "eval", "--checkpoint", str(tmp_path / "out" / "model_best.pt"), "--output_proposals", "--save_level_index",
+          "--batch_size", "2"] + common)
+    z = np.load(tmp_path / "out" / "proposals" / "a.npz")
+    assert set(z.files) == {"proposals", "scores", "level_indices"} and z["proposals"].shape[1] == 7
+    assert z["proposals"].shape[0] == z["scores"].shape[0] == z["level_indices"].shape[0] <= 300
+    js = json.load(open(tmp_path / "out" / "eval.json"))
+    assert {"recall_50_top_300", "recall_25_top_300", "recall_ar_top_300", "ap_50", "ap_25"} <= set(js)
+
+
+def test_rpn_command_line_with_swin_backbone(tmp_path, dev):
+    """run_rpn.py with --backbone_type swin_t (train.sh uses swin_s): one training epoch incl. stochastic depth + eval."""
+    from nerf_rpn_amd.run_rpn import main
+    rng = np.random.default_rng(2)
+    f, b = tmp_path / "features", tmp_path / "boxes"
+    os.makedirs(f); os.makedirs(b)
+    for s in ("a", "b"):
+        np.savez(f / f"{s}.npz", rgbsigma=(rng.random((40, 32, 24, 4), dtype=np.float32) * 4 - 2))
+        np.save(b / f"{s}.npy", np.array([[14., 12, 10, 12, 8, 8, 0.2], [24, 18, 12, 14, 10, 8, -0.5]], dtype=np.float32))
+    split = tmp_path / "split.npz"
+    np.savez(split, train_scenes=np.array(["a", "b"]), val_scenes=np.array(["a"]), test_scenes=np.array(["a", "b"]))
+    common = ["--dataset_name", "front3d", "--features_path", str(f), "--boxes_path", str(b), "--dataset_split", str(split),
+              "--backbone_type", "swin_t", "--rotated_bbox", "--save_path", str(tmp_path / "out"),
+              "--rpn_pre_nms_top_n_test", "500", "--rpn_post_nms_top_n_test", "300"]
+    main(["--mode", "train", "--num_epochs", "2", "--batch_size", "1", "--log_interval", "1"] + common)
+    ck = torch.load(tmp_path / "out" / "model_best.pt", map_location="cpu")
+    assert "stages.2.1.attn.relative_position_index" in ck["backbone_state_dict"]
+    main(["--mode", "eval", "--checkpoint", str(tmp_path / "out" / "model_best.pt"), "--output_proposals"] + common)
+    assert np.load(tmp_path / "out" / "proposals" / "b.npz")["proposal"].shape[1] == 7
