@@ -38,11 +38,31 @@ def synthetic_scene(seed, device):
     return x.to(device), torch.cat([ctr, size, theta], dim=1).to(device)
 
 
-def build_model(dtype, device):
-    from nerf_rpn_amd import ops
-    from nerf_rpn_amd.model import VGG_FPN, RPNHead, NeRFRegionProposalNetwork, AnchorGenerator3D
+def build_backbone(kind):
+    from nerf_rpn_amd.model import VGG_FPN, ResNet_FPN_256, Bottleneck, SwinTransformer_FPN
+    if kind == "vgg":
+        return VGG_FPN("EF", 4, True, GRID)
+    if kind == "resnet":
+        return ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True)
+    return SwinTransformer_FPN(patch_size=[4, 4, 4], embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=[4, 4, 4],
+                               stochastic_depth_prob=0.1 if kind == "swin" else 0.0, expand_dim=True)
+
+
+def build_fcos(dtype, device, backbone):
+    """Secondary workload (not the BASELINE metric): train_fcos.sh configuration, Swin-S + FCOS head, OBB."""
+    from nerf_rpn_amd.model.fcos import FCOSOverNeRF
     torch.manual_seed(0)
-    bb = VGG_FPN("EF", 4, True, GRID)
+    a = argparse.Namespace(num_convs=4, norm_reg_targets=True, centerness_on_reg=True, rotated_bbox=True, pre_nms_thresh=0.0,
+                           pre_nms_top_n=2500, nms_thresh=0.3, fpn_post_nms_top_n=2500, min_size=0.0, center_sampling_radius=1.5,
+                           iou_loss_type="iou", use_additional_l1_loss=False, proj2d_loss_weight=0.0)
+    return FCOSOverNeRF(a, build_backbone(backbone), [4, 8, 16, 32], compute_dtype=dtype).to(device).train()
+
+
+def build_model(dtype, device, backbone="vgg"):
+    from nerf_rpn_amd import ops
+    from nerf_rpn_amd.model import RPNHead, NeRFRegionProposalNetwork, AnchorGenerator3D
+    torch.manual_seed(0)
+    bb = build_backbone(backbone)
     hd = RPNHead(256, 13, 4, rotate=True)
     model = NeRFRegionProposalNetwork(bb, AnchorGenerator3D(ops.ANCHOR_SIZES, ops.ASPECT_RATIOS), hd, rpn_pre_nms_top_n_train=2500,
                                       rpn_pre_nms_top_n_test=2500, rpn_post_nms_top_n_train=2500, rpn_post_nms_top_n_test=2500,
@@ -145,6 +165,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="disable per-launch HIP-event timing of the conv kernels")
+    ap.add_argument("--model", default="vgg_rpn", choices=["vgg_rpn", "resnet_rpn", "swin_rpn", "swin_fcos", "vgg_fcos"],
+                    help="vgg_rpn = the BASELINE.json metric (default); the others are secondary workloads for profiling")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,7 +182,9 @@ def main():
     lib.call("check_device", local)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = build_model(dtype, dev)
+    backbone, head = args.model.split("_")
+    fcos = head == "fcos"
+    model = build_fcos(dtype, dev, "swin0" if backbone == "swin" else backbone) if fcos else build_model(dtype, dev, backbone)
     trainer = FlatTrainer(model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, total_steps=args.steps + args.warmup + 1)
     x, gt = synthetic_scene(rank, dev)
     probe = ConvProbe()
@@ -169,7 +193,10 @@ def main():
 
     def step():
         _, losses, _ = model([x], [gt])
-        loss = losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"] + 0.0 * losses["loss_rpn_box_reg_2d"]
+        if fcos:
+            loss = losses["loss_cls"] + losses["loss_reg"] + losses["loss_centerness"]
+        else:
+            loss = losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"] + 0.0 * losses["loss_rpn_box_reg_2d"]
         loss.backward()
         trainer.step()
         return loss
@@ -209,7 +236,10 @@ def main():
             "final_loss": round(final_loss, 5),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.model != "vgg_rpn":
+            out["metric"] = f"scenes/sec (160^3x4 grids, {args.model} fwd+bwd) -- secondary workload, not the BASELINE metric"
+            out["config"]["workload"] = f"{args.model}: one 160x160x160x4 grid per GPU, 16 OBB GT boxes, fwd+bwd+clip+AdamW, random-init weights"
+        if world == 1 and not args.no_cpu_baseline and args.model == "vgg_rpn":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
