@@ -124,7 +124,13 @@ class ConvProbe:
         peak = MFMA_PEAK_TFLOPS[dtype_name]
         total_ms = sum(v[1] for _, v in rows)
         total_fl = sum(v[0] * v[2] for _, v in rows)
-        kernel = "conv_igemm_kernel" if name == "conv3d_fwd" else "conv_wgrad_kernel"
+        vox, cin_, cout_, _k = shape
+        if name == "conv3d_fwd":     # tile selection of launch_conv (csrc/conv3d.hip)
+            big = cout_ >= 256 and -(-vox // 256) * -(-cout_ // 256) >= 200
+            ws_ = not big and cout_ > 64 and -(-vox // 256) * -(-cout_ // 128) >= 240
+            kernel = "conv_igemm_big_kernel" if big else ("conv_igemm_ws_kernel" if ws_ else "conv_igemm_kernel")
+        else:
+            kernel = "conv_wgrad_big_kernel" if (cin_ >= 256 and cout_ >= 256) else "conv_wgrad_kernel"
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_256x256_40c.json")
         if os.path.exists(pmc) and shape == (64000, 256, 256, 3):

@@ -175,17 +175,21 @@ int nrpn_rpn_sampled_loss_f32(const float *logits, const float *deltas, int dw, 
 enum { NRPN_CONV_BIAS = 1, NRPN_CONV_RELU = 2, NRPN_CONV_OUT_F32 = 4 };
 int nrpn_pack_conv_weight(const float *w_ref, int cout, int cin, int taps, int dtype, void *wp_fwd, void *wp_dgrad,
                           int rows_total, int row_offset, nrpn_stream_t stream);
-/* packed fp32 weight gradient [taps][rows_total][Cin] -> reference layout (optionally accumulating into gw_ref) */
+/* packed fp32 partial weight gradients [slices][taps][rows_total][Cin] (output of nrpn_conv3d_wgrad) -> sum over the
+ * slices in the reference layout [cout][Cin][taps] (optionally accumulating into gw_ref, e.g. a flat-arena slot) */
 int nrpn_unpack_conv_wgrad(const float *gw_packed, int cout, int cin, int taps, int rows_total, int row_offset,
-                           float *gw_ref, int accumulate, nrpn_stream_t stream);
+                           float *gw_ref, int accumulate, int slices, nrpn_stream_t stream);
 /* `workspace` (nrpn_conv3d_fwd_workspace_bytes; may be NULL = never split): for small grids the K loop is split over
  * blockIdx.z and fp32 partials are reduced through it so the 10^3 / 5^3 pyramid levels still fill 256 CUs. */
 size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
 int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
                     int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream);
-/* wgrad: gw_packed f32 [taps][wrows][Cin] (zero-filled by the call, split-K partials are atomically added);
+/* wgrad: the voxel axis is cut into S = nrpn_conv3d_wgrad_slices(...) slices; every (tile, tap, slice) workgroup writes
+ * its partial with plain stores into gw_packed f32 [S][taps][wrows][Cin] (fully overwritten: no memset, no atomics --
+ * cross-XCD fp32 atomics were ~1/3 of the kernel time); nrpn_unpack_conv_wgrad sums the slices.
  * optional gbias f32 [Cout] = column sums of dy. */
 size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int ksize);
+int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 /* accumulate_bias != 0: the column sums are ADDED to gbias (e.g. a slot of a flat gradient arena) instead of overwriting. */
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
                       int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
@@ -194,6 +198,11 @@ int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gb
 int nrpn_set_conv_kstep_bytes(int kb);
 /* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */
 int nrpn_set_conv_lds_dma(int on);
+/* tuning knob: tile of the bf16 k1/k3 LDS-DMA kernel -- 0 = per shape, 128 = 128x128 (two workgroups per CU), 256 = wave-specialised
+ * 256x128 (4 MFMA + 4 LDS-DMA waves), 512 = 256x256 with 8 waves (default for Cout >= 256 when it yields >= 200 workgroups) */
+int nrpn_set_conv_tile_m(int bm);
+/* tuning knob: 1 (default) = 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256; 0 = always the 128x128 kernel */
+int nrpn_set_wgrad_big_tile(int on);
 int nrpn_colsum(const void *dy, long long rows, int c, int dtype, float *out, nrpn_stream_t stream);
 /* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
 int nrpn_set_wgrad_transpose_read(int on);
@@ -202,7 +211,10 @@ int nrpn_set_wgrad_transpose_read(int on);
  * Output grid: (X - 1)/stride + 1 per axis. */
 int nrpn_stem_kpad(int dtype);
 int nrpn_pack_stem_weight(const float *w_ref, int cout, int dtype, void *wp, nrpn_stream_t stream);
-int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *gw_ref, int accumulate, nrpn_stream_t stream);
+/* stem wgrad writes S = nrpn_stem_wgrad_slices(...) partials [S][Cout][Kpad]; the unpack sums them */
+int nrpn_stem_wgrad_slices(int n, int gx, int gy, int gz, int cout, int stride, int dtype);
+int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *gw_ref, int accumulate, int slices,
+                           nrpn_stream_t stream);
 int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz,
                          int cout, int stride, int dtype, int flags, nrpn_stream_t stream);
 int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,

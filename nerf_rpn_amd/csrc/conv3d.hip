@@ -89,12 +89,11 @@ struct ConvArgs {
   float *ws;          // [M][Cout] fp32, zero-filled by the launcher (split-K only)
 };
 
-template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS>
-__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
-  constexpr int BM = 128;
+template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128>
+__global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(const ConvArgs p) {
   constexpr int WAVES_N = (BN == 128) ? 2 : 1;
-  constexpr int TM = (BN == 128) ? 2 : 1;   // 32x32 tiles per wave along M
-  constexpr int TN = 2;                      // ... along N
+  constexpr int TM = BM / (32 * (4 / WAVES_N));   // 32x32 tiles per wave along M: 1, 2 or (BM 256) 4
+  constexpr int TN = 2;                            // ... along N
   constexpr int KE = KB / (int)sizeof(T);    // K elements per step
   constexpr int PPR = KB / 16;               // 16-byte pieces per tile row (4 or 8)
   constexpr int RSTEP = 256 / PPR;           // row distance between a thread's pieces
@@ -102,7 +101,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
   constexpr int B_RPT = BN / RSTEP;          // B rows per thread (1, 2 or 4)
   constexpr int SWZ_SH = (KB == 64) ? 2 : 1; // rows per 256-byte LDS bank row = 256 / KB
   constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB;
-  __shared__ __attribute__((aligned(16))) char lds[2 * (A_BYTES + B_BYTES)];
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 * (A_BYTES + B_BYTES), sized by the launcher
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -380,6 +379,361 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant for the heavy bf16 shapes (k1 / k3, Cin*2 % 128 == 0, enough 256x128 tiles to fill the chip).
+// 512 threads = 8 waves, two per SIMD: waves 0-3 are CONSUMERS (each owns a 128x64 block of the 256x128 tile: 8 accumulators,
+// 6 ds_read_b128 per 8 MFMAs) and never touch global memory; waves 4-7 are PRODUCERS that only issue the LDS-DMA pieces of the
+// next K-step (12 per wave per step) -- the ~100-cycle issue cost of a `buffer_load ... lds` no longer sits in the MFMA wave's
+// instruction stream, and the bigger per-wave block cuts LDS reads and DMA pieces per MFMA by 25 %.  Three LDS buffers (144 KB), one barrier per
+// K-step, DMA issued two steps ahead.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool OUTF32>
+__global__ void __launch_bounds__(512, 1) conv_igemm_ws_kernel(const ConvArgs p) {
+  typedef bf16s T;
+  constexpr int BM = 256, BN = 128, KB = 128, KE = 64, PPR = 8, RSTEP = 32, TM = 4, TN = 2;
+  constexpr int A_RPT = BM / RSTEP, B_RPT = BN / RSTEP;    // 8 + 4 DMA pieces per producer lane per K-step
+  constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const unsigned ntiles = (p.Cout + BN - 1) / BN;
+  const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * ntiles;
+  const unsigned tile = xcd_remap(blockIdx.x, tiles);
+  const long long m0 = (long long)(tile / ntiles) * BM;
+  const int n0 = (int)(tile % ntiles) * BN;
+  const int cpt = p.Cin / KE;
+  const int nk = p.taps * cpt;
+
+  if (producer) {
+    const int ptid = tid - 256, lr = ptid / PPR, ls = ptid % PPR;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave - 4);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    unsigned a_voff[A_RPT], a_mask[A_RPT], b_voff[B_RPT];
+#pragma unroll
+    for (int i = 0; i < A_RPT; ++i) {
+      const int r = lr + RSTEP * i;
+      const long long v = m0 + r;
+      const bool ok = v < p.M;
+      const long long vv = ok ? v : 0;
+      const int oz = (int)(vv % p.OZ);
+      const long long t1 = vv / p.OZ;
+      const int oy = (int)(t1 % p.OY);
+      const int ox = (int)((t1 / p.OY) % p.OX);
+      unsigned m = 0;
+      if (ok) {
+        if (p.taps == 27) {
+#pragma unroll
+          for (int t = 0; t < 27; ++t) {
+            const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
+            const bool in = (unsigned)(ox + dx) < (unsigned)p.X && (unsigned)(oy + dy) < (unsigned)p.Y && (unsigned)(oz + dz) < (unsigned)p.Z;
+            m |= in ? (1u << t) : 0u;
+          }
+        } else {
+          m = 1u;
+        }
+      }
+      a_mask[i] = m;
+      a_voff[i] = (unsigned)(vv * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4);    // inverse-swizzled source slot
+    }
+#pragma unroll
+    for (int i = 0; i < B_RPT; ++i) {
+      const int r = lr + RSTEP * i, row = n0 + r;
+      b_voff[i] = row < p.wrows ? (unsigned)((long long)row * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4) : kOOB;
+    }
+    int l_tap = 0, l_chunk = 0, l_dx = 0, l_dy = 0, l_dz = 0;
+    if (p.taps == 27) { l_dx = -1; l_dy = -1; l_dz = -1; }
+    const long long w_tap_stride = (long long)p.wrows * p.Cin;
+    auto issue = [&](int buf) {
+      char *A = lds + buf * (A_BYTES + B_BYTES);
+      char *B = A + A_BYTES;
+      const int c0 = l_chunk * KE;
+      const unsigned shift = (unsigned)((((l_dx * p.Y + l_dy) * p.Z + l_dz) * p.Cin + c0) * 2);
+      const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * 2);
+#pragma unroll
+      for (int i = 0; i < A_RPT; ++i)
+        lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB, ((a_mask[i] >> l_tap) & 1u) ? a_voff[i] + shift : kOOB);
+#pragma unroll
+      for (int i = 0; i < B_RPT; ++i) lds_dma16(wr, B + (wave_u * (64 / PPR) + RSTEP * i) * KB, b_voff[i] + wshift);
+      if (++l_chunk == cpt) {
+        l_chunk = 0;
+        ++l_tap;
+        if (++l_dz > 1) { l_dz = -1; if (++l_dy > 1) { l_dy = -1; ++l_dx; } }
+      }
+    };
+    // 3-stage pipeline: the DMA of step k+2 is issued while the consumers multiply step k; the wait before each barrier only
+    // covers step k+1 (s_waitcnt vmcnt(12) leaves the 12 newest pieces in flight), so a tile has two full steps to land.
+    issue(0);
+    if (nk > 1) { issue(1); asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    int nb = 2;
+    for (int ks = 0; ks < nk; ++ks) {
+      if (ks + 2 < nk) {
+        issue(nb);
+        nb = nb == 2 ? 0 : nb + 1;
+        asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    return;
+  }
+
+  // ---- consumers
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fk = lane >> 5;
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // fragment addresses inside a buffer (loop invariant); sub-step s toggles the 16-byte slot by XOR
+  int a_row[TM], b_row[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_row[i] = (wm * TM + i) * 32 + fr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_row[j] = (wn * TN + j) * 32 + fr;
+  auto load_frags = [&](const char *A, const char *B, int s, f4 (&af)[TM], f4 (&bfv)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfv[j] = *reinterpret_cast<const f4 *>(B + b_row[j] * KB + (((s * 2 + fk) ^ ((b_row[j] >> 1) & (PPR - 1))) << 4));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f4 *>(A + a_row[i] * KB + (((s * 2 + fk) ^ ((a_row[i] >> 1) & (PPR - 1))) << 4));
+  };
+  // register double-buffered fragments: the ds_reads of sub-step s+1 are in flight under the 8 MFMAs of sub-step s
+  auto compute = [&](int buf) {
+    const char *A = lds + buf * (A_BYTES + B_BYTES);
+    const char *B = A + A_BYTES;
+    f4 af[2][TM], bfv[2][TN];
+    load_frags(A, B, 0, af[0], bfv[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+    for (int s = 0; s < KB / 32; ++s) {
+      if (s + 1 < KB / 32) load_frags(A, B, s + 1, af[(s + 1) & 1], bfv[(s + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[s & 1][i], bfv[s & 1][j]);
+      // pin the interleave: one ds_read of sub-step s+1 behind each of the first six MFMAs of sub-step s
+      if (s + 1 < KB / 32) {
+#pragma unroll
+        for (int q = 0; q < TM + TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      }
+    }
+  };
+  asm volatile("s_barrier" ::: "memory");
+  int cb = 0;
+#pragma unroll 1
+  for (int ks = 0; ks < nk; ++ks) {
+    compute(cb);
+    cb = cb == 2 ? 0 : cb + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  const bool has_bias = (p.flags & NRPN_CONV_BIAS) && p.bias;
+  const bool relu = p.flags & NRPN_CONV_RELU;
+  int elane = lane;
+  asm volatile("" : "+v"(elane));     // opaque copy: keeps the 128 output addresses from being hoisted above the K loop (spills)
+  const int efr = elane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + efr;
+    if (col >= p.Cout) continue;
+    const float bv = has_bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
+        if (v < p.M) {
+          float o = acc[i][j][r] + bv;
+          if (relu) o = fmaxf(o, 0.f);
+          if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
+          else elem<T>::st(reinterpret_cast<T *>(p.y) + v * p.Cout + col, o);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4, each 128x64), every wave loads and multiplies.  Per MFMA this halves both the bytes pulled
+// through the CU's vector-memory path (64 KB per 2048 MFMA cycles: the 128x128 tile needs 32 KB per 512 and saturates the
+// 64 B/clk L1 path) and the number of LDS-DMA issues (8 pieces per 32 MFMAs per wave).  Two LDS buffers of 64 KB.
+// Used when Cout >= 256 and the 256x256 tiling still yields ~one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool OUTF32>
+__global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p) {
+  typedef bf16s T;
+  constexpr int BM = 256, BN = 256, KB = 128, KE = 64, PPR = 8, RSTEP = 64, TM = 4, TN = 2;
+  constexpr int A_RPT = BM / RSTEP, B_RPT = BN / RSTEP;    // 4 + 4 DMA pieces per lane per K-step
+  constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned ntiles = (p.Cout + BN - 1) / BN;
+  const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * ntiles;
+  const unsigned tile = xcd_remap(blockIdx.x, tiles);
+  const long long m0 = (long long)(tile / ntiles) * BM;
+  const int n0 = (int)(tile % ntiles) * BN;
+  const int cpt = p.Cin / KE;
+  const int nk = p.taps * cpt;
+
+  const int lr = tid / PPR, ls = tid % PPR;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+  unsigned a_voff[A_RPT], a_mask[A_RPT], b_voff[B_RPT];
+#pragma unroll
+  for (int i = 0; i < A_RPT; ++i) {
+    const int r = lr + RSTEP * i;
+    const long long v = m0 + r;
+    const bool ok = v < p.M;
+    const long long vv = ok ? v : 0;
+    const int oz = (int)(vv % p.OZ);
+    const long long t1 = vv / p.OZ;
+    const int oy = (int)(t1 % p.OY);
+    const int ox = (int)((t1 / p.OY) % p.OX);
+    unsigned m = 0;
+    if (ok) {
+      if (p.taps == 27) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
+          const bool in = (unsigned)(ox + dx) < (unsigned)p.X && (unsigned)(oy + dy) < (unsigned)p.Y && (unsigned)(oz + dz) < (unsigned)p.Z;
+          m |= in ? (1u << t) : 0u;
+        }
+      } else {
+        m = 1u;
+      }
+    }
+    a_mask[i] = m;
+    a_voff[i] = (unsigned)(vv * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < B_RPT; ++i) {
+    const int r = lr + RSTEP * i, row = n0 + r;
+    b_voff[i] = row < p.wrows ? (unsigned)((long long)row * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4) : kOOB;
+  }
+  int l_tap = 0, l_chunk = 0, l_dx = 0, l_dy = 0, l_dz = 0;
+  if (p.taps == 27) { l_dx = -1; l_dy = -1; l_dz = -1; }
+  const long long w_tap_stride = (long long)p.wrows * p.Cin;
+  // branch-free: past the last K-step (`live` false) every lane reads out of range, i.e. deposits zeros in the idle buffer
+  auto issue = [&](int buf, bool live) {
+    char *A = lds + buf * (A_BYTES + B_BYTES);
+    char *B = A + A_BYTES;
+    const int c0 = l_chunk * KE;
+    const unsigned shift = (unsigned)((((l_dx * p.Y + l_dy) * p.Z + l_dz) * p.Cin + c0) * 2);
+    const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * 2);
+    const unsigned tapbit = live ? (1u << l_tap) : 0u;
+#pragma unroll
+    for (int i = 0; i < A_RPT; ++i)
+      lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB, (a_mask[i] & tapbit) ? a_voff[i] + shift : kOOB);
+#pragma unroll
+    for (int i = 0; i < B_RPT; ++i) lds_dma16(wr, B + (wave_u * (64 / PPR) + RSTEP * i) * KB, live ? b_voff[i] + wshift : kOOB);
+    if (++l_chunk == cpt) {
+      l_chunk = 0;
+      ++l_tap;
+      if (++l_dz > 1) { l_dz = -1; if (++l_dy > 1) { l_dy = -1; ++l_dx; } }
+    }
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fk = lane >> 5;
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int a_row[TM], b_row[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_row[i] = (wm * TM + i) * 32 + fr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_row[j] = (wn * TN + j) * 32 + fr;
+  auto load_frags = [&](const char *A, const char *B, int s, f4 (&af)[TM], f4 (&bfv)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfv[j] = *reinterpret_cast<const f4 *>(B + b_row[j] * KB + (((s * 2 + fk) ^ ((b_row[j] >> 1) & (PPR - 1))) << 4));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f4 *>(A + a_row[i] * KB + (((s * 2 + fk) ^ ((a_row[i] >> 1) & (PPR - 1))) << 4));
+  };
+  // one K-step: the 8 LDS-DMA pieces of the NEXT step are issued one behind each MFMA of sub-step 0 (an LDS-DMA issue
+  // costs ~60 cycles among bare MFMAs but >100 in a burst), the ds_reads of sub-step s+1 behind the MFMAs of sub-step s
+  auto compute = [&](int buf, bool next_live) {
+    const char *A = lds + buf * (A_BYTES + B_BYTES);
+    const char *B = A + A_BYTES;
+    f4 af[2][TM], bfv[2][TN];
+    load_frags(A, B, 0, af[0], bfv[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+    issue(buf ^ 1, next_live);
+#pragma unroll
+    for (int s = 0; s < KB / 32; ++s) {
+      if (s + 1 < KB / 32) load_frags(A, B, s + 1, af[(s + 1) & 1], bfv[(s + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[s & 1][i], bfv[s & 1][j]);
+      if (s == 0) {
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          if (q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      } else if (s + 1 < KB / 32) {
+#pragma unroll
+        for (int q = 0; q < TM + TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      }
+    }
+  };
+
+  issue(0, true);
+  __syncthreads();
+#pragma unroll 1
+  for (int ks = 0; ks < nk; ++ks) {
+    compute(ks & 1, ks + 1 < nk);
+    __syncthreads();
+  }
+
+  const bool has_bias = (p.flags & NRPN_CONV_BIAS) && p.bias;
+  const bool relu = p.flags & NRPN_CONV_RELU;
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+  const int efr = elane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + efr;
+    if (col >= p.Cout) continue;
+    const float bv = has_bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
+        if (v < p.M) {
+          float o = acc[i][j][r] + bv;
+          if (relu) o = fmaxf(o, 0.f);
+          if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
+          else elem<T>::st(reinterpret_cast<T *>(p.y) + v * p.Cout + col, o);
+        }
+      }
+    }
+  }
+}
+
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
                                        int cout, int relu) {
@@ -414,23 +768,70 @@ extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
   return NRPN_OK;
 }
 
+static int g_conv_bm = 0;     // 0: choose per shape; 128 / 256: force the M tile (tuning knob, tools/bench_conv.py)
+extern "C" int nrpn_set_conv_tile_m(int bm) {
+  if (bm != 0 && bm != 128 && bm != 256 && bm != 512)
+    return nrpn_fail(NRPN_ERR_ARG, "conv tile selector must be 0 (auto), 128 (128x128), 256 (wave-specialised 256x128) or 512 (256x256)");
+  g_conv_bm = bm;
+  return NRPN_OK;
+}
+
+template <typename K>
+static int launch_igemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const ConvArgs &a) {
+  if (lds > 64 * 1024) NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
+  return NRPN_OK;
+}
+
 template <typename T, int MODE>
 static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const int bn = (a.Cout <= 64) ? 64 : 128;
-  dim3 grid((unsigned)(cdiv64(a.M, 128) * ((a.Cout + bn - 1) / bn) * (a.ksplit > 1 ? a.ksplit : 1)));
   constexpr bool kDma = (MODE == 0);
   // the 128-byte K-step needs Cin*elemsize % 128 == 0; the stem gather keeps the 64-byte step
   const bool wide = MODE == 0 && g_conv_kb == 128 && (a.Cin * (int)sizeof(T)) % 128 == 0;
-#define NRPN_LC(BN_, OF_, KB_)                                                                                                  \
-  do {                                                                                                                         \
-    if (kDma && g_conv_glds) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_, KB_, kDma>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, MODE, OF_, KB_, false>), grid, dim3(256), 0, st, a);                    \
+  // 256-row M tiles (each wave owns 128x64: fewer LDS reads and DMA pieces per MFMA) when they still fill the chip
+  const long long tiles256 = cdiv64(a.M, 256) * ((a.Cout + bn - 1) / bn);
+  const bool can = kDma && g_conv_glds && wide && bn == 128 && a.ksplit <= 1 && sizeof(T) == 2;
+  const long long tiles_big = cdiv64(a.M, 256) * ((a.Cout + 255) / 256);
+  const bool huge = can && a.Cout >= 256 && (g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
+  const bool big = can && !huge && (g_conv_bm == 256 || (g_conv_bm == 0 && tiles256 >= 240));
+  const int bm = (big || huge) ? 256 : 128;
+  dim3 grid((unsigned)(cdiv64(a.M, bm) * ((a.Cout + (huge ? 256 : bn) - 1) / (huge ? 256 : bn)) * (a.ksplit > 1 ? a.ksplit : 1)));
+  int rc = 0;
+#define NRPN_LC(BN_, OF_, KB_)                                                                                                    \
+  do {                                                                                                                           \
+    const size_t lds_ = 2 * (size_t)(128 + BN_) * KB_;                                                                           \
+    if (kDma && g_conv_glds) rc = launch_igemm(conv_igemm_kernel<T, BN_, MODE, OF_, KB_, kDma>, grid, lds_, st, a);              \
+    else rc = launch_igemm(conv_igemm_kernel<T, BN_, MODE, OF_, KB_, false>, grid, lds_, st, a);                                 \
   } while (0)
 #define NRPN_LC2(BN_, OF_) do { if (wide) NRPN_LC(BN_, OF_, 128); else NRPN_LC(BN_, OF_, 64); } while (0)
-  if (bn == 64) { if (out_f32) NRPN_LC2(64, true); else NRPN_LC2(64, false); }
+  if (huge) {
+    if constexpr (MODE == 0 && sizeof(T) == 2) {
+      const size_t lds_ = 2 * (size_t)(256 + 256) * 128;
+      if (out_f32) {
+        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        hipLaunchKernelGGL(conv_igemm_big_kernel<true>, grid, dim3(512), lds_, st, a);
+      } else {
+        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        hipLaunchKernelGGL(conv_igemm_big_kernel<false>, grid, dim3(512), lds_, st, a);
+      }
+    }
+  } else if (big) {
+    if constexpr (MODE == 0 && sizeof(T) == 2) {
+      const size_t lds_ = 3 * (size_t)(256 + 128) * 128;
+      if (out_f32) {
+        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        hipLaunchKernelGGL(conv_igemm_ws_kernel<true>, grid, dim3(512), lds_, st, a);
+      } else {
+        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        hipLaunchKernelGGL(conv_igemm_ws_kernel<false>, grid, dim3(512), lds_, st, a);
+      }
+    }
+  } else if (bn == 64) { if (out_f32) NRPN_LC2(64, true); else NRPN_LC2(64, false); }
   else { if (out_f32) NRPN_LC2(128, true); else NRPN_LC2(128, false); }
 #undef NRPN_LC2
 #undef NRPN_LC
+  if (rc) return rc;
   NRPN_LAUNCH_CHECK("conv_igemm");
   return NRPN_OK;
 }
@@ -510,7 +911,7 @@ extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *
 struct WgradArgs {
   const void *x;
   const void *dy;
-  float *gw;          // MODE 0: [taps][wrows][Cin]; MODE 1: [wrows][Kpad]
+  float *gw;          // partial gradients, one per voxel slice: MODE 0 [ksplit][taps][wrows][Cin]; MODE 1 [ksplit][wrows][Kpad]
   long long M;        // voxels of dY (N*OX*OY*OZ)
   int X, Y, Z, OX, OY, OZ;
   int Cin, Cout, wrows, taps, stride;
@@ -520,6 +921,7 @@ struct WgradArgs {
   const unsigned *vmask;   // MODE 0, taps == 27: per-voxel 27-bit mask of in-bounds taps (built by tap_mask_kernel)
   unsigned x_bytes, dy_bytes;
   float *gbias;       // optional: column sums of dY, accumulated by the (centre tap, first n-tile) workgroups from their LDS A tiles
+  long long slice_stride;   // elements between the partial gradients of consecutive voxel slices ([ksplit][...] layout of gw)
 };
 
 template <typename T> struct WgCfg;
@@ -763,12 +1165,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     buf ^= 1;
   }
 
-  if (do_bias) {
-    constexpr int EPP = 16 / (int)sizeof(T);
+  if (do_bias) {   // reduce the row groups through LDS (free after the loop's last barrier): one atomic per column per workgroup
+    constexpr int EPP = 16 / (int)sizeof(T), NRG = 256 / PIECES_ROW;
+    float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
-    for (int e = 0; e < EPP; ++e) {
-      const int bc = m0 + ((tid % PIECES_ROW) ^ (((tid / PIECES_ROW) & 3) << 2)) * EPP + e;   // logical column of this thread's physical slot
-      if (bc < p.Cout) atomicAdd(p.gbias + bc, bias_acc[e]);
+    for (int e = 0; e < EPP; ++e) red[tid * 8 + e] = bias_acc[e];
+    __syncthreads();
+    if (tid < 128) {
+      const int g = tid / EPP, e = tid % EPP;
+      float sum = 0.f;
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg) sum += red[(rg * PIECES_ROW + (g ^ ((rg & 3) << 2))) * 8 + e];   // thread holding logical slot g of row group rg
+      if (m0 + tid < p.Cout) atomicAdd(p.gbias + m0 + tid, sum);
     }
   }
   const int fr = lane & 31;
@@ -782,10 +1190,166 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + (wm * 2 + i) * 32 + frag_row(r, lane);
-        if (row < p.wrows) {
-          float *dst = (MODE == 0) ? p.gw + ((long long)tap * p.wrows + row) * p.Cin + col : p.gw + (long long)row * p.kpad + col;
-          atomicAdd(dst, acc[i][j][r]);
+        if (row < p.wrows) {   // plain store into this slice's partial gradient (summed by nrpn_unpack_*_wgrad): no atomics, no memset
+          float *dst = p.gw + slice * p.slice_stride +
+                       ((MODE == 0) ? ((long long)tap * p.wrows + row) * p.Cin + col : (long long)row * p.kpad + col);
+          *dst = acc[i][j][r];
         }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256(Cout) x 256(Cin) wgrad tile for the wide bf16 layers: 8 waves (2 x 4, each 128x64), four [64 voxel][128 channel]
+// sub-tiles per LDS buffer in the layout of the 128-wide kernel (so wg_frag / the transpose reads are unchanged).  Halves the
+// bytes pulled through the CU's vector-memory path per MFMA (the 128x128 tile moves 32 KB per 16 MFMAs per wave and saturates
+// it).  One workgroup = (cout tile, cin tile, tap, voxel slice); fp32 atomics into the packed gradient.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs p) {
+  typedef bf16s T;
+  constexpr int KV = 64, RS = 256, SUB = KV * RS;            // 16 KB sub-tile
+  constexpr int PIECES_ROW = 16, KSUB = 16, TM = 4, TN = 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [2 buffers][A0 | A1 | B0 | B1]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const unsigned ntm = (p.wrows + 255) / 256, ntn = p.ntiles_n, tps = p.taps;
+  unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(id % ntm) * 256;
+  id /= ntm;
+  const int n0 = (int)(id % ntn) * 256;
+  id /= ntn;
+  const int tap = (int)(id % tps);
+  const int slice = (int)(id / tps);
+  int dx = 0, dy = 0, dz = 0;
+  if (p.taps == 27) { dx = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dz = tap % 3 - 1; }
+  const long long chunks = (p.M + KV - 1) / KV;
+  const long long per = (chunks + p.ksplit - 1) / p.ksplit;
+  const long long c_begin = slice * per, c_end = min(chunks, c_begin + per);
+  if (c_begin >= c_end) return;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(p.vmask, (unsigned)(p.M * 4));
+  const long long tap_shift = ((long long)dx * p.Y + dy) * p.Z + dz;
+  const bool use_mask = p.taps == 27;
+  // per thread: rows r_i = tid / 16 + 32 i (i = 0, 1) of every sub-tile, physical 16-byte slot tid % 16
+  unsigned a_voff[2][2], b_voff[2][2], m_voff[2], m_next[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = tid / PIECES_ROW + 32 * i;
+    const int col = (tid % PIECES_ROW) ^ ((row & 3) << 2);          // logical column of this physical slot
+    const long long v = c_begin * KV + row;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ca = m0 + 128 * t + col * 8, cb = n0 + 128 * t + col * 8;
+      a_voff[t][i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * 2) : kOOB;
+      b_voff[t][i] = cb < p.Cin ? (unsigned)(((v + tap_shift) * p.Cin + cb) * 2) : kOOB;
+    }
+    m_voff[i] = (unsigned)(v * 4);
+    m_next[i] = (v < p.M) ? 1u : 0u;
+    if (use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
+  }
+  const unsigned a_step = (unsigned)(KV * p.Cout * 2), b_step = (unsigned)(KV * p.Cin * 2);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_dma = [&](int buf) {
+    char *base = lds + buf * 4 * SUB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int dst = (64 * wave_u + 512 * i) * 16;
+      const bool in = (m_next[i] >> tap) & 1u;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        lds_dma16(dyr, base + t * SUB + dst, a_voff[t][i]);
+        lds_dma16(xr, base + (2 + t) * SUB + dst, (in && b_voff[t][i] != kOOB) ? b_voff[t][i] : kOOB);
+        a_voff[t][i] = a_voff[t][i] == kOOB ? kOOB : a_voff[t][i] + a_step;
+        b_voff[t][i] = b_voff[t][i] == kOOB ? kOOB : b_voff[t][i] + b_step;
+      }
+      m_voff[i] += KV * 4;
+      if (use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
+      else m_next[i] = (m_voff[i] < (unsigned)(p.M * 4)) ? 1u : 0u;
+    }
+  };
+
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool do_bias = p.gbias != nullptr && n0 == 0 && tap == (p.taps == 27 ? 13 : 0);
+  float bias_acc[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias_acc[t][e] = 0.f;
+
+  issue_dma(0);
+  __syncthreads();
+  int buf = 0;
+#pragma unroll 1
+  for (long long ch = c_begin; ch < c_end; ++ch) {
+    if (ch + 1 < c_end) issue_dma(buf ^ 1);
+    const char *base = lds + buf * 4 * SUB;
+    const char *A = base + wm * SUB;
+    const char *B = base + (2 + (wn >> 1)) * SUB;
+    if (do_bias) {
+      typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const f4 v = *reinterpret_cast<const f4 *>(base + t * SUB + (tid / PIECES_ROW + 32 * i) * RS + (tid % PIECES_ROW) * 16);
+          const u8v h = __builtin_bit_cast(u8v, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bias_acc[t][e] += bf16_bits_to_f32(h[e]);
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KV; kb += KSUB) {
+      f4 af[TM], bfv[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfv[j] = wg_frag<T, true>(B, (wn & 1) * 64 + j * 32, kb, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = wg_frag<T, true>(A, i * 32, kb, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bfv[j]);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (do_bias) {   // reduce the 32 row groups through LDS: one atomic per column per workgroup
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(tid * 2 + t) * 8 + e] = bias_acc[t][e];
+    __syncthreads();
+    if (tid < 256) {
+      const int t = tid >> 7, g = (tid & 127) >> 3, e = tid & 7;
+      float sum = 0.f;
+#pragma unroll 8
+      for (int rg = 0; rg < 32; ++rg) sum += red[((rg * PIECES_ROW + (g ^ ((rg & 3) << 2))) * 2 + t) * 8 + e];
+      if (m0 + tid < p.Cout) atomicAdd(p.gbias + m0 + tid, sum);
+    }
+  }
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+  const int fr = elane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + fr;
+    if (col >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + i * 32 + frag_row(r, elane);
+        if (row < p.wrows) p.gw[slice * p.slice_stride + ((long long)tap * p.wrows + row) * p.Cin + col] = acc[i][j][r];
       }
   }
 }
@@ -810,15 +1374,40 @@ __global__ void tap_mask_kernel(unsigned *__restrict__ mask, long long M, int X,
 static int g_wgrad_tr_mode = 1;
 extern "C" int nrpn_set_wgrad_transpose_read(int on) { g_wgrad_tr_mode = on ? 1 : 0; return NRPN_OK; }
 
+static int g_wgrad_big = 1;   // 1: 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256 (tuning knob)
+extern "C" int nrpn_set_wgrad_big_tile(int on) { g_wgrad_big = on ? 1 : 0; return NRPN_OK; }
+
+// How the voxel axis is cut: every (tile, tap, slice) workgroup writes one partial gradient; the slices are summed by the
+// unpack kernels.  `ksplit` is trimmed so that no slice is empty (every partial is fully written).
+struct WgPlan { int ksplit; bool big; };
+static WgPlan wgrad_plan(long long M, int wrows, int ncols, int taps, int elem_bytes, int mode, int cout, int cin) {
+  WgPlan pl{1, false};
+  const int kv = elem_bytes == 4 ? 32 : 64;
+  const long long chunks = (M + kv - 1) / kv;
+  long long ks = 1;
+  if (mode == 0 && elem_bytes == 2 && g_wgrad_big && g_wgrad_tr_mode != 0 && cout >= 256 && cin >= 256) {
+    // 256x256 tiles: fewest slices whose workgroup count fills >= 80 % of whole rounds of 256 CUs (one 128 KB-LDS workgroup per CU)
+    const int tiles = ((wrows + 255) / 256) * ((cin + 255) / 256) * taps;
+    for (long long k = 1; k <= 64 && k <= max(1ll, chunks / 16); ++k) {
+      const double rounds = (double)tiles * k / 256.0;
+      const long long whole = (long long)rounds + ((double)(long long)rounds < rounds ? 1 : 0);
+      if (rounds / (double)whole >= 0.8) { pl.big = true; ks = k; break; }
+    }
+  }
+  if (!pl.big) {
+    const int tiles = ((wrows + 127) / 128) * ((ncols + 127) / 128) * taps;
+    ks = (1024 + tiles - 1) / tiles;
+    if (ks > chunks / 16) ks = chunks / 16;     // >= 16 chunks per workgroup so the 128x128 epilogue stays amortised
+    if (ks < 1) ks = 1;
+    if (ks > 4096) ks = 4096;
+  }
+  const long long per = (chunks + ks - 1) / ks;
+  pl.ksplit = (int)((chunks + per - 1) / per);
+  return pl;
+}
+
 template <typename T, int MODE>
 static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
-  const int tiles = ((a.wrows + 127) / 128) * ntiles_n * (MODE == 0 ? a.taps : 1);
-  const long long chunks = (a.M + WgCfg<T>::KV - 1) / WgCfg<T>::KV;
-  long long ks = (1024 + tiles - 1) / tiles;
-  if (ks > chunks / 16) ks = chunks / 16;     // >= 16 chunks per workgroup so the 128x128 atomic epilogue stays amortised
-  if (ks < 1) ks = 1;
-  if (ks > 4096) ks = 4096;
-  a.ksplit = (int)ks;
   a.ntiles_n = ntiles_n;
   const size_t lds = 4 * (size_t)WgCfg<T>::KV * WgCfg<T>::RS;
   const bool tr = g_wgrad_tr_mode != 0;
@@ -916,11 +1505,38 @@ extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed
   a.vmask = reinterpret_cast<const unsigned *>(workspace);
   if (ksize == 3)
     hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz);
-  NRPN_HIP(hipMemsetAsync(gw_packed, 0, (size_t)a.taps * wrows * cin * 4, st));
   a.gbias = gbias;
   if (gbias && !accumulate_bias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  const WgPlan pl = wgrad_plan(a.M, wrows, cin, a.taps, es, 0, cout, cin);
+  a.ksplit = pl.ksplit;
+  a.slice_stride = (long long)a.taps * wrows * cin;
   if (dtype == NRPN_F32) return launch_wgrad<float, 0>(a, (cin + 127) / 128, st);
+  if (pl.big) {
+    a.ntiles_n = (cin + 255) / 256;
+    const int tiles = ((wrows + 255) / 256) * a.ntiles_n * a.taps;
+    const size_t lds = 2 * 4 * (size_t)64 * 256;
+    static bool done = false;
+    if (!done) {
+      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
+    NRPN_LAUNCH_CHECK("conv_wgrad_big");
+    return NRPN_OK;
+  }
   return launch_wgrad<bf16s, 0>(a, (cin + 127) / 128, st);
+}
+
+extern "C" int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype) {
+  return wgrad_plan((long long)n * gx * gy * gz, wrows, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, 0, cout, cin).ksplit;
+}
+
+static long long stem_out_voxels(int n, int gx, int gy, int gz, int stride) {
+  return (long long)n * ((gx - 1) / stride + 1) * ((gy - 1) / stride + 1) * ((gz - 1) / stride + 1);
+}
+
+extern "C" int nrpn_stem_wgrad_slices(int n, int gx, int gy, int gz, int cout, int stride, int dtype) {
+  return wgrad_plan(stem_out_voxels(n, gx, gy, gz, stride), cout, nrpn_stem_kpad(dtype), 1, dtype == NRPN_F32 ? 4 : 2, 1, cout, 4).ksplit;
 }
 
 extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
@@ -944,9 +1560,10 @@ extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_p
     NRPN_REQUIRE(xb < (1ll << 31) && db < (1ll << 31), "stem wgrad: tensors must stay below 2 GiB");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db; a.vmask = nullptr;
   }
-  NRPN_HIP(hipMemsetAsync(gw_packed, 0, (size_t)cout * a.kpad * 4, st));
   a.gbias = gbias;
   if (gbias && !accumulate_bias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  a.ksplit = wgrad_plan(a.M, cout, a.kpad, 1, es, 1, cout, 4).ksplit;
+  a.slice_stride = (long long)cout * a.kpad;
   if (dtype == NRPN_F32) return launch_wgrad<float, 1>(a, (a.kpad + 127) / 128, st);
   return launch_wgrad<bf16s, 1>(a, (a.kpad + 127) / 128, st);
 }
@@ -984,24 +1601,38 @@ extern "C" int nrpn_pack_conv_weight(const float *w_ref, int cout, int cin, int 
   return NRPN_OK;
 }
 
-__global__ void unpack_wgrad_kernel(const float *__restrict__ gp, int cout, int cin, int taps, int rows_total, int row_offset,
-                                    float *__restrict__ gw, int accumulate) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)cout * cin * taps;
-  if (i >= total) return;
-  const int t = (int)(i % taps);
-  const int c = (int)((i / taps) % cin);
-  const int o = (int)(i / ((long long)taps * cin));
-  const float v = gp[((long long)t * rows_total + row_offset + o) * cin + c];
-  gw[i] = accumulate ? gw[i] + v : v;
+// packed partial gradients [slices][taps][rows_total][cin] -> reference layout [cout][cin][taps], summed over the slices.
+// One block = one output row o and 64 input channels: reads are coalesced along cin, an LDS tile turns (tap, c) into
+// (c, tap), and the 64 x taps floats of the reference layout are written contiguously.
+__global__ void __launch_bounds__(256) unpack_wgrad_kernel(const float *__restrict__ gp, int cout, int cin, int taps, int rows_total,
+                                                           int row_offset, float *__restrict__ gw, int accumulate, int slices,
+                                                           long long slice_stride) {
+  __shared__ float tile[27][65];
+  const int o = blockIdx.y, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < taps * 64; i += 256) {
+    const int t = i / 64, c = i % 64;
+    float v = 0.f;
+    if (c0 + c < cin) {
+      const float *src = gp + ((long long)t * rows_total + row_offset + o) * cin + c0 + c;
+      for (int s = 0; s < slices; ++s) v += src[s * slice_stride];
+    }
+    tile[t][c] = v;
+  }
+  __syncthreads();
+  const int ncol = min(64, cin - c0);
+  float *dst = gw + ((long long)o * cin + c0) * taps;
+  for (int i = threadIdx.x; i < ncol * taps; i += 256) {
+    const float v = tile[i % taps][i / taps];
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
 }
 
 extern "C" int nrpn_unpack_conv_wgrad(const float *gw_packed, int cout, int cin, int taps, int rows_total, int row_offset, float *gw_ref,
-                                      int accumulate, nrpn_stream_t stream) {
-  NRPN_REQUIRE(gw_packed && gw_ref && cout > 0 && cin > 0 && taps > 0 && row_offset + cout <= rows_total, "unpack_conv_wgrad: bad args");
-  const long long total = (long long)cout * cin * taps;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, as_stream(stream), gw_packed, cout, cin, taps,
-                     rows_total, row_offset, gw_ref, accumulate);
+                                      int accumulate, int slices, nrpn_stream_t stream) {
+  NRPN_REQUIRE(gw_packed && gw_ref && cout > 0 && cin > 0 && taps > 0 && taps <= 27 && slices > 0 && row_offset + cout <= rows_total,
+               "unpack_conv_wgrad: bad args");
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((cin + 63) / 64), (unsigned)cout), dim3(256), 0, as_stream(stream), gw_packed, cout,
+                     cin, taps, rows_total, row_offset, gw_ref, accumulate, slices, (long long)taps * rows_total * cin);
   NRPN_LAUNCH_CHECK("unpack_conv_wgrad");
   return NRPN_OK;
 }
@@ -1028,19 +1659,22 @@ extern "C" int nrpn_pack_stem_weight(const float *w_ref, int cout, int dtype, vo
   return NRPN_OK;
 }
 
-__global__ void unpack_stem_wgrad_kernel(const float *__restrict__ gp, int cout, int kpad, float *__restrict__ gw, int accumulate) {
+__global__ void unpack_stem_wgrad_kernel(const float *__restrict__ gp, int cout, int kpad, float *__restrict__ gw, int accumulate, int slices) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)cout * 4 * 343) return;
   const int tap = (int)(i % 343), c = (int)((i / 343) % 4), o = (int)(i / (343 * 4));
-  const float v = gp[(long long)o * kpad + tap * 4 + c];
+  const float *src = gp + (long long)o * kpad + tap * 4 + c;
+  float v = 0.f;
+  for (int s = 0; s < slices; ++s) v += src[(long long)s * cout * kpad];
   gw[i] = accumulate ? gw[i] + v : v;
 }
 
-extern "C" int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *gw_ref, int accumulate, nrpn_stream_t stream) {
-  NRPN_REQUIRE(gw_packed && gw_ref && cout > 0, "unpack_stem_wgrad: bad args");
+extern "C" int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *gw_ref, int accumulate, int slices,
+                                      nrpn_stream_t stream) {
+  NRPN_REQUIRE(gw_packed && gw_ref && cout > 0 && slices > 0, "unpack_stem_wgrad: bad args");
   const int kpad = nrpn_stem_kpad(dtype);
   hipLaunchKernelGGL(unpack_stem_wgrad_kernel, dim3((unsigned)cdiv64((long long)cout * 4 * 343, 256)), dim3(256), 0, as_stream(stream),
-                     gw_packed, cout, kpad, gw_ref, accumulate);
+                     gw_packed, cout, kpad, gw_ref, accumulate, slices);
   NRPN_LAUNCH_CHECK("unpack_stem_wgrad");
   return NRPN_OK;
 }

@@ -437,7 +437,8 @@ class ConvFn(torch.autograd.Function):
             dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype)
         taps = ksize ** 3
         wsinks, bsinks = ctx.sinks
-        gwp = torch.empty((taps, rows_total, cin), dtype=torch.float32, device=x.device)
+        slices = query("conv3d_wgrad_slices", n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x))
+        gwp = torch.empty((slices, taps, rows_total, cin), dtype=torch.float32, device=x.device)     # per-slice partials, summed by the unpack
         direct_bias = has_bias and nw == 1 and bsinks[0] is not None
         gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
         wsb = query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, ksize)
@@ -447,12 +448,12 @@ class ConvFn(torch.autograd.Function):
         gws, gbs, row = [], [], 0
         for i, w in enumerate(weights):
             if wsinks[i] is not None:
-                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(wsinks[i].slot), 1, _s())
+                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(wsinks[i].slot), 1, slices, _s())
                 wsinks[i].notify()
                 gws.append(None)
             else:
                 gw = torch.empty_like(w, dtype=torch.float32)
-                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(gw), 0, _s())
+                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(gw), 0, slices, _s())
                 gws.append(gw)
             if not has_bias:
                 gbs.append(None)
@@ -501,18 +502,19 @@ class StemFn(torch.autograd.Function):
         n, gx, gy, gz, _ = x.shape
         cout = weight.shape[0]
         kpad = query("stem_kpad", _dt(x))
-        gwp = torch.empty((cout, kpad), dtype=torch.float32, device=x.device)
+        slices = query("stem_wgrad_slices", n, gx, gy, gz, cout, stride, _dt(x))
+        gwp = torch.empty((slices, cout, kpad), dtype=torch.float32, device=x.device)
         wsink, bsink = ctx.sinks
         direct_bias = has_bias and bsink is not None
         gb = bsink.slot if direct_bias else (torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None)
         call("conv3d_stem_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cout, stride, _dt(x), int(direct_bias), _s())
         if wsink is not None:
-            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(wsink.slot), 1, _s())
+            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(wsink.slot), 1, slices, _s())
             wsink.notify()
             gw = None
         else:
             gw = torch.empty_like(weight, dtype=torch.float32)
-            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(gw), 0, _s())
+            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(gw), 0, slices, _s())
         if direct_bias:
             bsink.notify()
             gb = None

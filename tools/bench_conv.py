@@ -24,7 +24,7 @@ def run(grid, cin, cout, k, dtype):
     wp, wpd = pk.get([w], dtype, cout, True)
     flops = 2.0 * n * grid ** 3 * cin * cout * k ** 3
     y = torch.empty(n, grid, grid, grid, cout, device=dev, dtype=dtype)
-    gw = torch.empty(k ** 3, cout, cin, device=dev)
+    gw = torch.empty(lib.query('conv3d_wgrad_slices', n, grid, grid, grid, cin, cout, cout, k, ops._dt(x)), k ** 3, cout, cin, device=dev)
     dt = ops._dt(x)
     wsb = lib.query('conv3d_fwd_workspace_bytes', n, grid, grid, grid, cin, cout, k, dt)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
