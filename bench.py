@@ -127,8 +127,7 @@ class ConvProbe:
         vox, cin_, cout_, _k = shape
         if name == "conv3d_fwd":     # tile selection of launch_conv (csrc/conv3d.hip)
             big = cout_ >= 256 and -(-vox // 256) * -(-cout_ // 256) >= 200
-            ws_ = not big and cout_ > 64 and -(-vox // 256) * -(-cout_ // 128) >= 240
-            kernel = "conv_igemm_big_kernel" if big else ("conv_igemm_ws_kernel" if ws_ else "conv_igemm_kernel")
+            kernel = "conv_igemm_big_kernel" if big else "conv_igemm_kernel"
         else:
             kernel = "conv_wgrad_big_kernel" if (cin_ >= 256 and cout_ >= 256) else "conv_wgrad_kernel"
         traffic = None

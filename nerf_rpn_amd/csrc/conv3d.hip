@@ -794,7 +794,7 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const bool can = kDma && g_conv_glds && wide && bn == 128 && a.ksplit <= 1 && sizeof(T) == 2;
   const long long tiles_big = cdiv64(a.M, 256) * ((a.Cout + 255) / 256);
   const bool huge = can && a.Cout >= 256 && (g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
-  const bool big = can && !huge && (g_conv_bm == 256 || (g_conv_bm == 0 && tiles256 >= 240));
+  const bool big = can && !huge && g_conv_bm == 256;      // wave-specialised 256x128: on par with 128x128 (measured), opt-in only
   const int bm = (big || huge) ? 256 : 128;
   dim3 grid((unsigned)(cdiv64(a.M, bm) * ((a.Cout + (huge ? 256 : bn) - 1) / (huge ? 256 : bn)) * (a.ksplit > 1 ? a.ksplit : 1)));
   int rc = 0;

@@ -79,7 +79,7 @@ def test_head_matches_oracle_on_identical_features(rot, ctr_on_reg, training, de
     hd = hd.to(dev).train(training)
     orc.train(training)
     g = torch.Generator().manual_seed(3)
-    feats = [torch.randn(2, 256, *s, generator=g) for s in ((10, 8, 6), (5, 4, 3), (3, 2, 2), (2, 1, 1))]
+    feats = [torch.randn(2, 256, *s, generator=g) for s in ((10, 8, 6), (5, 4, 3), (3, 2, 2), (2, 2, 2))]
     fo = [f.clone().requires_grad_() for f in feats]
     fg = [f.to(dev).requires_grad_() for f in feats]
     oo, og = orc(fo), hd(fg)
