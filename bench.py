@@ -135,13 +135,13 @@ class ConvProbe:
         if os.path.exists(pmc) and shape == (64000, 256, 256, 3):
             for kname, vals in json.load(open(pmc))["kernels"].items():
                 if kname.startswith(kernel):
-                    traffic = vals.get("hbm_bytes_est (FETCH_SIZE*2*1024 + WRITE_SIZE*1024)")
+                    traffic = vals.get("l2_miss_bytes (TCC_MISS_sum*128)", vals.get("hbm_bytes_est (FETCH_SIZE*2*1024 + WRITE_SIZE*1024)"))
         roof = {"bound": "mfma", "kernel": kernel,
                 "shape": {"voxels": shape[0], "cin": shape[1], "cout": shape[2], "k": shape[3]}, "launches": cnt,
                 "avg_ms": round(avg_ms, 4), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_note": "HBM+MALL bytes per launch from rocprofv3 --pmc (profiles/r01_pmc_conv_256x256_40c.json); algorithmic "
-                                "bytes of this launch = 69 MB (x 32.8 + w 3.5 + y 32.8)",
+                "traffic_note": "bytes beyond L2 (MALL+HBM) per launch = TCC_MISS_sum x 128 B from rocprofv3 --pmc "
+                                "(profiles/r01_pmc_conv_256x256_40c.json); algorithmic bytes of this launch = 69 MB (x 32.8 + w 3.5 + y 32.8)",
                 "timed_heavy_launches": {"tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2), "ms_per_step": None}}
         return roof, rows
 
