@@ -232,11 +232,12 @@ int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, float *mean, fl
 /* y = relu?((x - mean) * rsqrt(var + eps) * gamma + beta) */
 int nrpn_bn_apply(const void *x, void *y, int64_t rows, int c, int dtype, const float *mean, const float *var,
                   const float *gamma, const float *beta, float eps, int relu, nrpn_stream_t stream);
-/* backward of bn_apply(+relu) in train mode: given x (conv output), y (post-activation, for the ReLU mask) and dy,
+/* backward of bn_apply(+relu) in train mode: given x (conv output), dy and either beta (the ReLU mask is then recomputed
+ * from x with the bn_apply expression and y is not read -- one tensor less of HBM traffic) or y (post-activation),
  * writes dx and dgamma/dbeta (f32 [C], overwritten); acc_dgamma / acc_dbeta (optional) are additionally incremented. */
 int nrpn_bn_backward(const void *x, const void *y, const void *dy, void *dx, int64_t rows, int c, int dtype,
-                     const float *mean, const float *var, const float *gamma, float eps, int relu, float *dgamma,
-                     float *dbeta, float *acc_dgamma, float *acc_dbeta, void *workspace, nrpn_stream_t stream);
+                     const float *mean, const float *var, const float *gamma, const float *beta, float eps, int relu,
+                     float *dgamma, float *dbeta, float *acc_dgamma, float *acc_dbeta, void *workspace, nrpn_stream_t stream);
 int nrpn_relu_backward(const void *y, const void *dy, void *dx, int64_t count, int dtype, nrpn_stream_t stream);
 /* MaxPool3d(k, stride s, pad p, ceil_mode) forward writes int8 argmax offsets (window-local) for the backward. */
 int nrpn_pool_out_size(int in, int k, int s, int p, int ceil_mode);

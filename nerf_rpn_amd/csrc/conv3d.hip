@@ -87,6 +87,7 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;   // extents for the raw-buffer descriptors (out-of-range lanes read 0)
   int ksplit;         // > 1: blockIdx.z owns a slice of the K loop and atomically adds fp32 partials into `ws`
   float *ws;          // [M][Cout] fp32, zero-filled by the launcher (split-K only)
+  int slices;         // 1: split-K partials go to ws[z][M][Cout] with plain stores (256x256 kernel); 0: atomics into ws[M][Cout]
 };
 
 template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128>
@@ -580,11 +581,17 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned ntiles = (p.Cout + BN - 1) / BN;
   const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * ntiles;
-  const unsigned tile = xcd_remap(blockIdx.x, tiles);
+  const unsigned zsplit = blockIdx.x / tiles;                      // K slice (0 unless ksplit > 1)
+  const unsigned tile = xcd_remap(blockIdx.x - zsplit * tiles, tiles);
   const long long m0 = (long long)(tile / ntiles) * BM;
   const int n0 = (int)(tile % ntiles) * BN;
   const int cpt = p.Cin / KE;
-  const int nk = p.taps * cpt;
+  int ks_begin = 0, nk = p.taps * cpt;
+  if (p.ksplit > 1) {
+    const int per = (nk + p.ksplit - 1) / p.ksplit;
+    ks_begin = zsplit * per;
+    nk = min(nk, ks_begin + per);        // this workgroup runs K-steps [ks_begin, nk)
+  }
 
   const int lr = tid / PPR, ls = tid % PPR;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -621,8 +628,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     const int r = lr + RSTEP * i, row = n0 + r;
     b_voff[i] = row < p.wrows ? (unsigned)((long long)row * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4) : kOOB;
   }
-  int l_tap = 0, l_chunk = 0, l_dx = 0, l_dy = 0, l_dz = 0;
-  if (p.taps == 27) { l_dx = -1; l_dy = -1; l_dz = -1; }
+  int l_chunk = ks_begin / p.taps, l_tap = ks_begin - l_chunk * p.taps, l_dx = 0, l_dy = 0, l_dz = 0;
+  if (p.taps == 27) { l_dx = l_tap / 9 - 1; l_dy = (l_tap / 3) % 3 - 1; l_dz = l_tap % 3 - 1; }
   const long long w_tap_stride = (long long)p.wrows * p.Cin;
   // branch-free: past the last K-step (`live` false) every lane reads out of range, i.e. deposits zeros in the idle buffer
   auto issue = [&](int buf, bool live) {
@@ -705,11 +712,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     }
   };
 
-  issue(0, true);
+  issue(0, ks_begin < nk);
   __syncthreads();
 #pragma unroll 1
-  for (int ks = 0; ks < nk; ++ks) {
-    compute(ks & 1, ks + 1 < nk);
+  for (int ks = ks_begin; ks < nk; ++ks) {
+    compute((ks - ks_begin) & 1, ks + 1 < nk);
     __syncthreads();
   }
 
@@ -718,6 +725,22 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   int elane = lane;
   asm volatile("" : "+v"(elane));
   const int efr = elane & 31;
+  if (p.ksplit > 1) {     // fp32 partial of this K slice, plain stores; bias / ReLU / cast happen in splitk_epilogue_kernel
+    float *wsz = p.ws + (long long)zsplit * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + efr;
+      if (col >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
+          if (v < p.M) wsz[v * p.Cout + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + efr;
@@ -741,9 +764,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
 
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
-                                       int cout, int relu) {
+                                       int cout, int relu, int nslices) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    float o = ws[i] + (bias ? bias[i % cout] : 0.f);
+    float o = ws[i];
+    for (int z = 1; z < nslices; ++z) o += ws[z * total + i];
+    o += bias ? bias[i % cout] : 0.f;
     if (relu) o = fmaxf(o, 0.f);
     if (OUTF32) reinterpret_cast<float *>(y)[i] = o;
     else elem<T>::st(reinterpret_cast<T *>(y) + i, o);
@@ -765,6 +790,20 @@ static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes)
 
 static int g_conv_glds = 1;   // 1: LDS-DMA loads (buffer_load ... lds), 0: register-staged loads
 extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
+static int g_conv_bm = 0;     // 0: choose per shape; 128 / 256 / 512: force the tile (tuning knob, tools/bench_tile.py)
+
+// Mid-size grids (20^3: M = 8000) give only 32-64 tiles of 256x256: run the big kernel on K slices whose fp32 partials are
+// written with plain stores to ws[z][M][Cout] and summed by the epilogue (no atomics).  Returns the slice count, 0 = not used.
+static int conv_big_split(long long M, int cout, int cin, int taps, int elem_bytes) {
+  if (elem_bytes != 2 || !g_conv_glds || g_conv_kb_value() != 128 || (g_conv_bm != 0 && g_conv_bm != 512) || cout < 256 || (cin * 2) % 128 != 0) return 0;
+  const long long tiles = cdiv64(M, 256) * ((cout + 255) / 256);
+  if (tiles < 16 || tiles >= 200) return 0;
+  const int nk = taps * (cin / 64);
+  int s = (int)((256 + tiles - 1) / tiles);
+  if (s > 8) s = 8;
+  while (s > 1 && nk / s < 8) --s;
+  return s >= 2 ? s : 0;
+}
 static int g_conv_kb = 128;   // K-step bytes of the k1/k3 kernels (64 or 128); tuning knob, see tools/bench_conv.py
 static int g_conv_kb_value() { return g_conv_kb; }
 extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
@@ -773,7 +812,6 @@ extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
   return NRPN_OK;
 }
 
-static int g_conv_bm = 0;     // 0: choose per shape; 128 / 256: force the M tile (tuning knob, tools/bench_conv.py)
 extern "C" int nrpn_set_conv_tile_m(int bm) {
   if (bm != 0 && bm != 128 && bm != 256 && bm != 512)
     return nrpn_fail(NRPN_ERR_ARG, "conv tile selector must be 0 (auto), 128 (128x128), 256 (wave-specialised 256x128) or 512 (256x256)");
@@ -796,9 +834,9 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const bool wide = MODE == 0 && g_conv_kb == 128 && (a.Cin * (int)sizeof(T)) % 128 == 0;
   // 256-row M tiles (each wave owns 128x64: fewer LDS reads and DMA pieces per MFMA) when they still fill the chip
   const long long tiles256 = cdiv64(a.M, 256) * ((a.Cout + bn - 1) / bn);
-  const bool can = kDma && g_conv_glds && wide && bn == 128 && a.ksplit <= 1 && sizeof(T) == 2;
+  const bool can = kDma && g_conv_glds && wide && bn == 128 && (a.ksplit <= 1 || a.slices) && sizeof(T) == 2;
   const long long tiles_big = cdiv64(a.M, 256) * ((a.Cout + 255) / 256);
-  const bool huge = can && a.Cout >= 256 && (g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
+  const bool huge = can && a.Cout >= 256 && (a.slices || g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
   const bool big = can && !huge && g_conv_bm == 256;      // wave-specialised 256x128: on par with 128x128 (measured), opt-in only
   const int bm = (big || huge) ? 256 : 128;
   dim3 grid((unsigned)(cdiv64(a.M, bm) * ((a.Cout + (huge ? 256 : bn) - 1) / (huge ? 256 : bn)) * (a.ksplit > 1 ? a.ksplit : 1)));
@@ -843,6 +881,8 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
 
 extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
   const long long M = (long long)n * gx * gy * gz;
+  const int bs = conv_big_split(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
+  if (bs) return (size_t)bs * M * cout * 4;
   const int s = conv_ksplit(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
   return s > 1 ? (size_t)(M * cout * 4) : 0;
 }
@@ -865,11 +905,17 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
   a.x_bytes = (unsigned)(a.M * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);
   const bool out_f32 = (flags & NRPN_CONV_OUT_F32) != 0;
   hipStream_t st = as_stream(stream);
-  a.ksplit = workspace ? conv_ksplit(a.M, cout, cin, a.taps, dtype == NRPN_F32 ? 4 : 2) : 1;
-  if (a.ksplit > 1) {
-    a.ws = reinterpret_cast<float *>(workspace);
-    NRPN_HIP(hipMemsetAsync(workspace, 0, (size_t)(a.M * cout * 4), st));
+  const int bs = workspace ? conv_big_split(a.M, cout, cin, a.taps, es) : 0;
+  if (bs) {
+    a.ksplit = bs; a.slices = 1; a.ws = reinterpret_cast<float *>(workspace);
+  } else {
+    a.ksplit = workspace ? conv_ksplit(a.M, cout, cin, a.taps, es) : 1;
+    if (a.ksplit > 1) {
+      a.ws = reinterpret_cast<float *>(workspace);
+      NRPN_HIP(hipMemsetAsync(workspace, 0, (size_t)(a.M * cout * 4), st));
+    }
   }
+  const int nsl = a.slices ? a.ksplit : 1;
   int rc = (dtype == NRPN_F32) ? launch_conv<float, 0>(a, true, st) : launch_conv<bf16s, 0>(a, out_f32, st);
   if (rc || a.ksplit <= 1) return rc;
   const long long total = a.M * cout;
@@ -877,10 +923,10 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
   const float *b = (flags & NRPN_CONV_BIAS) ? bias : nullptr;
   const int relu = (flags & NRPN_CONV_RELU) ? 1 : 0;
   if (dtype == NRPN_F32 || out_f32) {
-    if (dtype == NRPN_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu);
-    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu);
+    if (dtype == NRPN_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl);
+    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl);
   } else {
-    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl);
   }
   NRPN_LAUNCH_CHECK("splitk_epilogue");
   return NRPN_OK;

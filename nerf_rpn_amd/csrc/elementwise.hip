@@ -35,18 +35,19 @@ template <> struct vec4<bf16s> {
 // =====================================================================================================================
 // per-channel reductions: slabs of 256 rows per block; thread = (4-channel group, row lane)
 // =====================================================================================================================
-constexpr int kSlab = 256;
+constexpr int kSlab = 64;    // rows per block of the channel reductions: 64000 rows -> 1000 blocks (256-row slabs left 3/4 of the chip idle)
 
 // MODE 0: (sum x, sum x^2)           MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * (y > 0 if relu)
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256)
 chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, long long rows, int c,
-                    const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu, float *__restrict__ partial) {
+                    const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu, float *__restrict__ partial,
+                    const float *__restrict__ gamma = nullptr, const float *__restrict__ beta = nullptr) {
   __shared__ float red[2][256][4];
   // channels are tiled over blockIdx.y in chunks of `cw` (<= 1024) so any C that is a multiple of 4 works
   const int cw = min(c, 1024), coff = blockIdx.y * 1024;
   x += coff; y = y ? y + coff : y; dy = dy ? dy + coff : dy;
-  if (MODE == 1) { mean += coff; var += coff; }
+  if (MODE == 1) { mean += coff; var += coff; if (beta) { gamma += coff; beta += coff; } }
   const int ct = min(cw, c - coff) / 4;       // channel groups of this tile (<= 256)
   const int ty_n = 256 / ct;                  // row lanes
   const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
@@ -54,11 +55,13 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
   f4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
   if (ty < ty_n) {
     f4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
+    f4 ga = {1, 1, 1, 1}, be = {0, 0, 0, 0};
     if (MODE == 1) {
       mu = *reinterpret_cast<const f4 *>(mean + tx * 4);
       const f4 vv = *reinterpret_cast<const f4 *>(var + tx * 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) is[k] = 1.0f / sqrtf(vv[k] + eps);
+      if (beta) { ga = *reinterpret_cast<const f4 *>(gamma + tx * 4); be = *reinterpret_cast<const f4 *>(beta + tx * 4); }
     }
 #pragma unroll 4
     for (long long r = r0 + ty; r < r1; r += ty_n) {
@@ -68,7 +71,10 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
         for (int k = 0; k < 4; ++k) { s0[k] += xv[k]; s1[k] += xv[k] * xv[k]; }
       } else {
         f4 g = vec4<T>::ld(dy + r * c + tx * 4);
-        if (relu) {
+        if (relu && beta) {   // ReLU mask recomputed from x (the bn_apply expression) instead of reading y: one tensor less
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[k] = ((xv[k] - mu[k]) * is[k] * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
+        } else if (relu) {
           const f4 yv = vec4<T>::ld(y + r * c + tx * 4);
 #pragma unroll
           for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
@@ -203,25 +209,28 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, T *__restrict__ dx,
                                     long long groups, int c, long long rows, const float *__restrict__ mean, const float *__restrict__ var,
                                     const float *__restrict__ gamma, float eps, int relu, const float *__restrict__ dgamma,
-                                    const float *__restrict__ dbeta) {
+                                    const float *__restrict__ dbeta, const float *__restrict__ beta) {
   const int ct = c / 4;
   const float invr = 1.0f / (float)rows;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long long)gridDim.x * blockDim.x) {
     const int cg = (int)(g % ct) * 4;
     const f4 xv = vec4<T>::ld(x + g * 4);
     f4 gv = vec4<T>::ld(dy + g * 4);
-    if (relu) {
+    const f4 mu = *reinterpret_cast<const f4 *>(mean + cg), vv = *reinterpret_cast<const f4 *>(var + cg);
+    const f4 ga = *reinterpret_cast<const f4 *>(gamma + cg);
+    const f4 dg = *reinterpret_cast<const f4 *>(dgamma + cg), db = *reinterpret_cast<const f4 *>(dbeta + cg);
+    if (relu && !beta) {
       const f4 yv = vec4<T>::ld(y + g * 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
     }
-    const f4 mu = *reinterpret_cast<const f4 *>(mean + cg), vv = *reinterpret_cast<const f4 *>(var + cg);
-    const f4 ga = *reinterpret_cast<const f4 *>(gamma + cg);
-    const f4 dg = *reinterpret_cast<const f4 *>(dgamma + cg), db = *reinterpret_cast<const f4 *>(dbeta + cg);
+    f4 be = {0, 0, 0, 0};
+    if (relu && beta) be = *reinterpret_cast<const f4 *>(beta + cg);
     f4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float is = 1.0f / sqrtf(vv[k] + eps);
+      if (relu && beta && !(((xv[k] - mu[k]) * is * ga[k] + be[k]) > 0.f)) gv[k] = 0.f;    // mask recomputed from x, y is not read
       const float xh = (xv[k] - mu[k]) * is;
       o[k] = ga[k] * is * (gv[k] - db[k] * invr - xh * dg[k] * invr);
     }
@@ -230,19 +239,19 @@ __global__ void bn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict
 }
 
 extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, void *dx, int64_t rows, int c, int dtype, const float *mean,
-                                const float *var, const float *gamma, float eps, int relu, float *dgamma, float *dbeta,
+                                const float *var, const float *gamma, const float *beta, float eps, int relu, float *dgamma, float *dbeta,
                                 float *acc_dgamma, float *acc_dbeta, void *workspace, nrpn_stream_t stream) {
   if (int rc = check_bn_shape("bn_backward", rows, c)) return rc;
-  NRPN_REQUIRE(x && dy && dx && mean && var && gamma && dgamma && dbeta && workspace && (!relu || y), "bn_backward: null pointer");
+  NRPN_REQUIRE(x && dy && dx && mean && var && gamma && dgamma && dbeta && workspace && (!relu || y || beta), "bn_backward: null pointer");
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
-                                       (long long)rows, c, mean, var, eps, relu, (float *)workspace));
+                                       (long long)rows, c, mean, var, eps, relu, (float *)workspace, gamma, beta));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
   const long long groups = rows * (c / 4);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, st, (const T *)x, (const T *)y,
                                        (const T *)dy, (T *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu,
-                                       (const float *)dgamma, (const float *)dbeta));
+                                       (const float *)dgamma, (const float *)dbeta, beta));
   NRPN_LAUNCH_CHECK("bn_backward");
   return NRPN_OK;
 }

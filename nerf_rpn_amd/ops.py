@@ -540,14 +540,14 @@ class BatchNormFn(torch.autograd.Function):
             mean, var = rmean.float().contiguous(), rvar.float().contiguous()
         y = torch.empty_like(x)
         call("bn_apply", _p(x), _p(y), rows, c, _dt(x), _p(mean), _p(var), _p(g32), _p(b32), float(eps), int(relu), _s())
-        ctx.save_for_backward(x, y, mean, var, g32)
+        ctx.save_for_backward(x, mean, var, g32, b32)      # y is not kept: the backward recomputes the ReLU mask from x
         ctx.meta = (training, eps, relu)
         ctx.sinks = (_sink(gamma), _sink(beta))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, var, g32 = ctx.saved_tensors
+        x, mean, var, g32, b32 = ctx.saved_tensors
         training, eps, relu = ctx.meta
         if not training:
             raise lib.NrpnError("BatchNorm backward in eval mode is not supported by the HIP path")
@@ -560,7 +560,7 @@ class BatchNormFn(torch.autograd.Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=dev)
         gsink, bsink = ctx.sinks
-        call("bn_backward", _p(x), _p(y), _p(dy), _p(dx), rows, c, _dt(x), _p(mean), _p(var), _p(g32), float(eps), int(relu), _p(dgamma),
+        call("bn_backward", _p(x), 0, _p(dy), _p(dx), rows, c, _dt(x), _p(mean), _p(var), _p(g32), _p(b32), float(eps), int(relu), _p(dgamma),
              _p(dbeta), _p(gsink.slot) if gsink is not None else 0, _p(bsink.slot) if bsink is not None else 0, _p(ws), _s())
         if gsink is not None:
             gsink.notify()

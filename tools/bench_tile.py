@@ -11,19 +11,21 @@ def timeit(fn, iters=20, warm=3):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
 dev = torch.device('cuda:0')
-for grid, cin, cout, k in [(40, 256, 256, 3), (40, 128, 256, 3), (40, 128, 128, 3), (20, 512, 512, 3), (40, 256, 128, 3)]:
+for grid, cin, cout, k in [(40, 256, 256, 3), (20, 512, 512, 3), (20, 256, 512, 3), (20, 256, 256, 3), (20, 512, 256, 1), (10, 512, 512, 3)]:
     x = torch.randn(1, grid, grid, grid, cin, device=dev).bfloat16()
     w = torch.randn(cout, cin, k, k, k, device=dev) * 0.05
     wp, _ = ops.PackedWeight().get([w], torch.bfloat16, cout, False)
     flops = 2.0 * grid ** 3 * cin * cout * k ** 3
     outs = {}
     line = f'{grid}^3 {cin}->{cout} k{k}:'
-    for bm in (128, 256, 512):
+    for bm in (128, 256, 0):
         lib.call('set_conv_tile_m', bm)
+        wsb = lib.query('conv3d_fwd_workspace_bytes', 1, grid, grid, grid, cin, cout, k, ops._dt(x))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         y = torch.empty(1, grid, grid, grid, cout, device=dev, dtype=torch.bfloat16)
-        fn = lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, ops._dt(x), 0, 0, ops._s())
+        fn = lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, ops._dt(x), 0, ws.data_ptr() if wsb else 0, ops._s())
         t = timeit(fn, iters=30)
         outs[bm] = y.float()
-        line += f'  bm{bm}: {t*1e3:.0f} us {flops / t / 1e9:.0f} TF'
-    print(line, ' maxdiff', (outs[128] - outs[256]).abs().max().item(), (outs[128] - outs[512]).abs().max().item())
+        line += f'  bm{bm}(ws {wsb>>20}MB): {t*1e3:.0f} us {flops / t / 1e9:.0f} TF'
+    print(line, ' maxdiff', (outs[128] - outs[256]).abs().max().item(), (outs[128] - outs[0]).abs().max().item())
 lib.call('set_conv_tile_m', 0)
