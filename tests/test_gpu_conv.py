@@ -202,3 +202,31 @@ def test_layout_roundtrip_and_adamw(dev):
         ops.grad_sumsq(gh, ss)
         ops.adamw_step(ph, gh, m, v, ss, 0.1, 3e-4, (0.9, 0.999), 1e-8, 1e-2, step)
     assert torch.allclose(ph.cpu(), ref.detach(), atol=1e-6)
+
+
+@pytest.mark.parametrize("case", [(1, (40, 40, 33), 256, 256, 3), (1, (20, 20, 20), 256, 512, 3), (1, (24, 20, 18), 320, 256, 3),
+                                  (2, (40, 30, 30), 128, 256, 1)])
+def test_large_tile_kernels_match_the_128_tile_kernels(case, dev):
+    """bf16 layers big enough for the 256x256 implicit-GEMM tile (plain, and K-sliced for mid-size grids) and the 256x256 wgrad
+    tile: forward, dgrad, wgrad and bias gradient must agree with the 128x128 kernels (which are checked against torch on
+    small shapes above) up to bf16 output rounding / fp32 summation order."""
+    from nerf_rpn_amd import lib
+    from nerf_rpn_amd.model import hip_nn
+    n, grid, cin, cout, k = case
+    torch.manual_seed(1)
+    conv = nn.Conv3d(cin, cout, k, padding=k // 2).to(dev)
+    x = torch.randn(n, *grid, cin, device=dev).bfloat16()
+    gy = (torch.randn(n, *grid, cout, device=dev) * (torch.rand(n, *grid, 1, device=dev) < 0.3)).bfloat16()
+    res = {}
+    for mode in ("base", "auto"):
+        lib.call("set_conv_tile_m", 128 if mode == "base" else 0)
+        lib.call("set_wgrad_big_tile", 0 if mode == "base" else 1)
+        conv.zero_grad()
+        xh = x.clone().requires_grad_(True)
+        y = hip_nn.conv3d(conv, xh, relu=True)
+        y.backward(gy)
+        res[mode] = (y.detach().float(), xh.grad.float(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    lib.call("set_conv_tile_m", 0)
+    lib.call("set_wgrad_big_tile", 1)
+    for name, a, b in zip(("y", "dx", "dw", "db"), res["auto"], res["base"]):
+        assert relerr(a.cpu(), b.cpu()) < (1e-2 if name in ("y", "dx") else 1e-4), (case, name, relerr(a.cpu(), b.cpu()))
