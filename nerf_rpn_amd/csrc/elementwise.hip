@@ -35,14 +35,16 @@ template <> struct vec4<bf16s> {
 // =====================================================================================================================
 // per-channel reductions: slabs of 256 rows per block; thread = (4-channel group, row lane)
 // =====================================================================================================================
-constexpr int kSlab = 64;    // rows per block of the channel reductions: 64000 rows -> 1000 blocks (256-row slabs left 3/4 of the chip idle)
+// rows per block of the channel reductions: ~1024 blocks for any tensor (fixed 256-row slabs left 3/4 of the chip idle on the
+// 64000-row maps), at least 64 rows so the finalize kernels read a bounded number of partials
+static inline int slab_rows(long long rows) { const long long s = (rows + 1023) / 1024; return (int)(s < 64 ? 64 : s); }
 
 // MODE 0: (sum x, sum x^2)           MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * (y > 0 if relu)
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256)
 chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, long long rows, int c,
                     const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu, float *__restrict__ partial,
-                    const float *__restrict__ gamma = nullptr, const float *__restrict__ beta = nullptr) {
+                    int kSlab, const float *__restrict__ gamma = nullptr, const float *__restrict__ beta = nullptr) {
   __shared__ float red[2][256][4];
   // channels are tiled over blockIdx.y in chunks of `cw` (<= 1024) so any C that is a multiple of 4 works
   const int cw = min(c, 1024), coff = blockIdx.y * 1024;
@@ -102,11 +104,24 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nblocks, int c, int ch, double &s, double &q) {
   __shared__ double rs[16][64], rq[16][64];
   double a = 0.0, b = 0.0;
-  if (ch < c)
-    for (int blk = threadIdx.y; blk < nblocks; blk += 16) {
-      a += (double)partial[(long long)blk * 2 * c + ch];
-      b += (double)partial[(long long)blk * 2 * c + c + ch];
+  if (ch < c) {
+    // four independent chains so four partial rows are in flight per thread (the loop is latency-, not bandwidth-bound)
+    double a4[4] = {0.0, 0.0, 0.0, 0.0}, b4[4] = {0.0, 0.0, 0.0, 0.0};
+    int blk = threadIdx.y;
+    for (; blk + 48 < nblocks; blk += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a4[u] += (double)partial[(long long)(blk + 16 * u) * 2 * c + ch];
+        b4[u] += (double)partial[(long long)(blk + 16 * u) * 2 * c + c + ch];
+      }
     }
+    for (; blk < nblocks; blk += 16) {
+      a4[0] += (double)partial[(long long)blk * 2 * c + ch];
+      b4[0] += (double)partial[(long long)blk * 2 * c + c + ch];
+    }
+    a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+  }
   rs[threadIdx.y][threadIdx.x] = a;
   rq[threadIdx.y][threadIdx.x] = b;
   __syncthreads();
@@ -145,7 +160,7 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb
   if (acc_gamma) acc_gamma[ch] += (float)q;
 }
 
-extern "C" size_t nrpn_bn_workspace_bytes(int64_t rows, int c) { return (size_t)(cdiv64(rows, kSlab) * 2 * c * 4); }
+extern "C" size_t nrpn_bn_workspace_bytes(int64_t rows, int c) { return (size_t)(cdiv64(rows, slab_rows(rows)) * 2 * c * 4); }
 
 static int check_bn_shape(const char *who, int64_t rows, int c) {
   const int tile = c > 1024 ? 1024 : c;
@@ -158,11 +173,12 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
                              float *running_var, float momentum, void *workspace, nrpn_stream_t stream) {
   if (int rc = check_bn_shape("bn_stats", rows, c)) return rc;
   NRPN_REQUIRE(x && mean && var && workspace, "bn_stats: null pointer");
+  const int kSlab = slab_rows(rows);
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 0>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
                                        (const T *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0,
-                                       (float *)workspace));
+                                       (float *)workspace, kSlab));
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
                      var, running_mean, running_var, momentum);
   NRPN_LAUNCH_CHECK("bn_stats");
@@ -243,10 +259,11 @@ extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, vo
                                 float *acc_dgamma, float *acc_dbeta, void *workspace, nrpn_stream_t stream) {
   if (int rc = check_bn_shape("bn_backward", rows, c)) return rc;
   NRPN_REQUIRE(x && dy && dx && mean && var && gamma && dgamma && dbeta && workspace && (!relu || y || beta), "bn_backward: null pointer");
+  const int kSlab = slab_rows(rows);
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
-                                       (long long)rows, c, mean, var, eps, relu, (float *)workspace, gamma, beta));
+                                       (long long)rows, c, mean, var, eps, relu, (float *)workspace, kSlab, gamma, beta));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
   const long long groups = rows * (c / 4);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, st, (const T *)x, (const T *)y,
