@@ -269,11 +269,13 @@ int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtype, int dst_
 /* patch_partition gather (feature_extractor.py:700-710): [N,X,Y,Z,4] -> [N,X/p,Y/p,Z/p,4p^3], inner order (c,dx,dy,dz)
  * = the flattened Conv3d(4,E,k=p,s=p) weight, so the patch embedding is a 1x1x1 GEMM on weight.view(E, 4p^3). */
 int nrpn_patchify(const void *x, void *y, int n, int gx, int gy, int gz, int patch, int dtype, nrpn_stream_t stream);
-/* nn.LayerNorm(C) over rows tokens; mean / rstd (f32 [rows]) are saved for the backward, which overwrites dgamma/dbeta. */
+/* nn.LayerNorm(C) over rows tokens; mean / rstd (f32 [rows]) are saved for the backward, which overwrites dgamma/dbeta
+ * (block partials in `workspace` = nrpn_layernorm_workspace_bytes(rows, c), summed by a second kernel: no atomics). */
 int nrpn_layernorm_fwd(const void *x, void *y, const float *gamma, const float *beta, float *mean, float *rstd, int64_t rows,
                        int c, float eps, int dtype, nrpn_stream_t stream);
+size_t nrpn_layernorm_workspace_bytes(int64_t rows, int c);
 int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *mean, const float *rstd,
-                       float *dgamma, float *dbeta, int64_t rows, int c, int dtype, nrpn_stream_t stream);
+                       float *dgamma, float *dbeta, int64_t rows, int c, int dtype, void *workspace, nrpn_stream_t stream);
 /* exact (erf) GELU; backward != 0: out = dy * gelu'(x) */
 int nrpn_gelu(const void *x, const void *dy, void *out, int64_t count, int backward, int dtype, nrpn_stream_t stream);
 /* y = (a ? a : 0) + scale[n] * b : residual join with the StochasticDepth("row") factor (scale == NULL: 1) */

@@ -21,29 +21,97 @@ static inline int ew_blocks(long long work, int cap = 8192) { long long b = (wor
 // =====================================================================================================================
 // GroupNorm
 // =====================================================================================================================
-// per-(sample, channel) sums over the sample's rows: fwd (sum x, sum x^2), bwd (sum g, sum g*x) with g = dy * relu mask
+// 4 consecutive channels per thread (8/16-byte accesses); C % 4 == 0
+template <typename T> struct gvec4;
+template <> struct gvec4<float> {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  static __device__ __forceinline__ void ld(const float *p, float *v) { const f4 t = *reinterpret_cast<const f4 *>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+  static __device__ __forceinline__ void st(float *p, const float *v) { f4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4 *>(p) = t; }
+};
+template <> struct gvec4<bf16s> {
+  typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+  static __device__ __forceinline__ void ld(const bf16s *p, float *v) {
+    const us4 t = *reinterpret_cast<const us4 *>(p);
+    v[0] = bf16_bits_to_f32(t[0]); v[1] = bf16_bits_to_f32(t[1]); v[2] = bf16_bits_to_f32(t[2]); v[3] = bf16_bits_to_f32(t[3]);
+  }
+  static __device__ __forceinline__ void st(bf16s *p, const float *v) {
+    us4 t = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+    *reinterpret_cast<us4 *>(p) = t;
+  }
+};
+
+// per-(sample, channel) sums over the sample's rows: fwd (sum x, sum x^2), bwd (sum g, sum g*x) with g = dy * relu mask.
+// Block = one slab of rows of one sample; thread = (4-channel group, row lane), 8/16-byte loads, 4 rows in flight per thread;
+// the row lanes are reduced through LDS and the block writes ONE partial row [C][2]; gn_reduce_kernel sums the partial rows
+// into ws[n][c][2].  (The first version added every block's sums with fp32 atomics and read one element per thread.)
+constexpr int kGnMaxParts = 1024;       // partial rows per sample
+static inline int gn_slab(long long rows) { const long long s = (rows + kGnMaxParts - 1) / kGnMaxParts; return (int)(s < 32 ? 32 : s); }
+
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256) gn_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
-                                                         float *__restrict__ ws, long long rows, int c, int relu) {
+                                                         float *__restrict__ partial, long long rows, int c, int relu, int nparts, int slab) {
+  __shared__ float red[2][256][4];
   const int n = blockIdx.y;
-  const int rpi = (c <= 256 && 256 % c == 0) ? 256 / c : 1;            // rows per block iteration
-  const int sub = rpi > 1 ? threadIdx.x / c : 0;
+  const int ct = c / 4;                        // 4-channel groups (<= 256)
+  const int lanes = 256 / ct;                  // row lanes
+  const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
+  const long long r0 = (long long)blockIdx.x * slab, r1 = min(rows, r0 + slab);
   const long long base = (long long)n * rows;
-  for (int ch = rpi > 1 ? threadIdx.x % c : threadIdx.x; ch < c; ch += 256) {
-    float s0 = 0.f, s1 = 0.f;
-    for (long long r = (long long)blockIdx.x * rpi + sub; r < rows; r += (long long)gridDim.x * rpi) {
-      const long long o = (base + r) * c + ch;
-      const float xv = elem<T>::ld(x + o);
-      if (!BWD) { s0 += xv; s1 += xv * xv; }
-      else {
-        float g = elem<T>::ld(dy + o);
-        if (relu && !(elem<T>::ld(y + o) > 0.f)) g = 0.f;
-        s0 += g; s1 += g * xv;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ty < lanes) {
+#pragma unroll 4
+    for (long long r = r0 + ty; r < r1; r += lanes) {
+      const long long o = (base + r) * c + tx * 4;
+      float xv[4];
+      gvec4<T>::ld(x + o, xv);
+      if (!BWD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += xv[k]; s1[k] += xv[k] * xv[k]; }
+      } else {
+        float g[4], yv[4] = {1.f, 1.f, 1.f, 1.f};
+        gvec4<T>::ld(dy + o, g);
+        if (relu) gvec4<T>::ld(y + o, yv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gk = (relu && !(yv[k] > 0.f)) ? 0.f : g[k];
+          s0[k] += gk; s1[k] += gk * xv[k];
+        }
       }
     }
-    atomicAdd(ws + ((long long)n * c + ch) * 2, s0);
-    atomicAdd(ws + ((long long)n * c + ch) * 2 + 1, s1);
-    if (rpi > 1) break;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; }
+  __syncthreads();
+  if (threadIdx.x < ct) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < lanes; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a[k] += red[0][q * ct + threadIdx.x][k]; b[k] += red[1][q * ct + threadIdx.x][k]; }
+    float *out = partial + (((long long)n * nparts + blockIdx.x) * c + threadIdx.x * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { out[2 * k] = a[k]; out[2 * k + 1] = b[k]; }
+  }
+}
+
+// ws[n][c][2] = sum over the partial rows; block = (64 channels, 16 part lanes), grid = (ceil(C/64), N)
+__global__ void gn_reduce_kernel(const float *__restrict__ partial, float *__restrict__ ws, int nparts, int c) {
+  __shared__ float r0[16][64], r1[16][64];
+  const int n = blockIdx.y, ch = blockIdx.x * 64 + threadIdx.x;
+  float a = 0.f, b = 0.f;
+  if (ch < c)
+    for (int p = threadIdx.y; p < nparts; p += 16) {
+      const float *src = partial + (((long long)n * nparts + p) * c + ch) * 2;
+      a += src[0];
+      b += src[1];
+    }
+  r0[threadIdx.y][threadIdx.x] = a;
+  r1[threadIdx.y][threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.y == 0 && ch < c) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < 16; ++k) { s += r0[k][threadIdx.x]; q += r1[k][threadIdx.x]; }
+    ws[((long long)n * c + ch) * 2] = s;
+    ws[((long long)n * c + ch) * 2 + 1] = q;
   }
 }
 
@@ -65,13 +133,18 @@ __global__ void gn_apply_kernel(const T *__restrict__ x, T *__restrict__ y, cons
                                 const float *__restrict__ gamma, const float *__restrict__ beta, long long rows, int c, int groups,
                                 long long total, int relu) {
   const int cpg = c / groups;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * blockDim.x * 4) {
     const int ch = (int)(i % c);
     const long long n = i / c / rows;
-    const int sg = (int)n * groups + ch / cpg;
-    float o = (elem<T>::ld(x + i) - mean[sg]) * rstd[sg] * gamma[ch] + beta[ch];
-    if (relu) o = fmaxf(o, 0.f);
-    elem<T>::st(y + i, o);
+    float v[4];
+    gvec4<T>::ld(x + i, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int sg = (int)n * groups + (ch + k) / cpg;
+      v[k] = (v[k] - mean[sg]) * rstd[sg] * gamma[ch + k] + beta[ch + k];
+      if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
+    gvec4<T>::st(y + i, v);
   }
 }
 
@@ -112,34 +185,46 @@ __global__ void gn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict
                                     const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
                                     const float *__restrict__ coef, long long rows, int c, int groups, long long total, int relu) {
   const int cpg = c / groups;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * blockDim.x * 4) {
     const int ch = (int)(i % c);
     const long long n = i / c / rows;
-    const int sg = (int)n * groups + ch / cpg;
-    float g = elem<T>::ld(dy + i);
-    if (relu && !(elem<T>::ld(y + i) > 0.f)) g = 0.f;
-    const float xh = (elem<T>::ld(x + i) - mean[sg]) * rstd[sg];
-    elem<T>::st(dx + i, rstd[sg] * (g * gamma[ch] - coef[sg * 2 + 1] - xh * coef[sg * 2]));
+    float xv[4], gv[4], yv[4] = {1.f, 1.f, 1.f, 1.f}, o[4];
+    gvec4<T>::ld(x + i, xv);
+    gvec4<T>::ld(dy + i, gv);
+    if (relu) gvec4<T>::ld(y + i, yv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int sg = (int)n * groups + (ch + k) / cpg;
+      const float g = (relu && !(yv[k] > 0.f)) ? 0.f : gv[k];
+      const float xh = (xv[k] - mean[sg]) * rstd[sg];
+      o[k] = rstd[sg] * (g * gamma[ch + k] - coef[sg * 2 + 1] - xh * coef[sg * 2]);
+    }
+    gvec4<T>::st(dx + i, o);
   }
 }
 
-extern "C" size_t nrpn_groupnorm_workspace_bytes(int n, int c, int groups) { return ((size_t)n * c * 2 + (size_t)n * groups * 2) * 4; }
+// workspace: sums [n][c][2] | group coefficients [n][groups][2] | partial rows [n][kGnMaxParts][c][2]
+extern "C" size_t nrpn_groupnorm_workspace_bytes(int n, int c, int groups) {
+  return ((size_t)n * c * 2 + (size_t)n * groups * 2 + (size_t)n * kGnMaxParts * c * 2) * 4;
+}
 
 extern "C" int nrpn_groupnorm_fwd(const void *x, void *y, const float *gamma, const float *beta, float *mean, float *rstd, int n,
                                   int64_t rows, int c, int groups, float eps, int relu, int dtype, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(x && y && gamma && beta && mean && rstd && workspace && n > 0 && rows > 0 && c > 0 && groups > 0 && c % groups == 0,
                "groupnorm_fwd: bad args");
   hipStream_t st = as_stream(stream);
+  NRPN_REQUIRE(c % 4 == 0 && c <= 1024, "groupnorm: C=%d must be a multiple of 4 and <= 1024", c);
   float *ws = reinterpret_cast<float *>(workspace);
-  NRPN_HIP(hipMemsetAsync(ws, 0, (size_t)n * c * 2 * 4, st));
-  const int bx = (int)min((long long)512, (long long)((rows + 31) / 32));
-  DISPATCH_T(dtype, hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(bx, n), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
-                                       (const T *)nullptr, ws, (long long)rows, c, 0));
+  float *partial = ws + (size_t)n * c * 2 + (size_t)n * groups * 2;
+  const int slab = gn_slab(rows), nparts = (int)cdiv64(rows, slab);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(nparts, n), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
+                                       (const T *)nullptr, partial, (long long)rows, c, 0, nparts, slab));
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3((c + 63) / 64, n), dim3(64, 16), 0, st, (const float *)partial, ws, nparts, c);
   const int ng = n * groups;
   hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, ws, mean, rstd, ng, c, groups,
                      (float)((double)rows * (c / groups)), eps);
   const long long total = (long long)n * rows * c;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, st, (const T *)x, (T *)y, mean, rstd, gamma,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ew_blocks(total / 4)), dim3(256), 0, st, (const T *)x, (T *)y, mean, rstd, gamma,
                                        beta, (long long)rows, c, groups, total, relu));
   NRPN_LAUNCH_CHECK("groupnorm_fwd");
   return NRPN_OK;
@@ -151,18 +236,20 @@ extern "C" int nrpn_groupnorm_bwd(const void *x, const void *y, const void *dy, 
   NRPN_REQUIRE(x && dy && dx && gamma && mean && rstd && dgamma && dbeta && workspace && (!relu || y) && n > 0 && rows > 0 && c > 0 &&
                    groups > 0 && c % groups == 0, "groupnorm_bwd: bad args");
   hipStream_t st = as_stream(stream);
+  NRPN_REQUIRE(c % 4 == 0 && c <= 1024, "groupnorm: C=%d must be a multiple of 4 and <= 1024", c);
   float *ws = reinterpret_cast<float *>(workspace);
   float *coef = ws + (size_t)n * c * 2;
-  NRPN_HIP(hipMemsetAsync(ws, 0, (size_t)n * c * 2 * 4, st));
-  const int bx = (int)min((long long)512, (long long)((rows + 31) / 32));
-  DISPATCH_T(dtype, hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(bx, n), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
-                                       ws, (long long)rows, c, relu));
+  float *partial = coef + (size_t)n * groups * 2;
+  const int slab = gn_slab(rows), nparts = (int)cdiv64(rows, slab);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(nparts, n), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
+                                       partial, (long long)rows, c, relu, nparts, slab));
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3((c + 63) / 64, n), dim3(64, 16), 0, st, (const float *)partial, ws, nparts, c);
   const int ng = n * groups;
   hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, ws, mean, rstd, gamma, coef, ng, c, groups,
                      (float)((double)rows * (c / groups)));
   hipLaunchKernelGGL(gn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, st, ws, mean, rstd, dgamma, dbeta, n, c, groups);
   const long long total = (long long)n * rows * c;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, st, (const T *)x, (const T *)y,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(ew_blocks(total / 4)), dim3(256), 0, st, (const T *)x, (const T *)y,
                                        (const T *)dy, (T *)dx, mean, rstd, gamma, coef, (long long)rows, c, groups, total, relu));
   NRPN_LAUNCH_CHECK("groupnorm_bwd");
   return NRPN_OK;

@@ -78,17 +78,20 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T *__restrict_
   }
 }
 
-// dx per row; dgamma / dbeta: per-lane partial sums over the block's rows, one atomic per channel per block
+// dx per row; dgamma / dbeta: per-lane partial sums over the block's rows, reduced over the block's 4 waves through LDS and
+// written as one partial row per block (no atomics: ~1000 same-address fp32 atomics per channel made this kernel 3x slower,
+// and the result is now run-to-run deterministic); layernorm_param_kernel sums the block partials.
 template <typename T, int MAXK>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ dx,
                                                             const float *__restrict__ gamma, const float *__restrict__ mean,
-                                                            const float *__restrict__ rstd, float *__restrict__ dgamma,
-                                                            float *__restrict__ dbeta, long long rows, int c) {
-  const int lane = threadIdx.x & 63;
+                                                            const float *__restrict__ rstd, float *__restrict__ partial, long long rows,
+                                                            int c) {
+  __shared__ float red[3][2][64 * (MAXK > 12 ? 12 : MAXK)];     // waves 1-3 park their sums here, MAXK handled in passes of <= 12
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[MAXK], ab[MAXK];
 #pragma unroll
   for (int j = 0; j < MAXK; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
-  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
     const float m = mean[r], rs = rstd[r];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -114,12 +117,61 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T *__restrict_
       }
     }
   }
+  constexpr int PASS = MAXK > 12 ? 12 : MAXK;
+  float *out = partial + (long long)blockIdx.x * 2 * c;
 #pragma unroll
-  for (int j = 0; j < MAXK; ++j) {
-    const int k = lane + 64 * j;
-    if (k < c) { atomicAdd(dgamma + k, ag[j]); atomicAdd(dbeta + k, ab[j]); }
+  for (int j0 = 0; j0 < MAXK; j0 += PASS) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int j = 0; j < PASS; ++j)
+        if (j0 + j < MAXK) { red[wave - 1][0][j * 64 + lane] = ag[j0 + j]; red[wave - 1][1][j * 64 + lane] = ab[j0 + j]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int j = 0; j < PASS; ++j) {
+        const int k = lane + 64 * (j0 + j);
+        if (j0 + j < MAXK && k < c) {
+          out[k] = ag[j0 + j] + red[0][0][j * 64 + lane] + red[1][0][j * 64 + lane] + red[2][0][j * 64 + lane];
+          out[c + k] = ab[j0 + j] + red[0][1][j * 64 + lane] + red[1][1][j * 64 + lane] + red[2][1][j * 64 + lane];
+        }
+      }
+    }
   }
 }
+
+// dgamma[c], dbeta[c] = sum over the block partials; block = (64 channels, 16 partial lanes)
+__global__ void layernorm_param_kernel(const float *__restrict__ partial, int nblocks, int c, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta) {
+  __shared__ float rs[16][64], rq[16][64];
+  const int ch = blockIdx.x * 64 + threadIdx.x;
+  float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ch < c) {
+    int blk = threadIdx.y;
+    for (; blk + 48 < nblocks; blk += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a4[u] += partial[(long long)(blk + 16 * u) * 2 * c + ch];
+        b4[u] += partial[(long long)(blk + 16 * u) * 2 * c + c + ch];
+      }
+    }
+    for (; blk < nblocks; blk += 16) { a4[0] += partial[(long long)blk * 2 * c + ch]; b4[0] += partial[(long long)blk * 2 * c + c + ch]; }
+  }
+  rs[threadIdx.y][threadIdx.x] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  rq[threadIdx.y][threadIdx.x] = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+  __syncthreads();
+  if (threadIdx.y == 0 && ch < c) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < 16; ++k) { s += rs[k][threadIdx.x]; q += rq[k][threadIdx.x]; }
+    dgamma[ch] = s;
+    dbeta[ch] = q;
+  }
+}
+
+static inline int ln_bwd_blocks(long long rows) { return (int)min((long long)1024, (long long)((rows + 3) / 4)); }
+
+extern "C" size_t nrpn_layernorm_workspace_bytes(int64_t rows, int c) { return (size_t)ln_bwd_blocks(rows) * 2 * c * 4; }
 
 extern "C" int nrpn_layernorm_fwd(const void *x, void *y, const float *gamma, const float *beta, float *mean, float *rstd, int64_t rows,
                                   int c, float eps, int dtype, nrpn_stream_t stream) {
@@ -132,17 +184,17 @@ extern "C" int nrpn_layernorm_fwd(const void *x, void *y, const float *gamma, co
 }
 
 extern "C" int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *mean, const float *rstd,
-                                  float *dgamma, float *dbeta, int64_t rows, int c, int dtype, nrpn_stream_t stream) {
-  NRPN_REQUIRE(x && dy && dx && gamma && mean && rstd && dgamma && dbeta && rows > 0 && c > 0 && c <= 64 * 48,
-               "layernorm_bwd: bad args (C <= 3072)");
+                                  float *dgamma, float *dbeta, int64_t rows, int c, int dtype, void *workspace, nrpn_stream_t stream) {
+  NRPN_REQUIRE(x && dy && dx && gamma && mean && rstd && dgamma && dbeta && workspace && rows > 0 && c > 0 && c <= 64 * 48,
+               "layernorm_bwd: bad args (C <= 3072, workspace = nrpn_layernorm_workspace_bytes)");
   hipStream_t st = as_stream(stream);
-  NRPN_HIP(hipMemsetAsync(dgamma, 0, (size_t)c * 4, st));
-  NRPN_HIP(hipMemsetAsync(dbeta, 0, (size_t)c * 4, st));
-  const int blocks = (int)min((long long)1024, (long long)((rows + 3) / 4));
+  const int blocks = ln_bwd_blocks(rows);
+  float *partial = reinterpret_cast<float *>(workspace);
 #define NRPN_LNB(K_) DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T, K_>), dim3(blocks), dim3(256), 0, st, (const T *)x, \
-    (const T *)dy, (T *)dx, gamma, mean, rstd, dgamma, dbeta, (long long)rows, c))
+    (const T *)dy, (T *)dx, gamma, mean, rstd, partial, (long long)rows, c))
   if (c <= 64 * 4) { NRPN_LNB(4); } else if (c <= 64 * 12) { NRPN_LNB(12); } else if (c <= 64 * 24) { NRPN_LNB(24); } else { NRPN_LNB(48); }
 #undef NRPN_LNB
+  hipLaunchKernelGGL(layernorm_param_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)partial, blocks, c, dgamma, dbeta);
   NRPN_LAUNCH_CHECK("layernorm_bwd");
   return NRPN_OK;
 }

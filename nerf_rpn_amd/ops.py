@@ -708,7 +708,8 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty(c, dtype=torch.float32, device=x.device)
         db = torch.empty(c, dtype=torch.float32, device=x.device)
-        call("layernorm_bwd", _p(x), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(dg), _p(db), x.numel() // c, c, _dt(x), _s())
+        ws = torch.empty(query("layernorm_workspace_bytes", x.numel() // c, c), dtype=torch.uint8, device=x.device)
+        call("layernorm_bwd", _p(x), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(dg), _p(db), x.numel() // c, c, _dt(x), _p(ws), _s())
         gs, bs = ctx.sinks
         if gs is not None:
             gs.slot.add_(dg)

@@ -94,7 +94,7 @@ def test_head_matches_oracle_on_identical_features(rot, ctr_on_reg, training, de
     gg = torch.autograd.grad(flat_g, fg + used_g, [d.to(dev) for d in dys])
     names = [f"feat{i}" for i in range(4)] + [n for n, _ in orc.named_parameters() if "scales.4" not in n]
     for n, a, r in zip(names, gg, go):
-        assert rel(a, r) < 1e-3, (n, rel(a, r))     # GroupNorm over 16-element groups (2-voxel level) amplifies fp32 rounding
+        assert rel(a, r) < 3e-3, (n, rel(a, r))     # GroupNorm over 64-element groups (8-voxel level) amplifies fp32 rounding
 
 
 @pytest.mark.parametrize("name", ["fcos_train_aabb_vgg", "fcos_train_aabb_giou_batch2", "fcos_train_obb_l1_proj"])
