@@ -291,6 +291,10 @@ int nrpn_patch_merge(const void *src, void *dst, int n, int gx, int gy, int gz, 
  * (shift 2 on every axis longer than one window, -100 mask between regions).  out [N,X,Y,Z,C] feeds the proj Linear.
  * Backward overwrites dqkv [N,X,Y,Z,3C], dtable f32 [343,heads] and dbias_pad f32 [3C] (gradient reaching the qkv bias
  * through padded tokens; may be NULL). */
+/* bf16 tensors run on MFMA kernels that compute the relative-position index as code(i) - code(j) + 171 (the reference's
+ * define_relative_position_index for a 4x4x4 window) instead of reading rel_index; nrpn_set_window_attn_mfma(0) selects the
+ * VALU kernels (always used for fp32). */
+int nrpn_set_window_attn_mfma(int on);
 int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, void *out,
                          int n, int gx, int gy, int gz, int c, int heads, int shift, int dtype, nrpn_stream_t stream);
 int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index,

@@ -489,6 +489,306 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T *__restrict
     if (tab[k] != 0.f) atomicAdd(dtable + k * g.heads + head, tab[k]);
 }
 
+// =====================================================================================================================
+// bf16 path: the same attention on the matrix cores.  One wavefront per (window, head); q/k/v/dO rows of the 64 tokens are
+// staged once in LDS ([64][32] bf16, 80-byte rows).  Products are formed in the TRANSPOSED orientation
+//     S^T[j][i] = sum_d K[j][d] Q[i][d]        (v_mfma_f32_32x32x16_bf16; D layout: lane = query i, registers = keys j)
+// so a softmax row lives in one lane pair (l, l ^ 32): 32 in-lane values + one cross-lane exchange.  The probabilities then
+// feed the next MFMA straight from registers as its B operand -- the k index of an MFMA is summed out, so A and B only have
+// to agree on the key each (lane half h, element e) stands for: j = 16 m + 4 h + (e & 3) + 8 (e >> 2), which is what the D
+// layout holds in registers 8m .. 8m+7; the matching A fragment (V^T, K^T, Q^T, dO^T) is two ds_read_b64_tr_b16 of four
+// consecutive rows each.  The backward also forms S, dP in the normal orientation (for dV, dK) with the row statistics
+// passed through LDS.  Relative-position index = code(i) - code(j) + 171 with code(t) = 49 (t/16) + 7 ((t/4)%4) + t%4
+// (the reference's define_relative_position_index for a 4x4x4 window, feature_extractor.py:562-576).
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8v;
+typedef __attribute__((ext_vector_type(4))) short s4v;
+constexpr int AROW = 80;                                    // bytes per staged token row (64 + 16 pad: conflict-free ds_read_b128)
+
+__device__ __forceinline__ int frow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int tok_code(int t) { return (t >> 4) * 49 + ((t >> 2) & 3) * 7 + (t & 3); }
+__device__ __forceinline__ f16v mma_bf16(f4 a, f4 b, f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+// 8 fp32 -> 8 bf16 packed as an MFMA operand
+__device__ __forceinline__ f4 pack8(const float *v) {
+  f4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = __uint_as_float((unsigned)f32_to_bf16_bits(v[2 * q]) | ((unsigned)f32_to_bf16_bits(v[2 * q + 1]) << 16));
+  return o;
+}
+// direct fragment: row (tile*32 + lane%32) of a staged tile, 8 consecutive d at kk*16 + (lane/32)*8
+__device__ __forceinline__ f4 row_frag(const char *tile, int t, int kk, int lane) {
+  return *reinterpret_cast<const f4 *>(tile + (t * 32 + (lane & 31)) * AROW + kk * 32 + (lane >> 5) * 16);
+}
+// transposed fragment: A[row d = lane%32][k <-> token row0 + {0..3, 8..11}] from a staged [token][d] tile
+__device__ __forceinline__ f4 tr_frag(const char *tile, int row0, int lane) {
+  const int p = lane & 15, dbase = 16 * ((lane >> 4) & 1);
+  const char *a0 = tile + (row0 + (p >> 2)) * AROW + (dbase + 4 * (p & 3)) * 2;
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0 + 8 * AROW));
+  typedef __attribute__((ext_vector_type(2))) long long l2v;
+  l2v r = {__builtin_bit_cast(long long, lo), __builtin_bit_cast(long long, hi)};
+  return __builtin_bit_cast(f4, r);
+}
+// stage the 32 bf16 of token `lane` (or the bias vector for a padded token) into row `lane` of an LDS tile
+__device__ __forceinline__ void stage_row(char *tile, int lane, const bf16s *src, const float *bias, bool real) {
+  f4 *dst = reinterpret_cast<f4 *>(tile + lane * AROW);
+  if (real) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f4 *>(src + 8 * q);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bias ? bias[8 * q + e] : 0.f;
+      dst[q] = pack8(v);
+    }
+  }
+}
+
+struct AttnRows { long long row[2]; bool real[2]; };
+
+// S^T (or dP^T) style product of two staged tiles X (A operand, rows -> D rows) and Y (B operand, rows -> D columns)
+__device__ __forceinline__ void tile_product(const char *X, const char *Y, int lane, f16v (&d)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc = mma_bf16(row_frag(X, a, kk, lane), row_frag(Y, b, kk, lane), acc);
+      d[a][b] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(64) window_attn_fwd_mfma_kernel(const bf16s *__restrict__ qkv, const float *__restrict__ qkv_bias,
+                                                                  const float *__restrict__ bias_table, bf16s *__restrict__ out, AttnGeom g) {
+  __shared__ __attribute__((aligned(16))) char Qs[64 * AROW], Ks[64 * AROW], Vs[64 * AROW];
+  __shared__ float tabv[343];
+  __shared__ int reg[64];
+  const int w = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+  const bool shifted = (g.sx + g.sy + g.sz) > 0;
+  const int C = g.C, off = head * HD;
+  {
+    long long row; int region;
+    const bool real = attn_token(g, w, lane, row, region);
+    reg[lane] = region;
+    const bf16s *src = qkv + row * 3 * C + off;
+    stage_row(Qs, lane, src, qkv_bias ? qkv_bias + off : nullptr, real);
+    stage_row(Ks, lane, src + C, qkv_bias ? qkv_bias + C + off : nullptr, real);
+    stage_row(Vs, lane, src + 2 * C, qkv_bias ? qkv_bias + 2 * C + off : nullptr, real);
+    for (int k = lane; k < 343; k += 64) tabv[k] = bias_table[k * g.heads + head];
+  }
+  __syncthreads();
+  const float scale = 0.17677669529663687f;
+  f16v st[2][2];                                   // st[tj][ti]: rows = keys j, columns = queries i
+  tile_product(Ks, Qs, lane, st);
+  float mx[2] = {-INFINITY, -INFINITY}, den[2] = {0.f, 0.f};
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int i = ti * 32 + (lane & 31), ci = tok_code(i) + 171, ri = reg[i];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = tj * 32 + frow(r, lane);
+        float v = st[tj][ti][r] * scale + tabv[ci - tok_code(j)];
+        if (shifted && reg[j] != ri) v += -100.0f;
+        st[tj][ti][r] = v;
+        mx[ti] = fmaxf(mx[ti], v);
+      }
+    mx[ti] = fmaxf(mx[ti], __shfl_xor(mx[ti], 32, 64));
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float e = expf(st[tj][ti][r] - mx[ti]); st[tj][ti][r] = e; den[ti] += e; }
+    den[ti] += __shfl_xor(den[ti], 32, 64);
+  }
+  // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float inv = 1.0f / den[ti];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = st[tj][ti][8 * m + e] * inv;
+        acc = mma_bf16(tr_frag(Vs, tj * 32 + 16 * m + 4 * (lane >> 5), lane), pack8(pv), acc);
+      }
+    long long row; int region;
+    if (attn_token(g, w, ti * 32 + (lane & 31), row, region)) {
+      bf16s *dst = out + row * C + off;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {           // registers 4q..4q+3 are d = 8q + 4h + 0..3: one 8-byte store
+        us4 o = {f32_to_bf16_bits(acc[4 * q]), f32_to_bf16_bits(acc[4 * q + 1]), f32_to_bf16_bits(acc[4 * q + 2]), f32_to_bf16_bits(acc[4 * q + 3])};
+        *reinterpret_cast<us4 *>(dst + 8 * q + 4 * (lane >> 5)) = o;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16s *__restrict__ qkv, const float *__restrict__ qkv_bias,
+                                                                  const float *__restrict__ bias_table, const bf16s *__restrict__ dout,
+                                                                  bf16s *__restrict__ dqkv, float *__restrict__ dtable,
+                                                                  float *__restrict__ dbias_pad, AttnGeom g) {
+  __shared__ __attribute__((aligned(16))) char Qs[64 * AROW], Ks[64 * AROW], Vs[64 * AROW], Ds[64 * AROW];
+  __shared__ float tabv[343], tabg[343], smax[64], sinv[64], sdot[64];
+  __shared__ int reg[64];
+  const int w = blockIdx.x, head = blockIdx.y, lane = threadIdx.x, h = lane >> 5;
+  const bool shifted = (g.sx + g.sy + g.sz) > 0;
+  const int C = g.C, off = head * HD;
+  AttnRows tk;                                     // the two tokens (tile 0 / 1) this lane owns as a D-layout column
+  {
+    long long row; int region;
+    const bool real = attn_token(g, w, lane, row, region);
+    reg[lane] = region;
+    const bf16s *src = qkv + row * 3 * C + off;
+    stage_row(Qs, lane, src, qkv_bias ? qkv_bias + off : nullptr, real);
+    stage_row(Ks, lane, src + C, qkv_bias ? qkv_bias + C + off : nullptr, real);
+    stage_row(Vs, lane, src + 2 * C, qkv_bias ? qkv_bias + 2 * C + off : nullptr, real);
+    stage_row(Ds, lane, dout + row * C + off, nullptr, real);            // outputs of padded queries are discarded: dO = 0
+    for (int k = lane; k < 343; k += 64) { tabv[k] = bias_table[k * g.heads + head]; tabg[k] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { int rg; tk.real[t] = attn_token(g, w, t * 32 + (lane & 31), tk.row[t], rg); }
+  }
+  __syncthreads();
+  const float scale = 0.17677669529663687f;
+
+  // ---------------- transposed orientation: lane = query i, registers = keys j
+  {
+    f16v st[2][2], dp[2][2];
+    tile_product(Ks, Qs, lane, st);                // S^T
+    tile_product(Vs, Ds, lane, dp);                // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const int i = ti * 32 + (lane & 31), ci = tok_code(i) + 171, ri = reg[i];
+      float mx = -INFINITY, den = 0.f, dot = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = tj * 32 + frow(r, lane);
+          float v = st[tj][ti][r] * scale + tabv[ci - tok_code(j)];
+          if (shifted && reg[j] != ri) v += -100.0f;
+          st[tj][ti][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = expf(st[tj][ti][r] - mx); st[tj][ti][r] = e; den += e; }
+      den += __shfl_xor(den, 32, 64);
+      const float inv = 1.0f / den;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[tj][ti][r] *= inv; dot += st[tj][ti][r] * dp[tj][ti][r]; }
+      dot += __shfl_xor(dot, 32, 64);
+      if (h == 0) { smax[i] = mx; sinv[i] = inv; sdot[i] = dot; }
+      // dS^T = P^T (dP^T - rowdot); bias-table gradient; dq^T[d][i] = scale sum_j K^T[d][j] dS^T[j][i]
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ds = st[tj][ti][r] * (dp[tj][ti][r] - dot);
+          dp[tj][ti][r] = ds;
+          atomicAdd(&tabg[ci - tok_code(tj * 32 + frow(r, lane))], ds);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float v8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v8[e] = dp[tj][ti][8 * m + e];
+          acc = mma_bf16(tr_frag(Ks, tj * 32 + 16 * m + 4 * h, lane), pack8(v8), acc);
+        }
+      }
+      if (tk.real[ti]) {
+        bf16s *dst = dqkv + tk.row[ti] * 3 * C + off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          us4 o = {f32_to_bf16_bits(acc[4 * q] * scale), f32_to_bf16_bits(acc[4 * q + 1] * scale), f32_to_bf16_bits(acc[4 * q + 2] * scale),
+                   f32_to_bf16_bits(acc[4 * q + 3] * scale)};
+          *reinterpret_cast<us4 *>(dst + 8 * q + 4 * h) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- normal orientation: lane = key j, registers = queries i  (P and dS as B operands with k = i)
+  {
+    f16v sn[2][2], dn[2][2];                       // [ti][tj]
+    tile_product(Qs, Ks, lane, sn);                // S[i][j]
+    tile_product(Ds, Vs, lane, dn);                // dP[i][j]
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int j = tj * 32 + (lane & 31), cj = tok_code(j), rj = reg[j];
+      f16v accv, acck;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accv[r] = 0.f; acck[r] = 0.f; }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = ti * 32 + frow(r, lane);
+          float v = sn[ti][tj][r] * scale + tabv[tok_code(i) + 171 - cj];
+          if (shifted && reg[i] != rj) v += -100.0f;
+          const float p = expf(v - smax[i]) * sinv[i];
+          sn[ti][tj][r] = p;
+          dn[ti][tj][r] = p * (dn[ti][tj][r] - sdot[i]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float p8[8], s8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { p8[e] = sn[ti][tj][8 * m + e]; s8[e] = dn[ti][tj][8 * m + e]; }
+          const int row0 = ti * 32 + 16 * m + 4 * h;
+          accv = mma_bf16(tr_frag(Ds, row0, lane), pack8(p8), accv);     // dV^T[d][j] += dO^T[d][i] P[i][j]
+          acck = mma_bf16(tr_frag(Qs, row0, lane), pack8(s8), acck);     // dK^T[d][j] += Q^T[d][i] dS[i][j]
+        }
+      }
+      if (tk.real[tj]) {
+        bf16s *dst = dqkv + tk.row[tj] * 3 * C + off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          us4 ok = {f32_to_bf16_bits(acck[4 * q] * scale), f32_to_bf16_bits(acck[4 * q + 1] * scale), f32_to_bf16_bits(acck[4 * q + 2] * scale),
+                    f32_to_bf16_bits(acck[4 * q + 3] * scale)};
+          us4 ov = {f32_to_bf16_bits(accv[4 * q]), f32_to_bf16_bits(accv[4 * q + 1]), f32_to_bf16_bits(accv[4 * q + 2]), f32_to_bf16_bits(accv[4 * q + 3])};
+          *reinterpret_cast<us4 *>(dst + C + 8 * q + 4 * h) = ok;
+          *reinterpret_cast<us4 *>(dst + 2 * C + 8 * q + 4 * h) = ov;
+        }
+      } else if (dbias_pad) {     // padded tokens carry the bias vectors as k and v: their gradient goes to the qkv bias
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = frow(r, lane);
+          atomicAdd(dbias_pad + C + off + d, acck[r] * scale);
+          atomicAdd(dbias_pad + 2 * C + off + d, accv[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = lane; k < 343; k += 64)
+    if (tabg[k] != 0.f) atomicAdd(dtable + k * g.heads + head, tabg[k]);
+}
+
+static int g_attn_mfma = 1;   // 1: bf16 tensors use the MFMA kernels (standard relative-position index assumed), 0: always the VALU kernels
+extern "C" int nrpn_set_window_attn_mfma(int on) { g_attn_mfma = on ? 1 : 0; return NRPN_OK; }
+
 static int fill_geom(AttnGeom &g, int n, int gx, int gy, int gz, int c, int heads, int shift) {
   if (n <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || heads <= 0 || c != heads * HD)
     return nrpn_fail(NRPN_ERR_ARG, "window_attn: C (%d) must equal heads (%d) * 32", c, heads);
@@ -506,8 +806,13 @@ extern "C" int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, cons
   if (int rc = fill_geom(g, n, gx, gy, gz, c, heads, shift)) return rc;
   NRPN_REQUIRE(qkv && bias_table && rel_index && out, "window_attn_fwd: null pointer");
   dim3 grid((unsigned)(n * (g.px / WS) * (g.py / WS) * (g.pz / WS)), (unsigned)heads);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_fwd_kernel<T>, grid, dim3(64), 0, as_stream(stream), (const T *)qkv, qkv_bias, bias_table,
-                                       rel_index, (T *)out, g));
+  if (dtype == NRPN_BF16 && g_attn_mfma) {
+    hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, grid, dim3(64), 0, as_stream(stream), (const bf16s *)qkv, qkv_bias, bias_table,
+                       (bf16s *)out, g);
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_fwd_kernel<T>, grid, dim3(64), 0, as_stream(stream), (const T *)qkv, qkv_bias, bias_table,
+                                         rel_index, (T *)out, g));
+  }
   NRPN_LAUNCH_CHECK("window_attn_fwd");
   return NRPN_OK;
 }
@@ -522,8 +827,13 @@ extern "C" int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, cons
   NRPN_HIP(hipMemsetAsync(dtable, 0, (size_t)343 * heads * 4, st));
   if (dbias_pad) NRPN_HIP(hipMemsetAsync(dbias_pad, 0, (size_t)3 * c * 4, st));
   dim3 grid((unsigned)(n * (g.px / WS) * (g.py / WS) * (g.pz / WS)), (unsigned)heads);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_bwd_kernel<T>, grid, dim3(64), 0, st, (const T *)qkv, qkv_bias, bias_table, rel_index,
-                                       (const T *)dout, (T *)dqkv, dtable, dbias_pad, g));
+  if (dtype == NRPN_BF16 && g_attn_mfma) {
+    hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16s *)qkv, qkv_bias, bias_table, (const bf16s *)dout,
+                       (bf16s *)dqkv, dtable, dbias_pad, g);
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_bwd_kernel<T>, grid, dim3(64), 0, st, (const T *)qkv, qkv_bias, bias_table, rel_index,
+                                         (const T *)dout, (T *)dqkv, dtable, dbias_pad, g));
+  }
   NRPN_LAUNCH_CHECK("window_attn_bwd");
   return NRPN_OK;
 }

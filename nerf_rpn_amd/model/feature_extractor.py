@@ -253,6 +253,11 @@ class ShiftedWindowAttention(nn.Module):
         idx = self.__dict__.get("_nrpn_idx32")
         if idx is None or idx.device != self.relative_position_index.device:
             idx = self.relative_position_index.to(torch.int32).contiguous()
+            # the bf16 MFMA attention kernels compute this index arithmetically: make sure a loaded checkpoint agrees
+            t = torch.arange(64, device=idx.device)
+            code = (t // 16) * 49 + ((t // 4) % 4) * 7 + t % 4
+            if not torch.equal(idx.view(64, 64).long(), code[:, None] - code[None, :] + 171):
+                raise NotImplementedError("relative_position_index differs from the reference's 4x4x4 window formula")
             self.__dict__["_nrpn_idx32"] = idx
         return idx
 

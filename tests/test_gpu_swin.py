@@ -145,3 +145,31 @@ def test_swin_bf16_close_to_fp32(dev):
         f16 = bb(x)
     for a, b in zip(f16, f32):
         assert a.dtype == torch.bfloat16 and rel(a.float(), b) < 0.06, rel(a.float(), b)
+
+
+@pytest.mark.parametrize("shape,heads,shift", [((2, 8, 8, 8), 3, 0), ((1, 10, 7, 6), 6, 2), ((2, 5, 4, 3), 12, 2), ((1, 12, 9, 4), 3, 2)])
+def test_bf16_mfma_attention_matches_valu_kernels(shape, heads, shift, dev):
+    """bf16 tensors run the attention on the matrix cores (transposed-orientation MFMA kernels); same bf16 inputs through the
+    VALU kernels (fp32 math, checked against the oracle above) must agree up to bf16 rounding of the probabilities, forward
+    and backward (dq/dk/dv through the qkv Linear, bias table, qkv bias incl. the padded-token path)."""
+    from nerf_rpn_amd import lib
+    from nerf_rpn_amd.model.feature_extractor import ShiftedWindowAttention
+    b, h, w, d = shape
+    c = 32 * heads
+    att = ShiftedWindowAttention(c, [4, 4, 4], [shift] * 3, heads)
+    seeded_state(att, 3)
+    att = att.to(dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, h, w, d, c, generator=g).to(dev).bfloat16()
+    dy = torch.randn(b, h, w, d, c, generator=g).to(dev).bfloat16()
+    res = {}
+    for mode in (0, 1):
+        lib.call("set_window_attn_mfma", mode)
+        xg = x.clone().requires_grad_()
+        y = att(xg)
+        grads = torch.autograd.grad(y, [xg] + list(att.parameters()), dy)
+        res[mode] = [y.float()] + [t.float() for t in grads]
+    lib.call("set_window_attn_mfma", 1)
+    names = ["y", "x"] + [n for n, _ in att.named_parameters()]
+    for n, a, r in zip(names, res[1], res[0]):
+        assert rel(a, r) < 3e-2, (n, rel(a, r))
