@@ -290,16 +290,18 @@ int nrpn_patch_merge(const void *src, void *dst, int n, int gx, int gy, int gz, 
  * may be NULL), bias_table f32 [343,heads], rel_index i32 [64*64]; shift != 0 selects the shifted-window variant
  * (shift 2 on every axis longer than one window, -100 mask between regions).  out [N,X,Y,Z,C] feeds the proj Linear.
  * Backward overwrites dqkv [N,X,Y,Z,3C], dtable f32 [343,heads] and dbias_pad f32 [3C] (gradient reaching the qkv bias
- * through padded tokens; may be NULL). */
+ * through padded tokens; may be NULL).  Every (window, head) unit writes its partial bias-table gradient to `workspace`
+ * (nrpn_window_attn_bwd_workspace_bytes) and a second kernel sums them: no same-address atomics, deterministic. */
 /* bf16 tensors run on MFMA kernels that compute the relative-position index as code(i) - code(j) + 171 (the reference's
  * define_relative_position_index for a 4x4x4 window) instead of reading rel_index; nrpn_set_window_attn_mfma(0) selects the
  * VALU kernels (always used for fp32). */
 int nrpn_set_window_attn_mfma(int on);
 int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, void *out,
                          int n, int gx, int gy, int gz, int c, int heads, int shift, int dtype, nrpn_stream_t stream);
+size_t nrpn_window_attn_bwd_workspace_bytes(int n, int gx, int gy, int gz, int heads);
 int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index,
                          const void *dout, void *dqkv, float *dtable, float *dbias_pad, int n, int gx, int gy, int gz, int c,
-                         int heads, int shift, int dtype, nrpn_stream_t stream);
+                         int heads, int shift, int dtype, void *workspace, nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FCOS variant of the path.  [a23]  (model/fcos/fcos.py, inference.py, loss.py, utils.py)

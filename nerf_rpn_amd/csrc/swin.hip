@@ -367,11 +367,11 @@ __global__ void __launch_bounds__(64) window_attn_fwd_kernel(const T *__restrict
 template <typename T>
 __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T *__restrict__ qkv, const float *__restrict__ qkv_bias,
                                                              const float *__restrict__ bias_table, const int *__restrict__ rel_index,
-                                                             const T *__restrict__ dout, T *__restrict__ dqkv, float *__restrict__ dtable,
+                                                             const T *__restrict__ dout, T *__restrict__ dqkv, float *__restrict__ tabws,
                                                              float *__restrict__ dbias_pad, AttnGeom g) {
   __shared__ float K[WT][HD + 1], V[WT][HD + 1], Q[WT][HD + 1], DO[WT][HD + 1];
   __shared__ float M[WT][WT + 1];
-  __shared__ float tab[343];
+  __shared__ float tab[343], padacc[2 * HD];
   __shared__ int reg[WT];
   const int w = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
   const bool shifted = (g.sx + g.sy + g.sz) > 0;
@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T *__restrict
   const float scale = 0.17677669529663687f;
   const int C = g.C, off = head * HD;
   for (int k = i; k < 343; k += 64) tab[k] = 0.f;
+  padacc[i] = 0.f;
   float q[HD], dO[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) {
@@ -429,9 +430,9 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T *__restrict
     if (real) {
 #pragma unroll
       for (int d = 0; d < HD; ++d) elem<T>::st(dqkv + row * 3 * C + 2 * C + off + d, dv[d]);
-    } else if (dbias_pad) {   // padded tokens carry the bias vectors as k and v: their gradient goes to the qkv bias
+    } else if (dbias_pad) {   // padded tokens carry the bias vectors as k and v: their gradient goes to the qkv bias (LDS first)
 #pragma unroll
-      for (int d = 0; d < HD; ++d) atomicAdd(dbias_pad + 2 * C + off + d, dv[d]);
+      for (int d = 0; d < HD; ++d) atomicAdd(&padacc[HD + d], dv[d]);
     }
   }
   // rowdot_i = sum_j dP_ij P_ij
@@ -482,11 +483,13 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T *__restrict
       for (int d = 0; d < HD; ++d) elem<T>::st(dqkv + row * 3 * C + C + off + d, dk[d]);
     } else if (dbias_pad) {
 #pragma unroll
-      for (int d = 0; d < HD; ++d) atomicAdd(dbias_pad + C + off + d, dk[d]);
+      for (int d = 0; d < HD; ++d) atomicAdd(&padacc[d], dk[d]);
     }
   }
-  for (int k = i; k < 343; k += 64)
-    if (tab[k] != 0.f) atomicAdd(dtable + k * g.heads + head, tab[k]);
+  __syncthreads();
+  if (dbias_pad && padacc[i] != 0.f) atomicAdd(dbias_pad + (i < HD ? C + off + i : 2 * C + off + i - HD), padacc[i]);
+  float *tw = tabws + ((long long)w * g.heads + head) * 343;       // this unit's partial table (summed by attn_table_reduce_kernel)
+  for (int k = i; k < 343; k += 64) tw[k] = tab[k];
 }
 
 // =====================================================================================================================
@@ -639,10 +642,10 @@ __global__ void __launch_bounds__(64) window_attn_fwd_mfma_kernel(const bf16s *_
 
 __global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16s *__restrict__ qkv, const float *__restrict__ qkv_bias,
                                                                   const float *__restrict__ bias_table, const bf16s *__restrict__ dout,
-                                                                  bf16s *__restrict__ dqkv, float *__restrict__ dtable,
+                                                                  bf16s *__restrict__ dqkv, float *__restrict__ tabws,
                                                                   float *__restrict__ dbias_pad, AttnGeom g) {
   __shared__ __attribute__((aligned(16))) char Qs[64 * AROW], Ks[64 * AROW], Vs[64 * AROW], Ds[64 * AROW];
-  __shared__ float tabv[343], tabg[343], smax[64], sinv[64], sdot[64];
+  __shared__ float tabv[343], tabg[343], smax[64], sinv[64], sdot[64], padacc[64];
   __shared__ int reg[64];
   const int w = blockIdx.x, head = blockIdx.y, lane = threadIdx.x, h = lane >> 5;
   const bool shifted = (g.sx + g.sy + g.sz) > 0;
@@ -658,6 +661,7 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16s *_
     stage_row(Vs, lane, src + 2 * C, qkv_bias ? qkv_bias + 2 * C + off : nullptr, real);
     stage_row(Ds, lane, dout + row * C + off, nullptr, real);            // outputs of padded queries are discarded: dO = 0
     for (int k = lane; k < 343; k += 64) { tabv[k] = bias_table[k * g.heads + head]; tabg[k] = 0.f; }
+    padacc[lane] = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) { int rg; tk.real[t] = attn_token(g, w, t * 32 + (lane & 31), tk.row[t], rg); }
   }
@@ -771,19 +775,41 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16s *_
           *reinterpret_cast<us4 *>(dst + C + 8 * q + 4 * h) = ok;
           *reinterpret_cast<us4 *>(dst + 2 * C + 8 * q + 4 * h) = ov;
         }
-      } else if (dbias_pad) {     // padded tokens carry the bias vectors as k and v: their gradient goes to the qkv bias
+      } else if (dbias_pad) {     // padded tokens carry the bias vectors as k and v: their gradient goes to the qkv bias (LDS first)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int d = frow(r, lane);
-          atomicAdd(dbias_pad + C + off + d, acck[r] * scale);
-          atomicAdd(dbias_pad + 2 * C + off + d, accv[r]);
+          atomicAdd(&padacc[d], acck[r] * scale);
+          atomicAdd(&padacc[32 + d], accv[r]);
         }
       }
     }
   }
   __syncthreads();
-  for (int k = lane; k < 343; k += 64)
-    if (tabg[k] != 0.f) atomicAdd(dtable + k * g.heads + head, tabg[k]);
+  if (dbias_pad && padacc[lane] != 0.f) atomicAdd(dbias_pad + (lane < 32 ? C + off + lane : 2 * C + off + lane - 32), padacc[lane]);
+  float *tw = tabws + ((long long)w * g.heads + head) * 343;       // this unit's partial table (summed by attn_table_reduce_kernel)
+  for (int k = lane; k < 343; k += 64) tw[k] = tabg[k];
+}
+
+// dtable[k][head] = sum over the windows' partial tables; block = (64 table entries, 16 window lanes), grid = (6, heads)
+__global__ void attn_table_reduce_kernel(const float *__restrict__ tabws, float *__restrict__ dtable, int windows, int heads) {
+  __shared__ float red[16][64];
+  const int head = blockIdx.y, k = blockIdx.x * 64 + threadIdx.x;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (k < 343) {
+    int w = threadIdx.y;
+    for (; w + 48 < windows; w += 64)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += tabws[((long long)(w + 16 * u) * heads + head) * 343 + k];
+    for (; w < windows; w += 16) a[0] += tabws[((long long)w * heads + head) * 343 + k];
+  }
+  red[threadIdx.y][threadIdx.x] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+  if (threadIdx.y == 0 && k < 343) {
+    float sum = 0.f;
+    for (int q = 0; q < 16; ++q) sum += red[q][threadIdx.x];
+    dtable[k * heads + head] = sum;
+  }
 }
 
 static int g_attn_mfma = 1;   // 1: bf16 tensors use the MFMA kernels (standard relative-position index assumed), 0: always the VALU kernels
@@ -817,23 +843,30 @@ extern "C" int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, cons
   return NRPN_OK;
 }
 
+extern "C" size_t nrpn_window_attn_bwd_workspace_bytes(int n, int gx, int gy, int gz, int heads) {
+  const long long windows = (long long)n * ((gx + WS - 1) / WS) * ((gy + WS - 1) / WS) * ((gz + WS - 1) / WS);
+  return (size_t)(windows * heads * 343 * 4);
+}
+
 extern "C" int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, const void *dout,
                                     void *dqkv, float *dtable, float *dbias_pad, int n, int gx, int gy, int gz, int c, int heads, int shift,
-                                    int dtype, nrpn_stream_t stream) {
+                                    int dtype, void *workspace, nrpn_stream_t stream) {
   AttnGeom g;
   if (int rc = fill_geom(g, n, gx, gy, gz, c, heads, shift)) return rc;
-  NRPN_REQUIRE(qkv && bias_table && rel_index && dout && dqkv && dtable, "window_attn_bwd: null pointer");
+  NRPN_REQUIRE(qkv && bias_table && rel_index && dout && dqkv && dtable && workspace, "window_attn_bwd: null pointer");
   hipStream_t st = as_stream(stream);
-  NRPN_HIP(hipMemsetAsync(dtable, 0, (size_t)343 * heads * 4, st));
   if (dbias_pad) NRPN_HIP(hipMemsetAsync(dbias_pad, 0, (size_t)3 * c * 4, st));
-  dim3 grid((unsigned)(n * (g.px / WS) * (g.py / WS) * (g.pz / WS)), (unsigned)heads);
+  const int windows = n * (g.px / WS) * (g.py / WS) * (g.pz / WS);
+  float *tabws = reinterpret_cast<float *>(workspace);
+  dim3 grid((unsigned)windows, (unsigned)heads);
   if (dtype == NRPN_BF16 && g_attn_mfma) {
     hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16s *)qkv, qkv_bias, bias_table, (const bf16s *)dout,
-                       (bf16s *)dqkv, dtable, dbias_pad, g);
+                       (bf16s *)dqkv, tabws, dbias_pad, g);
   } else {
     DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_bwd_kernel<T>, grid, dim3(64), 0, st, (const T *)qkv, qkv_bias, bias_table, rel_index,
-                                         (const T *)dout, (T *)dqkv, dtable, dbias_pad, g));
+                                         (const T *)dout, (T *)dqkv, tabws, dbias_pad, g));
   }
+  hipLaunchKernelGGL(attn_table_reduce_kernel, dim3(6, heads), dim3(64, 16), 0, st, (const float *)tabws, dtable, windows, heads);
   NRPN_LAUNCH_CHECK("window_attn_bwd");
   return NRPN_OK;
 }

@@ -814,8 +814,9 @@ class WindowAttnFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dtable = torch.empty_like(t32)
         dpad = torch.empty(c3, dtype=torch.float32, device=qkv.device) if (padded and qb is not None) else None
+        ws = torch.empty(query("window_attn_bwd_workspace_bytes", n, gx, gy, gz, heads), dtype=torch.uint8, device=qkv.device)
         call("window_attn_bwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(dout), _p(dqkv), _p(dtable), _p(dpad), n, gx, gy, gz, c, heads,
-             shift, _dt(qkv), _s())
+             shift, _dt(qkv), _p(ws), _s())
         return dqkv, dpad, dtable, None, None, None
 
 
