@@ -202,41 +202,69 @@ extern "C" int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const
 // =====================================================================================================================
 // exact GELU (nn.GELU default) and the residual join y = a + s[n] * b (s = stochastic-depth row scale, or 1)
 // =====================================================================================================================
+// 4 elements per thread (8/16-byte accesses) when the count allows it
+template <typename T> struct ev4;
+template <> struct ev4<float> {
+  static __device__ __forceinline__ void ld(const float *p, float *v) { const f4 t = *reinterpret_cast<const f4 *>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+  static __device__ __forceinline__ void st(float *p, const float *v) { f4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4 *>(p) = t; }
+};
+template <> struct ev4<bf16s> {
+  static __device__ __forceinline__ void ld(const bf16s *p, float *v) {
+    const us4 t = *reinterpret_cast<const us4 *>(p);
+    v[0] = bf16_bits_to_f32(t[0]); v[1] = bf16_bits_to_f32(t[1]); v[2] = bf16_bits_to_f32(t[2]); v[3] = bf16_bits_to_f32(t[3]);
+  }
+  static __device__ __forceinline__ void st(bf16s *p, const float *v) {
+    us4 t = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+    *reinterpret_cast<us4 *>(p) = t;
+  }
+};
+
 template <typename T, bool BWD>
-__global__ void gelu_kernel(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ out, long long count) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
-    const float v = elem<T>::ld(x + i);
-    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
-    if (!BWD) elem<T>::st(out + i, v * cdf);
-    else elem<T>::st(out + i, elem<T>::ld(dy + i) * (cdf + v * 0.39894228040143268f * expf(-0.5f * v * v)));
+__global__ void gelu_kernel(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ out, long long groups) {
+  for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
+    float v[4], d[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+    ev4<T>::ld(x + gi * 4, v);
+    if (BWD) ev4<T>::ld(dy + gi * 4, d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float cdf = 0.5f * (1.0f + erff(v[k] * 0.70710678118654752f));
+      o[k] = BWD ? d[k] * (cdf + v[k] * 0.39894228040143268f * expf(-0.5f * v[k] * v[k])) : v[k] * cdf;
+    }
+    ev4<T>::st(out + gi * 4, o);
   }
 }
 
 extern "C" int nrpn_gelu(const void *x, const void *dy, void *out, int64_t count, int backward, int dtype, nrpn_stream_t stream) {
-  NRPN_REQUIRE(x && out && count > 0 && (!backward || dy), "gelu: bad args");
-  if (backward) { DISPATCH_T(dtype, hipLaunchKernelGGL((gelu_kernel<T, true>), dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream),
-                                                       (const T *)x, (const T *)dy, (T *)out, (long long)count)); }
-  else { DISPATCH_T(dtype, hipLaunchKernelGGL((gelu_kernel<T, false>), dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), (const T *)x,
-                                              (const T *)nullptr, (T *)out, (long long)count)); }
+  NRPN_REQUIRE(x && out && count > 0 && count % 4 == 0 && (!backward || dy), "gelu: bad args (count must be a multiple of 4)");
+  const long long groups = count / 4;
+  if (backward) { DISPATCH_T(dtype, hipLaunchKernelGGL((gelu_kernel<T, true>), dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream),
+                                                       (const T *)x, (const T *)dy, (T *)out, groups)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((gelu_kernel<T, false>), dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream), (const T *)x,
+                                              (const T *)nullptr, (T *)out, groups)); }
   NRPN_LAUNCH_CHECK("gelu");
   return NRPN_OK;
 }
 
 template <typename T>
 __global__ void scale_add_kernel(const T *__restrict__ a, const T *__restrict__ b, const float *__restrict__ scale, T *__restrict__ y,
-                                 long long per_sample, long long count) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
-    const float s = scale ? scale[i / per_sample] : 1.0f;
-    elem<T>::st(y + i, (a ? elem<T>::ld(a + i) : 0.f) + s * elem<T>::ld(b + i));
+                                 long long per_sample, long long groups) {
+  for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
+    const float s = scale ? scale[gi * 4 / per_sample] : 1.0f;
+    float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4], o[4];
+    if (a) ev4<T>::ld(a + gi * 4, av);
+    ev4<T>::ld(b + gi * 4, bv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = av[k] + s * bv[k];
+    ev4<T>::st(y + gi * 4, o);
   }
 }
 
 extern "C" int nrpn_scale_add(const void *a, const void *b, const float *scale, void *y, int n, int64_t per_sample, int dtype,
                               nrpn_stream_t stream) {
-  NRPN_REQUIRE(b && y && n > 0 && per_sample > 0, "scale_add: bad args");
-  const long long count = (long long)n * per_sample;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(scale_add_kernel<T>, dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), (const T *)a, (const T *)b,
-                                       scale, (T *)y, (long long)per_sample, count));
+  NRPN_REQUIRE(b && y && n > 0 && per_sample > 0 && per_sample % 4 == 0, "scale_add: bad args (per_sample must be a multiple of 4)");
+  const long long groups = (long long)n * per_sample / 4;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(scale_add_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream), (const T *)a, (const T *)b,
+                                       scale, (T *)y, (long long)per_sample, groups));
   NRPN_LAUNCH_CHECK("scale_add");
   return NRPN_OK;
 }
