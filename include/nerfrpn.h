@@ -256,6 +256,11 @@ int nrpn_upsample_add_bwd(const void *dfine, void *dcoarse, int n, int fx, int f
 int nrpn_subsample3d(const void *src, void *dst, int n, int gx, int gy, int gz, int c, int stride, int backward, int dtype,
                      nrpn_stream_t stream);
 int nrpn_add_relu(const void *a, const void *b, void *y, int64_t count, int relu, int dtype, nrpn_stream_t stream);
+/* Scene ingest [a1] (datasets.py:39-63,165-167; ScanNet :227-231): src = the on-disk (W,L,H,4) rgb-sigma array (f32, or uint8
+ * -> /255) on the device; dst = channels-last [W,L,H,4] in the compute dtype; alpha_mode 0 none, 1 density_to_alpha
+ * clip(1-exp(-exp(s)/100),0,1), 2 the ScanNet variant clip(1-exp(-max(s,0)/100),0,1) on channel 3.  One pass instead of
+ * numpy alpha + host transpose + H2D of fp32 + device transpose. */
+int nrpn_ingest_rgbsigma(const void *src, int src_is_u8, void *dst, int64_t voxels, int alpha_mode, int dtype, nrpn_stream_t stream);
 /* layout / dtype conversion between the reference's [N,C,X,Y,Z] f32 and channels-last f32|bf16 */
 int nrpn_ncdhw_to_ndhwc(const float *src, void *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
 int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);

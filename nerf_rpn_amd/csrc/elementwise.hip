@@ -688,3 +688,33 @@ extern "C" int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, 
   NRPN_LAUNCH_CHECK("adamw_step");
   return NRPN_OK;
 }
+
+// =====================================================================================================================
+// scene ingest (reference datasets.py:39-63, 165-167, 227-231): the on-disk (W,L,H,4) rgb-sigma array is already the
+// channels-last activation layout -- one pass applies uint8 -> /255, density_to_alpha on channel 3 and the cast to the
+// compute dtype, instead of numpy alpha + host transpose + float conversion + a device transpose back.
+// =====================================================================================================================
+template <typename S, typename T>
+__global__ void ingest_kernel(const S *__restrict__ src, T *__restrict__ dst, long long voxels, int mode) {
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < voxels; v += (long long)gridDim.x * blockDim.x) {
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = sizeof(S) == 1 ? (float)src[v * 4 + k] * (1.0f / 255.0f) : (float)src[v * 4 + k];
+    if (mode == 1) c[3] = fminf(fmaxf(1.0f - expf(-expf(c[3]) / 100.0f), 0.f), 1.f);                 // density_to_alpha
+    else if (mode == 2) c[3] = fminf(fmaxf(1.0f - expf(-fmaxf(c[3], 0.f) / 100.0f), 0.f), 1.f);     // ScanNet variant (relu)
+    f4 o = {c[0], c[1], c[2], c[3]};
+    vec4<T>::st(dst + v * 4, o);
+  }
+}
+
+extern "C" int nrpn_ingest_rgbsigma(const void *src, int src_is_u8, void *dst, int64_t voxels, int alpha_mode, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && dst && voxels > 0 && alpha_mode >= 0 && alpha_mode <= 2, "ingest_rgbsigma: bad args");
+  NRPN_REQUIRE(!(src_is_u8 && alpha_mode), "ingest_rgbsigma: density_to_alpha on uint8 grids follows numpy's float16/uint8 casts in the "
+                                           "reference and is only available on the host path");
+  const int blocks = (int)min((long long)8192, (long long)((voxels + 255) / 256));
+  hipStream_t st = as_stream(stream);
+  if (src_is_u8) { DISPATCH_T(dtype, hipLaunchKernelGGL((ingest_kernel<unsigned char, T>), dim3(blocks), dim3(256), 0, st, (const unsigned char *)src, (T *)dst, (long long)voxels, alpha_mode)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((ingest_kernel<float, T>), dim3(blocks), dim3(256), 0, st, (const float *)src, (T *)dst, (long long)voxels, alpha_mode)); }
+  NRPN_LAUNCH_CHECK("ingest_rgbsigma");
+  return NRPN_OK;
+}

@@ -22,9 +22,33 @@ def density_to_alpha_relu(density):
     return np.clip(1.0 - np.exp(-np.clip(density, a_min=0, a_max=None) / 100.0), 0.0, 1.0)
 
 
-def _grid_from_npz(path, normalize_density):
+class RawScene:
+    """A scene still in its on-disk (W,L,H,4) layout (float32 or uint8), to be finished ON THE DEVICE by
+    ``ops.ingest_rgbsigma`` (uint8 -> /255, density_to_alpha, cast to the compute dtype, channels-last) instead of numpy alpha +
+    host transpose + fp32 conversion.  Produced by datasets built with ``device_ingest=True`` when no augmentation is active."""
+    __slots__ = ("data", "alpha_mode")
+
+    def __init__(self, data, alpha_mode):
+        self.data, self.alpha_mode = data, alpha_mode
+
+    @property
+    def shape(self):            # the logical [4,W,L,H] shape, so len()/shape based bookkeeping keeps working
+        return torch.Size((4,) + tuple(self.data.shape[:3]))
+
+    def pin_memory(self):
+        self.data = self.data.pin_memory()
+        return self
+
+    def to_device(self, dtype=torch.float32):
+        from . import ops
+        return ops.ingest_rgbsigma(self.data.cuda(non_blocking=True), self.alpha_mode, dtype)
+
+
+def _grid_from_npz(path, normalize_density, raw=False):
     with np.load(path) as f:
         g = f["rgbsigma"]
+        if raw and not (normalize_density and g.dtype == np.uint8):      # uint8 + alpha follows numpy's casts: host path only
+            return RawScene(torch.from_numpy(np.ascontiguousarray(g)), 1 if normalize_density else 0)
         if normalize_density:
             g[..., -1] = density_to_alpha(g[..., -1])
         t = torch.from_numpy(np.transpose(g, (3, 0, 1, 2)))          # (W,L,H,C) -> (C,W,L,H)
@@ -65,12 +89,14 @@ class BaseDataset(torch.utils.data.Dataset):
         self.flip_prob, self.rotate_prob, self.rot_scale_prob = flip_prob, rotate_prob, rot_scale_prob
         self.z_up = z_up
         self.scene_data = []
+        self.device_ingest = False       # True: un-augmented scenes are returned as RawScene (finished on the GPU)
 
     density_to_alpha = staticmethod(density_to_alpha)
 
     def load_single_scene(self, scene: str):
         boxes = None if self.boxes_path is None else torch.from_numpy(np.load(os.path.join(self.boxes_path, scene + ".npy")))
-        return scene, _grid_from_npz(os.path.join(self.features_path, scene + ".npz"), self.normalize_density), boxes
+        raw = self.device_ingest and not (self.flip_prob > 0 or self.rotate_prob > 0 or self.rot_scale_prob > 0)
+        return scene, _grid_from_npz(os.path.join(self.features_path, scene + ".npz"), self.normalize_density, raw), boxes
 
     def load_scene_data(self, preload: bool = False):
         if self.scene_list is None:

@@ -192,6 +192,6 @@ class FCOSOverNeRF(nn.Module):
         meshes = list(meshes)
         if len(meshes) > 1:
             meshes = self.transform(meshes)
-        features = list(self.backbone(torch.stack(meshes, dim=0)))
+        features = list(self.backbone(ops.stack_scenes(meshes)))
         boxes, scores, losses = self.fcos_module(sizes, features, targets, objectness_output_paths)
         return boxes, losses, scores

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import ops
 from .anchor import AnchorGenerator3D, RPNHead
 from .rpn import RegionProposalNetwork
 
@@ -86,7 +87,7 @@ class NeRFRegionProposalNetwork(nn.Module):
             original_mesh_sizes.append((int(val[0]), int(val[1]), int(val[2])))
         meshes, targets = self.transform(list(meshes), targets)
         self.check_bbox_degeneration(targets)
-        mesh_tensors = torch.stack(meshes, dim=0)
+        mesh_tensors = ops.stack_scenes(meshes)
         features = list(self.backbone(mesh_tensors))
         proposals, level_index, proposal_losses, scores = self.rpn(mesh_tensors, features, original_mesh_sizes, targets,
                                                                    objectness_output_paths)

@@ -1020,8 +1020,31 @@ class _ToChannelsLast(torch.autograd.Function):
 
 
 def to_channels_last(x, dtype):
-    """[N,C,X,Y,Z] fp32 -> [N,X,Y,Z,C] dtype (differentiable)."""
+    """[N,C,X,Y,Z] fp32 -> [N,X,Y,Z,C] dtype (differentiable).  A tensor that is already channels-last in memory (e.g. the output
+    of ``ingest_rgbsigma``) passes through as a view."""
+    cl = x.permute(0, 2, 3, 4, 1)
+    if cl.is_contiguous() and cl.dtype == dtype and not x.requires_grad:
+        return cl
     return _ToChannelsLast.apply(x, dtype)
+
+
+def ingest_rgbsigma(raw, alpha_mode=0, dtype=torch.float32):
+    """On-disk layout (W,L,H,4) f32|uint8 on the device -> the reference's logical [4,W,L,H] scene tensor, backed by
+    channels-last memory in the compute dtype (reference datasets.py:39-63; alpha_mode 1 = density_to_alpha, 2 = ScanNet's)."""
+    raw = raw.contiguous()
+    _chk(raw)
+    if raw.dim() != 4 or raw.shape[-1] != 4 or raw.dtype not in (torch.float32, torch.uint8):
+        raise lib.NrpnError("ingest_rgbsigma expects a (W,L,H,4) float32 or uint8 tensor")
+    out = torch.empty(raw.shape, dtype=dtype, device=raw.device)
+    call("ingest_rgbsigma", _p(raw), int(raw.dtype == torch.uint8), _p(out), raw.numel() // 4, int(alpha_mode), _dt(out), _s())
+    return out.permute(3, 0, 1, 2)
+
+
+def stack_scenes(meshes):
+    """torch.stack for scene tensors [4,W,L,H]: keeps channels-last memory when every scene has it (no layout round trip)."""
+    if all(m.permute(1, 2, 3, 0).is_contiguous() for m in meshes):
+        return torch.stack([m.permute(1, 2, 3, 0) for m in meshes], dim=0).permute(0, 4, 1, 2, 3)
+    return torch.stack(meshes, dim=0)
 
 
 def to_channels_first(x):

@@ -133,7 +133,7 @@ class Trainer(run_rpn.Trainer):
         a = self.args
         for i, (rgbsigma, boxes, scene_name) in enumerate(self.train_loader):
             self.model.train()
-            rgbsigma = [t.cuda(non_blocking=True) for t in rgbsigma]
+            rgbsigma = self.scenes_to_device(rgbsigma)
             boxes = [t.cuda(non_blocking=True) for t in boxes]
             _, losses, _ = self.model(rgbsigma, boxes)
             lc, lr_, lt = losses['loss_cls'], losses['loss_reg'] * a.reg_loss_weight, losses['loss_centerness']
@@ -175,7 +175,7 @@ class Trainer(run_rpn.Trainer):
         self.logger.info('Evaluating...')
         proposals_list, scores_list, gt_list, scenes_list = [], [], [], []
         for rgbsigma, gt_boxes, scenes in loader:
-            rgbsigma = [t.cuda() for t in rgbsigma]
+            rgbsigma = self.scenes_to_device(rgbsigma)
             paths = None
             if a.output_voxel_scores:
                 d = os.path.join(a.save_path, 'voxel_scores')

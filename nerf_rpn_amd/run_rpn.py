@@ -22,7 +22,7 @@ import torch.multiprocessing as mp
 from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
-from .datasets import BaseDataset, Front3DRPNDataset, GeneralRPNDataset, HypersimRPNDataset, ScanNetRPNDataset
+from .datasets import BaseDataset, Front3DRPNDataset, GeneralRPNDataset, HypersimRPNDataset, RawScene, ScanNetRPNDataset
 from .engine import FlatTrainer
 from .eval import evaluate_box_proposals_ap, evaluate_box_proposals_recall
 from .model.anchor import AnchorGenerator3D, RPNHead
@@ -183,11 +183,21 @@ class Trainer:
         a = self.args
         aug = dict(flip_prob=a.flip_prob, rotate_prob=a.rotate_prob, rot_scale_prob=a.rot_scale_prob) if augment else {}
         if a.dataset_name in ('hypersim', 'front3d'):
-            return self.dataset(scene_list=scenes, features_path=a.features_path, boxes_path=a.boxes_path,
-                                normalize_density=a.normalize_density, preload=a.preload, **aug)
+            ds = self.dataset(scene_list=scenes, features_path=a.features_path, boxes_path=a.boxes_path,
+                              normalize_density=a.normalize_density, preload=False if not augment else a.preload, **aug)
+            if not augment:        # evaluation scenes skip the host-side alpha / transpose / float pass (ops.ingest_rgbsigma)
+                ds.device_ingest = True
+                if a.preload:
+                    ds.load_scene_data(preload=True)
+            return ds
         if a.dataset_name == 'scannet':
             return ScanNetRPNDataset(scene_list=scenes, features_path=a.features_path, boxes_path=a.boxes_path, **aug)
         return GeneralRPNDataset(csv_path=csv, normalize_density=a.normalize_density)
+
+    def scenes_to_device(self, rgbsigma):
+        """Host scene tensors [4,W,L,H] -> device; RawScene items are finished by the ingest kernel in the compute dtype."""
+        dt = getattr(self.model, 'compute_dtype', torch.float32)
+        return [t.to_device(dt) if isinstance(t, RawScene) else t.cuda(non_blocking=True) for t in rgbsigma]
 
     def save_checkpoint(self, epoch, path):
         torch.save({'epoch': epoch, 'backbone_state_dict': self.backbone.state_dict(),
@@ -235,7 +245,7 @@ class Trainer:
         a = self.args
         for i, (rgbsigma, boxes, scene_name) in enumerate(self.train_loader):
             self.model.train()
-            rgbsigma = [t.cuda(non_blocking=True) for t in rgbsigma]
+            rgbsigma = self.scenes_to_device(rgbsigma)
             boxes = [t.cuda(non_blocking=True) for t in boxes]
             _, losses, _ = self.model(rgbsigma, boxes)
             lo = losses['loss_objectness']
@@ -271,7 +281,7 @@ class Trainer:
         self.logger.info('Evaluating...')
         proposals_list, scores_list, gt_list, scenes_list = [], [], [], []
         for rgbsigma, gt_boxes, scenes in loader:
-            rgbsigma = [t.cuda() for t in rgbsigma]
+            rgbsigma = self.scenes_to_device(rgbsigma)
             paths = None
             if a.output_voxel_scores:
                 d = os.path.join(a.save_path, 'voxel_scores')

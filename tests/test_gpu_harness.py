@@ -100,3 +100,35 @@ def test_rpn_command_line_with_swin_backbone(tmp_path, dev):
     assert "stages.2.1.attn.relative_position_index" in ck["backbone_state_dict"]
     main(["--mode", "eval", "--checkpoint", str(tmp_path / "out" / "model_best.pt"), "--output_proposals"] + common)
     assert np.load(tmp_path / "out" / "proposals" / "b.npz")["proposal"].shape[1] == 7
+
+
+def test_device_ingest_matches_host_loader(tmp_path, dev):
+    """ops.ingest_rgbsigma (on-disk (W,L,H,4) layout -> channels-last compute dtype with density_to_alpha on the GPU) against the
+    host loader that restates the reference's load_single_scene (datasets.py:39-63); and the model consumes the
+    channels-last-backed scene without a layout round trip, giving the same proposals."""
+    from nerf_rpn_amd import ops
+    from nerf_rpn_amd.datasets import RawScene, _grid_from_npz
+    rng = np.random.default_rng(3)
+    g32 = (rng.random((24, 20, 16, 4), dtype=np.float32) * 8 - 4)
+    g8 = rng.integers(0, 256, (12, 10, 8, 4), dtype=np.uint8)
+    np.savez(tmp_path / "f.npz", rgbsigma=g32)
+    np.savez(tmp_path / "u.npz", rgbsigma=g8)
+    for path, norm in (("f.npz", True), ("f.npz", False), ("u.npz", False)):
+        host = _grid_from_npz(str(tmp_path / path), norm)
+        raw = _grid_from_npz(str(tmp_path / path), norm, raw=True)
+        assert isinstance(raw, RawScene) and tuple(raw.shape) == tuple(host.shape)
+        got = raw.to_device(torch.float32)
+        assert got.shape == host.shape and got.permute(1, 2, 3, 0).is_contiguous()
+        assert torch.allclose(got.cpu(), host, atol=2e-6, rtol=1e-6), (path, norm, (got.cpu() - host).abs().max())
+    assert not isinstance(_grid_from_npz(str(tmp_path / "u.npz"), True, raw=True), RawScene)       # numpy-cast quirk: host path only
+    relu = ops.ingest_rgbsigma(torch.from_numpy(g32).to(dev), 2, torch.float32).cpu()
+    ref = torch.from_numpy(np.clip(1.0 - np.exp(-np.clip(g32[..., 3], 0, None) / 100.0), 0.0, 1.0))
+    assert torch.allclose(relu[3], ref, atol=2e-6)
+    # the model on a channels-last-backed scene == the model on the plain [4,W,L,H] tensor
+    from test_gpu_e2e import build
+    m = build(False, 160, dev).eval()
+    raw = _grid_from_npz(str(tmp_path / "f.npz"), True, raw=True)
+    with torch.no_grad():
+        (_, p1, _), _, s1 = m([raw.to_device(torch.float32)])
+        (_, p2, _), _, s2 = m([_grid_from_npz(str(tmp_path / "f.npz"), True).to(dev)])
+    assert p1[0].shape == p2[0].shape and torch.allclose(s1[0], s2[0], atol=1e-5) and torch.allclose(p1[0], p2[0], atol=1e-3)
