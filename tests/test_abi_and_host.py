@@ -66,3 +66,27 @@ def test_state_dict_keys_match_reference_layout():
     for rot in (False, True):
         a, b = RPNHead(256, 13, 4, rotate=rot), nets.RPNHead(256, 13, 4, rot)
         assert {k: v.shape for k, v in a.state_dict().items()} == {k: v.shape for k, v in b.state_dict().items()}
+
+
+def test_swin_and_fcos_state_dict_keys_match_reference_layout():
+    """Same key names / shapes / buffer values as the oracle modules, which load the reference's state dicts strictly
+    (tests/golden/make_golden.py): checkpoints of the reference's default swin_s / FCOS configuration interchange."""
+    import argparse
+    import torch
+    from nerf_rpn_amd.model.feature_extractor import SwinTransformer_FPN
+    from nerf_rpn_amd.model.fcos import FCOSModule
+    from oracle import fcos as OF, nets
+    a = SwinTransformer_FPN([4, 4, 4], 96, [2, 2, 18, 2], [3, 6, 12, 24], [4, 4, 4])
+    b = nets.SwinFPN(96, (2, 2, 18, 2), (3, 6, 12, 24), 0.1)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert len(sa) == 365 and {k: v.shape for k, v in sa.items()} == {k: v.shape for k, v in sb.items()}
+    k = "stages.2.5.attn.relative_position_index"
+    assert sa[k].dtype == torch.int64 and torch.equal(sa[k], sb[k])
+    for rot in (False, True):
+        args = argparse.Namespace(num_convs=4, norm_reg_targets=True, centerness_on_reg=True, rotated_bbox=rot, pre_nms_thresh=0.0,
+                                  pre_nms_top_n=2500, nms_thresh=0.3, fpn_post_nms_top_n=2500, min_size=0.0, center_sampling_radius=1.5,
+                                  iou_loss_type="iou", use_additional_l1_loss=False, proj2d_loss_weight=0.0)
+        mod = FCOSModule(args, 256, [4, 8, 16, 32])
+        ref = OF.FCOSHead(256, 4, [4, 8, 16, 32], True, True, rot)
+        got = {k: v.shape for k, v in mod.state_dict().items()}
+        assert got == {"head." + k: v.shape for k, v in ref.state_dict().items()}       # checkpoint key 'fcos_state_dict' holds head.*
