@@ -1,7 +1,8 @@
 import sys, os
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+_R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
+sys.path.insert(0, _R)
+sys.path.insert(0, os.path.join(_R, 'tests'))
 from test_gpu_e2e import build, scene, T
 dev = torch.device('cuda:0')
 G = lambda n: dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', n + '.npz')))

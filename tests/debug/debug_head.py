@@ -1,6 +1,6 @@
 import sys, os
 import numpy as np, torch
-R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from fixture_init import seeded_state
 from oracle import nets as ON
