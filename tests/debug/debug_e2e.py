@@ -5,7 +5,7 @@ sys.path.insert(0, _R)
 sys.path.insert(0, os.path.join(_R, 'tests'))
 from test_gpu_e2e import build, scene, T
 dev = torch.device('cuda:0')
-G = lambda n: dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', n + '.npz')))
+G = lambda n: dict(np.load(os.path.join(_R, 'tests', 'golden', n + '.npz')))
 g = G('eval_aabb_s2')
 m = build(False, 160, dev).eval()
 with torch.no_grad():
