@@ -194,6 +194,15 @@ int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, i
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
                       int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
                       nrpn_stream_t stream);
+/* Ragged voxel lists: nseg <= 16 grids laid end to end in x / y / dy (dims: host int32 [nseg*3] = X,Y,Z of each segment), e.g. the
+ * (level, scene) maps of a weight-sharing RPN / FCOS head, which then run as ONE launch per layer instead of one per level
+ * (the 10^3 / 5^3 levels are launch- and latency-bound on their own).  Same semantics as the per-grid calls on every segment;
+ * workspace sizes / slice counts: call the queries above with n = 1, gx = total voxels, gy = gz = 1. */
+int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, void *y, int nseg, const int32_t *dims, int cin,
+                           int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream);
+int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, float *gbias, int nseg, const int32_t *dims,
+                             int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
+                             nrpn_stream_t stream);
 /* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
 int nrpn_set_conv_kstep_bytes(int kb);
 /* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */

@@ -71,6 +71,52 @@ __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * 
 // =====================================================================================================================
 // forward / dgrad
 // =====================================================================================================================
+// Ragged voxel lists: several grids laid end to end ((level, scene) segments of a weight-sharing head run in ONE launch).
+// n == 0 means the classic layout: N copies of one X*Y*Z grid.
+constexpr int kMaxSeg = 16;
+struct Segs {
+  int n;
+  int start[kMaxSeg + 1];                 // first voxel of each segment, start[n] = total
+  int X[kMaxSeg], Y[kMaxSeg], Z[kMaxSeg];
+};
+
+// voxel -> coordinates inside its grid, that grid's dims and its segment id (no dynamic indexing of the kernel-argument struct)
+__device__ __forceinline__ int locate_voxel(const Segs &s, long long v, int cX, int cY, int cZ, int &x, int &y, int &z, int &X, int &Y,
+                                            int &Z) {
+  int seg = 0;
+  long long local = v;
+  if (s.n > 0) {
+    X = s.X[0]; Y = s.Y[0]; Z = s.Z[0];
+    int st = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSeg; ++k)
+      if (k < s.n && v >= s.start[k]) { X = s.X[k]; Y = s.Y[k]; Z = s.Z[k]; st = s.start[k]; seg = k; }
+    local = v - st;
+  } else {
+    X = cX; Y = cY; Z = cZ;
+  }
+  z = (int)(local % Z);
+  const long long t1 = local / Z;
+  y = (int)(t1 % Y);
+  x = (int)((t1 / Y) % X);
+  return seg;
+}
+
+static int fill_segs(Segs &sg, int nseg, const int32_t *dims, long long &M) {
+  if (nseg < 1 || nseg > kMaxSeg || !dims) return nrpn_fail(NRPN_ERR_ARG, "ragged conv: 1..%d segments", kMaxSeg);
+  sg.n = nseg;
+  long long off = 0;
+  for (int k = 0; k < nseg; ++k) {
+    if (dims[3 * k] <= 0 || dims[3 * k + 1] <= 0 || dims[3 * k + 2] <= 0) return nrpn_fail(NRPN_ERR_ARG, "ragged conv: bad segment %d", k);
+    sg.start[k] = (int)off; sg.X[k] = dims[3 * k]; sg.Y[k] = dims[3 * k + 1]; sg.Z[k] = dims[3 * k + 2];
+    off += (long long)dims[3 * k] * dims[3 * k + 1] * dims[3 * k + 2];
+    if (off >= (1ll << 31)) return nrpn_fail(NRPN_ERR_ARG, "ragged conv: too many voxels");
+  }
+  for (int k = nseg; k <= kMaxSeg; ++k) sg.start[k] = (int)off;
+  M = off;
+  return 0;
+}
+
 struct ConvArgs {
   const void *x;
   const void *w;      // MODE 0: [taps][wrows][Cin];  MODE 1 (stem): [wrows][Kpad], k = tap*4 + c
@@ -88,6 +134,7 @@ struct ConvArgs {
   int ksplit;         // > 1: blockIdx.z owns a slice of the K loop and atomically adds fp32 partials into `ws`
   float *ws;          // [M][Cout] fp32, zero-filled by the launcher (split-K only)
   int slices;         // 1: split-K partials go to ws[z][M][Cout] with plain stores (256x256 kernel); 0: atomics into ws[M][Cout]
+  Segs segs;          // MODE 0 only: ragged voxel list (n > 0) instead of N copies of X*Y*Z
 };
 
 template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128>
@@ -119,19 +166,28 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
   int a_x[A_RPT], a_y[A_RPT], a_z[A_RPT];
   bool a_ok[A_RPT];
   unsigned a_mask[A_RPT];
+  int a_yz[A_RPT], a_zs[A_RPT];   // MODE 0: byte strides of one x / one y step in this row's own grid (ragged lists mix grids)
   long long a_nbase[A_RPT];  // MODE 1: element offset of batch n
 #pragma unroll
   for (int i = 0; i < A_RPT; ++i) {
     const long long v = m0 + lr + RSTEP * i;
     a_ok[i] = v < p.M;
     const long long vv = a_ok[i] ? v : 0;
-    const int oz = (int)(vv % p.OZ);
-    const long long t1 = vv / p.OZ;
-    const int oy = (int)(t1 % p.OY);
-    const long long t2 = t1 / p.OY;
-    const int ox = (int)(t2 % p.OX);
-    const long long n = t2 / p.OX;
+    int ox, oy, oz, gX = p.X, gY = p.Y, gZ = p.Z;
+    long long n = 0;
+    if (MODE == 0) {
+      locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
+    } else {
+      oz = (int)(vv % p.OZ);
+      const long long t1 = vv / p.OZ;
+      oy = (int)(t1 % p.OY);
+      const long long t2 = t1 / p.OY;
+      ox = (int)(t2 % p.OX);
+      n = t2 / p.OX;
+    }
     a_x[i] = ox; a_y[i] = oy; a_z[i] = oz;
+    a_yz[i] = gY * gZ * p.Cin * (int)sizeof(T);
+    a_zs[i] = gZ * p.Cin * (int)sizeof(T);
     a_off[i] = (MODE == 0) ? vv * p.Cin : 0;
     a_nbase[i] = (MODE == 0) ? 0 : n * (long long)p.X * p.Y * p.Z * 4;
     unsigned m = 0;
@@ -140,7 +196,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
           const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
-          const bool in = (unsigned)(ox + dx) < (unsigned)p.X && (unsigned)(oy + dy) < (unsigned)p.Y && (unsigned)(oz + dz) < (unsigned)p.Z;
+          const bool in = (unsigned)(ox + dx) < (unsigned)gX && (unsigned)(oy + dy) < (unsigned)gY && (unsigned)(oz + dz) < (unsigned)gZ;
           m |= in ? (1u << t) : 0u;
         }
       } else {
@@ -193,9 +249,10 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
   auto load_step = [&](int ks, f4 (&ra)[A_RPT], f4 (&rb)[B_RPT]) {
     if (MODE == 0) {
       const int c0 = l_chunk * KE;
-      const unsigned shift = (unsigned)((((l_dx * p.Y + l_dy) * p.Z + l_dz) * p.Cin + c0) * (int)sizeof(T));
+      const int zshift = (l_dz * p.Cin + c0) * (int)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < A_RPT; ++i) ra[i] = bufld16(xr, ((a_mask[i] >> l_tap) & 1u) ? a_voff[i] + shift : kOOB);
+      for (int i = 0; i < A_RPT; ++i)
+        ra[i] = bufld16(xr, ((a_mask[i] >> l_tap) & 1u) ? a_voff[i] + (unsigned)(l_dx * a_yz[i] + l_dy * a_zs[i] + zshift) : kOOB);
       const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * (long long)sizeof(T));
 #pragma unroll
       for (int i = 0; i < B_RPT; ++i) rb[i] = bufld16(wr, b_voff[i] + wshift);
@@ -242,11 +299,12 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     char *A = lds + buf * (A_BYTES + B_BYTES);
     char *B = A + A_BYTES;
     const int c0 = l_chunk * KE;
-    const unsigned shift = (unsigned)((((l_dx * p.Y + l_dy) * p.Z + l_dz) * p.Cin + c0) * (int)sizeof(T));
+    const int zshift = (l_dz * p.Cin + c0) * (int)sizeof(T);
     const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * (long long)sizeof(T));
 #pragma unroll
     for (int i = 0; i < A_RPT; ++i)
-      lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB, ((a_mask[i] >> l_tap) & 1u) ? a_voff[i] + shift : kOOB);
+      lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB,
+                ((a_mask[i] >> l_tap) & 1u) ? a_voff[i] + (unsigned)(l_dx * a_yz[i] + l_dy * a_zs[i] + zshift) : kOOB);
 #pragma unroll
     for (int i = 0; i < B_RPT; ++i)
       lds_dma16(wr, B + (wave_u * (64 / PPR) + RSTEP * i) * KB, b_voff[i] + wshift);
@@ -597,23 +655,24 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
   unsigned a_voff[A_RPT], a_mask[A_RPT], b_voff[B_RPT];
+  int a_yz[A_RPT], a_zs[A_RPT];            // byte strides of one x / one y step in this row's own grid
 #pragma unroll
   for (int i = 0; i < A_RPT; ++i) {
     const int r = lr + RSTEP * i;
     const long long v = m0 + r;
     const bool ok = v < p.M;
     const long long vv = ok ? v : 0;
-    const int oz = (int)(vv % p.OZ);
-    const long long t1 = vv / p.OZ;
-    const int oy = (int)(t1 % p.OY);
-    const int ox = (int)((t1 / p.OY) % p.OX);
+    int ox, oy, oz, gX, gY, gZ;
+    locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
+    a_yz[i] = gY * gZ * p.Cin * 2;
+    a_zs[i] = gZ * p.Cin * 2;
     unsigned m = 0;
     if (ok) {
       if (p.taps == 27) {
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
           const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
-          const bool in = (unsigned)(ox + dx) < (unsigned)p.X && (unsigned)(oy + dy) < (unsigned)p.Y && (unsigned)(oz + dz) < (unsigned)p.Z;
+          const bool in = (unsigned)(ox + dx) < (unsigned)gX && (unsigned)(oy + dy) < (unsigned)gY && (unsigned)(oz + dz) < (unsigned)gZ;
           m |= in ? (1u << t) : 0u;
         }
       } else {
@@ -636,12 +695,13 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     char *A = lds + buf * (A_BYTES + B_BYTES);
     char *B = A + A_BYTES;
     const int c0 = l_chunk * KE;
-    const unsigned shift = (unsigned)((((l_dx * p.Y + l_dy) * p.Z + l_dz) * p.Cin + c0) * 2);
+    const int zshift = (l_dz * p.Cin + c0) * 2;
     const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * 2);
     const unsigned tapbit = live ? (1u << l_tap) : 0u;
 #pragma unroll
     for (int i = 0; i < A_RPT; ++i)
-      lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB, (a_mask[i] & tapbit) ? a_voff[i] + shift : kOOB);
+      lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB,
+                (a_mask[i] & tapbit) ? a_voff[i] + (unsigned)(l_dx * a_yz[i] + l_dy * a_zs[i] + zshift) : kOOB);
 #pragma unroll
     for (int i = 0; i < B_RPT; ++i) lds_dma16(wr, B + (wave_u * (64 / PPR) + RSTEP * i) * KB, live ? b_voff[i] + wshift : kOOB);
     // K order: 64-channel chunk OUTER, tap INNER.  All workgroups of an XCD then sweep the 27 shifted views of one 128-byte
@@ -837,7 +897,7 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const bool can = kDma && g_conv_glds && wide && bn == 128 && (a.ksplit <= 1 || a.slices) && sizeof(T) == 2;
   const long long tiles_big = cdiv64(a.M, 256) * ((a.Cout + 255) / 256);
   const bool huge = can && a.Cout >= 256 && (a.slices || g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
-  const bool big = can && !huge && g_conv_bm == 256;      // wave-specialised 256x128: on par with 128x128 (measured), opt-in only
+  const bool big = can && !huge && g_conv_bm == 256 && a.segs.n == 0;      // wave-specialised 256x128: on par with 128x128 (measured), opt-in only
   const int bm = (big || huge) ? 256 : 128;
   dim3 grid((unsigned)(cdiv64(a.M, bm) * ((a.Cout + (huge ? 256 : bn) - 1) / (huge ? 256 : bn)) * (a.ksplit > 1 ? a.ksplit : 1)));
   int rc = 0;
@@ -887,18 +947,19 @@ extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz,
   return s > 1 ? (size_t)(M * cout * 4) : 0;
 }
 
-extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
-                               int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
+static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, void *y, long long M, int gx, int gy, int gz, const Segs *segs,
+                           int cin, int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_fwd: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_fwd: bad dtype %d", dtype);
-  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && cin > 0 && cout > 0 && wrows >= cout, "conv3d_fwd: bad sizes");
+  NRPN_REQUIRE(M > 0 && gx > 0 && gy > 0 && gz > 0 && cin > 0 && cout > 0 && wrows >= cout, "conv3d_fwd: bad sizes");
   const int es = dtype == NRPN_F32 ? 4 : 2;
   NRPN_REQUIRE((cin * es) % 64 == 0, "conv3d_fwd: Cin*elemsize must be a multiple of 64 bytes (Cin=%d)", cin);
   NRPN_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
   ConvArgs a{};
   a.x = x; a.w = wp; a.bias = bias; a.y = y;
-  a.M = (long long)n * gx * gy * gz;
-  a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // the kernel splits v into (batch, x, y, z) with these
+  a.M = M;
+  a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // classic layout: the kernel splits v into (batch, x, y, z) with these
+  if (segs) a.segs = *segs;
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.flags = flags & 3;
   NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && (long long)a.taps * wrows * cin * es < (1ll << 31),
                "conv3d_fwd: activation / weight tensors must stay below 2 GiB (32-bit buffer offsets)");
@@ -930,6 +991,21 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
   }
   NRPN_LAUNCH_CHECK("splitk_epilogue");
   return NRPN_OK;
+}
+
+extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
+                               int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0, "conv3d_fwd: bad sizes");
+  return conv3d_fwd_impl(x, wp, bias, y, (long long)n * gx * gy * gz, gx, gy, gz, nullptr, cin, cout, wrows, ksize, dtype, flags, workspace,
+                         stream);
+}
+
+extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, void *y, int nseg, const int32_t *dims, int cin,
+                                      int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
+  Segs sg{};
+  long long M = 0;
+  if (int rc = fill_segs(sg, nseg, dims, M)) return rc;
+  return conv3d_fwd_impl(x, wp, bias, y, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, flags, workspace, stream);
 }
 
 extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
@@ -973,6 +1049,7 @@ struct WgradArgs {
   unsigned x_bytes, dy_bytes;
   float *gbias;       // optional: column sums of dY, accumulated by the (centre tap, first n-tile) workgroups from their LDS A tiles
   long long slice_stride;   // elements between the partial gradients of consecutive voxel slices ([ksplit][...] layout of gw)
+  Segs segs;          // MODE 0: ragged voxel list (n > 0); the tap-mask word then carries the segment id in bits 27-31
 };
 
 template <typename T> struct WgCfg;
@@ -1065,7 +1142,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   // ahead so the mask -> address dependency never stalls the data loads.
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
   const __amdgpu_buffer_rsrc_t mr = make_rsrc(p.vmask, (unsigned)(p.M * 4));
-  const long long tap_shift = ((long long)dx * p.Y + dy) * p.Z + dz;
+  // byte shift of this workgroup's tap inside each segment's own grid (classic layout: one entry); the mask word of a voxel
+  // carries its segment id in bits 27..31
+  __shared__ int seg_shift[kMaxSeg];
+  if (MODE == 0 && tid < kMaxSeg) {
+    int Y = p.Y, Z = p.Z;
+#pragma unroll
+    for (int q = 0; q < kMaxSeg; ++q)
+      if (q == tid && q < p.segs.n) { Y = p.segs.Y[q]; Z = p.segs.Z[q]; }
+    seg_shift[tid] = (int)((((long long)dx * Y + dy) * Z + dz) * p.Cin * (long long)sizeof(T));
+  }
+  __syncthreads();
   unsigned a_voff[PIECES], b_voff[PIECES], m_voff[PIECES], m_next[PIECES];
   const bool use_mask = MODE == 0 && p.taps == 27;
 #pragma unroll
@@ -1075,7 +1162,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     const long long v = c_begin * KV + row;
     const int ca = m0 + col * (16 / (int)sizeof(T)), cb = n0 + col * (16 / (int)sizeof(T));
     a_voff[i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * (long long)sizeof(T)) : kOOB;
-    b_voff[i] = cb < p.Cin ? (unsigned)(((v + tap_shift) * p.Cin + cb) * (long long)sizeof(T)) : kOOB;
+    b_voff[i] = cb < p.Cin ? (unsigned)((v * p.Cin + cb) * (long long)sizeof(T)) : kOOB;       // the tap shift is added per chunk
     m_voff[i] = (unsigned)(v * 4);
     m_next[i] = (v < p.M) ? 1u : 0u;
     if (MODE == 0 && use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
@@ -1089,7 +1176,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
       if (MODE == 0) {
         ra[i] = bufld16(dyr, a_voff[i]);
         const bool in = (m_next[i] >> tap) & 1u;      // 0 beyond the tensor (the mask load itself was out of range)
-        rb[i] = bufld16(xr, (in && b_voff[i] != kOOB) ? b_voff[i] : kOOB);
+        rb[i] = bufld16(xr, (in && b_voff[i] != kOOB) ? b_voff[i] + (unsigned)seg_shift[m_next[i] >> 27] : kOOB);
         a_voff[i] = a_voff[i] == kOOB ? kOOB : a_voff[i] + a_step;
         b_voff[i] = b_voff[i] == kOOB ? kOOB : b_voff[i] + b_step;
         m_voff[i] += KV * 4;
@@ -1145,7 +1232,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
       const int dst = (64 * wave_u + 256 * i) * 16;
       lds_dma16(dyr, A + dst, a_voff[i]);
       const bool in = (m_next[i] >> tap) & 1u;
-      lds_dma16(xr, B + dst, (in && b_voff[i] != kOOB) ? b_voff[i] : kOOB);
+      lds_dma16(xr, B + dst, (in && b_voff[i] != kOOB) ? b_voff[i] + (unsigned)seg_shift[m_next[i] >> 27] : kOOB);
       a_voff[i] = a_voff[i] == kOOB ? kOOB : a_voff[i] + a_step;
       b_voff[i] = b_voff[i] == kOOB ? kOOB : b_voff[i] + b_step;
       m_voff[i] += KV * 4;
@@ -1281,7 +1368,15 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
   const __amdgpu_buffer_rsrc_t mr = make_rsrc(p.vmask, (unsigned)(p.M * 4));
-  const long long tap_shift = ((long long)dx * p.Y + dy) * p.Z + dz;
+  __shared__ int seg_shift[kMaxSeg];            // byte shift of this tap inside each segment's grid (see conv_wgrad_kernel)
+  if (tid < kMaxSeg) {
+    int Y = p.Y, Z = p.Z;
+#pragma unroll
+    for (int q = 0; q < kMaxSeg; ++q)
+      if (q == tid && q < p.segs.n) { Y = p.segs.Y[q]; Z = p.segs.Z[q]; }
+    seg_shift[tid] = (int)((((long long)dx * Y + dy) * Z + dz) * p.Cin * 2);
+  }
+  __syncthreads();
   const bool use_mask = p.taps == 27;
   // per thread: rows r_i = tid / 16 + 32 i (i = 0, 1) of every sub-tile, physical 16-byte slot tid % 16
   unsigned a_voff[2][2], b_voff[2][2], m_voff[2], m_next[2];
@@ -1294,7 +1389,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
     for (int t = 0; t < 2; ++t) {
       const int ca = m0 + 128 * t + col * 8, cb = n0 + 128 * t + col * 8;
       a_voff[t][i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * 2) : kOOB;
-      b_voff[t][i] = cb < p.Cin ? (unsigned)(((v + tap_shift) * p.Cin + cb) * 2) : kOOB;
+      b_voff[t][i] = cb < p.Cin ? (unsigned)((v * p.Cin + cb) * 2) : kOOB;                   // the tap shift is added per chunk
     }
     m_voff[i] = (unsigned)(v * 4);
     m_next[i] = (v < p.M) ? 1u : 0u;
@@ -1308,10 +1403,11 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
     for (int i = 0; i < 2; ++i) {
       const int dst = (64 * wave_u + 512 * i) * 16;
       const bool in = (m_next[i] >> tap) & 1u;
+      const unsigned tsh = (unsigned)seg_shift[m_next[i] >> 27];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         lds_dma16(dyr, base + t * SUB + dst, a_voff[t][i]);
-        lds_dma16(xr, base + (2 + t) * SUB + dst, (in && b_voff[t][i] != kOOB) ? b_voff[t][i] : kOOB);
+        lds_dma16(xr, base + (2 + t) * SUB + dst, (in && b_voff[t][i] != kOOB) ? b_voff[t][i] + tsh : kOOB);
         a_voff[t][i] = a_voff[t][i] == kOOB ? kOOB : a_voff[t][i] + a_step;
         b_voff[t][i] = b_voff[t][i] == kOOB ? kOOB : b_voff[t][i] + b_step;
       }
@@ -1423,19 +1519,18 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   }
 }
 
-// bit t of mask[v] = 1 iff voxel v shifted by tap t = (dx+1)*9 + (dy+1)*3 + (dz+1) stays inside its scene
-__global__ void tap_mask_kernel(unsigned *__restrict__ mask, long long M, int X, int Y, int Z) {
+// bit t of mask[v] = 1 iff voxel v shifted by tap t = (dx+1)*9 + (dy+1)*3 + (dz+1) stays inside its own grid; bits 27..31 = the
+// voxel's segment id (0 in the classic layout)
+__global__ void tap_mask_kernel(unsigned *__restrict__ mask, long long M, int X, int Y, int Z, Segs segs) {
   const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= M) return;
-  const int z = (int)(v % Z);
-  const long long t1 = v / Z;
-  const int y = (int)(t1 % Y);
-  const int x = (int)((t1 / Y) % X);
-  unsigned m = 0;
+  int x, y, z, gX, gY, gZ;
+  const int seg = locate_voxel(segs, v, X, Y, Z, x, y, z, gX, gY, gZ);
+  unsigned m = (unsigned)seg << 27;
 #pragma unroll
   for (int t = 0; t < 27; ++t) {
     const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
-    if ((unsigned)(x + dx) < (unsigned)X && (unsigned)(y + dy) < (unsigned)Y && (unsigned)(z + dz) < (unsigned)Z) m |= 1u << t;
+    if ((unsigned)(x + dx) < (unsigned)gX && (unsigned)(y + dy) < (unsigned)gY && (unsigned)(z + dz) < (unsigned)gZ) m |= 1u << t;
   }
   mask[v] = m;
 }
@@ -1555,8 +1650,9 @@ extern "C" size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int g
   return ksize == 3 ? (size_t)n * gx * gy * gz * 4 : 0;
 }
 
-extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz, int cin,
-                                 int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace, nrpn_stream_t stream) {
+static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, float *gbias, long long M, int gx, int gy, int gz,
+                             const Segs *segs, int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
+                             nrpn_stream_t stream) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_wgrad: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_wgrad: bad dtype %d", dtype);
   const int es = dtype == NRPN_F32 ? 4 : 2;
@@ -1564,8 +1660,9 @@ extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed
   NRPN_REQUIRE(x && dy && gw_packed && wrows >= cout, "conv3d_wgrad: bad args");
   WgradArgs a{};
   a.x = x; a.dy = dy; a.gw = gw_packed;
-  a.M = (long long)n * gx * gy * gz;
+  a.M = M;
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;
+  if (segs) a.segs = *segs;
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.kpad = 0;
   hipStream_t st = as_stream(stream);
   NRPN_REQUIRE(ksize == 1 || workspace, "conv3d_wgrad: k3 needs the tap-mask workspace (nrpn_conv3d_wgrad_workspace_bytes)");
@@ -1573,7 +1670,8 @@ extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed
   a.x_bytes = (unsigned)(a.M * cin * es); a.dy_bytes = (unsigned)(a.M * cout * es);
   a.vmask = reinterpret_cast<const unsigned *>(workspace);
   if (ksize == 3)
-    hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz);
+    hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz,
+                       a.segs);
   a.gbias = gbias;
   if (gbias && !accumulate_bias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
   const WgPlan pl = wgrad_plan(a.M, wrows, cin, a.taps, es, 0, cout, cin);
@@ -1594,6 +1692,22 @@ extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed
     return NRPN_OK;
   }
   return launch_wgrad<bf16s, 0>(a, (cin + 127) / 128, st);
+}
+
+extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz, int cin,
+                                 int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0, "conv3d_wgrad: bad sizes");
+  return conv3d_wgrad_impl(x, dy, gw_packed, gbias, (long long)n * gx * gy * gz, gx, gy, gz, nullptr, cin, cout, wrows, ksize, dtype,
+                           accumulate_bias, workspace, stream);
+}
+
+extern "C" int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, float *gbias, int nseg, const int32_t *dims,
+                                        int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
+                                        nrpn_stream_t stream) {
+  Segs sg{};
+  long long M = 0;
+  if (int rc = fill_segs(sg, nseg, dims, M)) return rc;
+  return conv3d_wgrad_impl(x, dy, gw_packed, gbias, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, accumulate_bias, workspace, stream);
 }
 
 extern "C" int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype) {

@@ -80,9 +80,25 @@ class RPNHead(nn.Module):
         used = num_anchors * (1 + self.delta_width)
         self.head_rows = ((used + 63) // 64) * 64      # padded GEMM width (128 for 13 anchors)
         self._pack = ops.PackedWeight()
+        self.ragged = False        # True: the coarser levels run as one ragged launch per layer (measured: no gain)
 
     def forward_fused(self, feats_cl: List[Tensor]) -> List[Tensor]:
         """channels-last features -> per level fp32 [N,X,Y,Z,head_rows]: columns [0,A) logits, [A, A+A*dw) deltas."""
+        n_seg = (len(feats_cl) - 1) * feats_cl[0].shape[0]
+        if self.ragged and len(feats_cl) > 2 and n_seg <= 16:
+            # The head shares its weights across the pyramid.  The finest level fills the chip on its own (250 tiles of 256x256 =
+            # one round of the 256 CUs; adding the others would spill into a second round), so it keeps its own launches; the
+            # coarser levels -- launch- and latency-bound one by one -- run as ONE launch per layer on a ragged voxel list.
+            fine = hip_nn.run_modules(self.conv, feats_cl[0])
+            out0 = ops.ConvFn.apply(fine, self._pack, self.head_rows, False, True, 2, self.cls_logits.weight, self.bbox_pred.weight,
+                                    self.cls_logits.bias, self.bbox_pred.bias)
+            x, segs = hip_nn.ragged_cat(feats_cl[1:])
+            mods = list(self.conv)
+            for i in range(0, len(mods), 2):
+                x = hip_nn.conv3d(mods[i], x, relu=True, segs=segs)
+            h = ops.ConvFn.apply(x, self._pack, self.head_rows, False, True, 2, self.cls_logits.weight, self.bbox_pred.weight,
+                                 self.cls_logits.bias, self.bbox_pred.bias)
+            return [out0] + hip_nn.ragged_split(h, feats_cl[1:])
         outs = []
         for f in feats_cl:
             t = hip_nn.run_modules(self.conv, f)

@@ -16,8 +16,9 @@ def _pack_of(mod):
     return pk
 
 
-def conv3d(mod, x, relu=False, out_f32=False):
-    """nn.Conv3d (k 1|3, stride 1, same padding; or the 4-channel k7 stem) on a channels-last tensor."""
+def conv3d(mod, x, relu=False, out_f32=False, segs=None):
+    """nn.Conv3d (k 1|3, stride 1, same padding; or the 4-channel k7 stem) on a channels-last tensor.
+    ``segs``: x is a ragged list [1, sum voxels, 1, 1, C] of grids with these (X, Y, Z) dims (see ``ragged_cat``)."""
     k = mod.kernel_size[0]
     if k == 7:
         if mod.in_channels != 4 or mod.padding[0] != 3:
@@ -31,7 +32,29 @@ def conv3d(mod, x, relu=False, out_f32=False):
         x = ops.SubsampleFn.apply(x, mod.stride[0])      # strided 1x1x1 conv = subsample + 1x1x1 GEMM
     elif k not in (1, 3) or mod.stride[0] != 1 or mod.padding[0] != k // 2:
         raise NotImplementedError(f"Conv3d k={k} stride={mod.stride} padding={mod.padding} has no HIP kernel yet")
-    return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, relu, out_f32, 1, mod.weight, mod.bias)
+    if segs is not None and (k == 7 or mod.stride[0] != 1):
+        raise NotImplementedError("ragged voxel lists are supported by the stride-1 k1 / k3 convolutions only")
+    return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, relu, out_f32, 1 if segs is None else (1, tuple(segs)), mod.weight, mod.bias)
+
+
+def ragged_cat(feats):
+    """Pyramid levels [N,X_l,Y_l,Z_l,C] -> one ragged voxel list [1, sum N*X*Y*Z, 1, 1, C] (level-major, scene-major inside a level)
+    plus the per-segment grid dims; layers that share weights across levels then run as ONE launch (ops.ConvFn with segs)."""
+    import torch
+    n, c = feats[0].shape[0], feats[0].shape[-1]
+    segs = [tuple(int(v) for v in f.shape[1:4]) for f in feats for _ in range(n)]
+    x = torch.cat([f.reshape(-1, c) for f in feats], dim=0)
+    return x.view(1, x.shape[0], 1, 1, c), segs
+
+
+def ragged_split(x, feats):
+    """Inverse view of ``ragged_cat`` for a tensor with any channel count: per-level [N,X_l,Y_l,Z_l,C'] views."""
+    outs, off = [], 0
+    for f in feats:
+        cnt = f.shape[0] * f.shape[1] * f.shape[2] * f.shape[3]
+        outs.append(x[0, off:off + cnt, 0, 0, :].view(f.shape[0], f.shape[1], f.shape[2], f.shape[3], x.shape[-1]))
+        off += cnt
+    return outs
 
 
 def batch_norm(mod, x, relu):

@@ -382,7 +382,15 @@ class PackedWeight:
         return fwd, dgrad
 
 
-def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype):
+def _seg_dims(segs):
+    import ctypes
+    flat = [int(v) for d in segs for v in d]
+    return (ctypes.c_int32 * len(flat))(*flat)
+
+
+def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None):
+    """segs: None, or the (X, Y, Z) dims of the grids laid end to end in x = [1, sum(X*Y*Z), 1, 1, C] (ragged list)."""
+    import ctypes
     n, gx, gy, gz, cin = x.shape
     y = torch.empty((n, gx, gy, gz, cout), dtype=out_dtype, device=x.device)
     if out_dtype == torch.float32 and x.dtype == torch.bfloat16:
@@ -391,7 +399,12 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype):
         flags |= CONV_BIAS
     wsb = query("conv3d_fwd_workspace_bytes", n, gx, gy, gz, cin, cout, ksize, _dt(x))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-    call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), _s())
+    if segs is None or ksize == 1:
+        call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), _s())
+    else:
+        dims = _seg_dims(segs)
+        call("conv3d_fwd_ragged", _p(x), _p(wp), _p(bias), _p(y), len(segs), ctypes.addressof(dims), cin, cout, wrows, ksize, _dt(x), flags,
+             _p(ws), _s())
     return y
 
 
@@ -402,6 +415,9 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pack, rows_total, relu, out_f32, nw, *wb):
+        segs = None
+        if isinstance(nw, tuple):          # (nw, segs): ragged voxel list, x = [1, sum voxels, 1, 1, C]
+            nw, segs = nw
         weights, biases = wb[:nw], wb[nw:]
         _chk(x)
         ksize = weights[0].shape[2] if weights[0][0].numel() != x.shape[-1] else 1
@@ -413,16 +429,16 @@ class ConvFn(torch.autograd.Function):
             if bias.numel() < rows_total:
                 bias = torch.cat([bias, bias.new_zeros(rows_total - bias.numel())])
         out_dtype = torch.float32 if out_f32 else x.dtype
-        y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype)
+        y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs)
         ctx.save_for_backward(x, y if relu else None, wpd, *weights)
-        ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None)
+        ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None, segs)
         ctx.sinks = ([_sink(w) for w in weights], [_sink(b) for b in biases])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, wpd, *weights = ctx.saved_tensors
-        rows_total, relu, nw, ksize, has_bias = ctx.meta
+        rows_total, relu, nw, ksize, has_bias, segs = ctx.meta
         n, gx, gy, gz, cin = x.shape
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
@@ -434,7 +450,7 @@ class ConvFn(torch.autograd.Function):
             dy = dyr
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype)
+            dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype, segs)
         taps = ksize ** 3
         wsinks, bsinks = ctx.sinks
         slices = query("conv3d_wgrad_slices", n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x))
@@ -443,8 +459,14 @@ class ConvFn(torch.autograd.Function):
         gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
         wsb = query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, ksize)
         ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-        call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), int(direct_bias),
-             _p(ws), _s())
+        if segs is None or ksize == 1:
+            call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), int(direct_bias),
+                 _p(ws), _s())
+        else:
+            import ctypes
+            dims = _seg_dims(segs)
+            call("conv3d_wgrad_ragged", _p(x), _p(dy), _p(gwp), _p(gb), len(segs), ctypes.addressof(dims), cin, rows_total, rows_total, ksize,
+                 _dt(x), int(direct_bias), _p(ws), _s())
         gws, gbs, row = [], [], 0
         for i, w in enumerate(weights):
             if wsinks[i] is not None:

@@ -230,3 +230,34 @@ def test_large_tile_kernels_match_the_128_tile_kernels(case, dev):
     lib.call("set_wgrad_big_tile", 1)
     for name, a, b in zip(("y", "dx", "dw", "db"), res["auto"], res["base"]):
         assert relerr(a.cpu(), b.cpu()) < (1e-2 if name in ("y", "dx") else 1e-4), (case, name, relerr(a.cpu(), b.cpu()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("grids,cin,cout", [([(6, 5, 4), (3, 3, 2), (9, 2, 1), (1, 1, 1)], 64, 128), ([(12, 10, 9), (6, 5, 5), (3, 3, 3)], 256, 256),
+                                            ([(40, 40, 36), (20, 20, 18), (10, 10, 9), (5, 5, 5)], 256, 256)])
+def test_ragged_conv_equals_per_grid_convs(grids, cin, cout, dtype, dev):
+    """A weight-sharing 3x3x3 conv over several grids laid end to end in ONE launch (ragged voxel list: per-row grid geometry in the
+    implicit-GEMM loaders, segment ids in the wgrad tap masks) == the same conv run grid by grid: forward, dgrad, wgrad, bias."""
+    from nerf_rpn_amd.model import hip_nn
+    torch.manual_seed(2)
+    n = 2 if grids[0][0] < 20 else 1
+    conv = nn.Conv3d(cin, cout, 3, padding=1).to(dev)
+    feats = [torch.randn(n, *g, cin, device=dev).to(dtype) for g in grids]
+    gys = [(torch.randn(n, *g, cout, device=dev) * (torch.rand(n, *g, 1, device=dev) < 0.5)).to(dtype) for g in grids]
+    xs = [f.clone().requires_grad_(True) for f in feats]
+    ys = [hip_nn.conv3d(conv, x, relu=True) for x in xs]
+    torch.autograd.backward(ys, gys)
+    ref = ([y.detach().float() for y in ys], [x.grad.float() for x in xs], conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.zero_grad()
+    xr = [f.clone().requires_grad_(True) for f in feats]
+    rag, segs = hip_nn.ragged_cat(xr)
+    assert len(segs) == n * len(grids)
+    yr = hip_nn.ragged_split(hip_nn.conv3d(conv, rag, relu=True, segs=segs), feats)
+    torch.autograd.backward(yr, gys)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for a, b in zip(yr, ref[0]):
+        assert a.shape == b.shape and relerr(a.detach().float().cpu(), b.cpu()) < tol
+    for x, b in zip(xr, ref[1]):
+        assert relerr(x.grad.float().cpu(), b.cpu()) < tol
+    assert relerr(conv.weight.grad.cpu(), ref[2].cpu()) < (1e-5 if dtype == torch.float32 else 1e-4)
+    assert relerr(conv.bias.grad.cpu(), ref[3].cpu()) < 1e-5
