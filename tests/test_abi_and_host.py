@@ -90,3 +90,29 @@ def test_swin_and_fcos_state_dict_keys_match_reference_layout():
         ref = OF.FCOSHead(256, 4, [4, 8, 16, 32], True, True, rot)
         got = {k: v.shape for k, v in mod.state_dict().items()}
         assert got == {"head." + k: v.shape for k, v in ref.state_dict().items()}       # checkpoint key 'fcos_state_dict' holds head.*
+
+
+def test_host_side_geometry_helpers():
+    """Pure host logic used around the kernels: flattened FCOS location bookkeeping, ragged voxel lists, scene stacking."""
+    import torch
+    from nerf_rpn_amd import ops
+    from nerf_rpn_amd.model import hip_nn
+    geom = ops.FcosGeometry(2, [(10, 8, 6), (5, 4, 3), (3, 2, 2)], [4, 8, 16])
+    assert geom.counts == [480, 60, 12] and geom.total == 2 * 552
+    assert geom.segment_offsets == [0, 480, 960, 1020, 1080, 1092, 1104]            # (level, scene) segments, level-major
+    feats = [torch.arange(2 * x * y * z * 3, dtype=torch.float32).view(2, x, y, z, 3) for (x, y, z) in ((4, 3, 2), (2, 2, 1), (1, 1, 1))]
+    rag, segs = hip_nn.ragged_cat(feats)
+    assert rag.shape == (1, 2 * (24 + 4 + 1), 1, 1, 3) and segs == [(4, 3, 2)] * 2 + [(2, 2, 1)] * 2 + [(1, 1, 1)] * 2
+    back = hip_nn.ragged_split(rag, feats)
+    assert all(torch.equal(a, b) for a, b in zip(back, feats))
+    # channels-last-backed scenes keep their memory layout through the stack, plain ones stack as usual
+    cl = [torch.rand(5, 4, 3, 4).permute(3, 0, 1, 2) for _ in range(2)]
+    st = ops.stack_scenes(cl)
+    assert st.shape == (2, 4, 5, 4, 3) and st.permute(0, 2, 3, 4, 1).is_contiguous() and torch.equal(st[1], cl[1])
+    plain = [torch.rand(4, 5, 4, 3) for _ in range(2)]
+    assert torch.equal(ops.stack_scenes(plain), torch.stack(plain))
+    from nerf_rpn_amd.datasets import RawScene
+    rs = RawScene(torch.zeros(7, 6, 5, 4), 1)
+    assert tuple(rs.shape) == (4, 7, 6, 5)
+    import pickle
+    assert pickle.loads(pickle.dumps(rs)).alpha_mode == 1                              # travels through DataLoader workers
