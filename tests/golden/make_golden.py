@@ -379,6 +379,7 @@ def gen_train():
     print("end-to-end train")
     cases = [("train_swin_obb", True, "smooth_l1", [(80, 56, 48)]),      # stochastic depth 0 (the draw is RNG-stream specific)
              ("train_resnet_aabb", False, "smooth_l1", [(64, 56, 48)]),
+             ("train_resnet_obb_iou", True, "iou", [(64, 56, 48)]),        # BASELINE configs[4]: ResNet-50 + rotated-IoU loss
              ("train_aabb", False, "smooth_l1", [(48, 48, 48)]),
              ("train_obb", True, "smooth_l1", [(48, 40, 32)]),
              ("train_obb_iou", True, "iou", [(48, 40, 32)]),
