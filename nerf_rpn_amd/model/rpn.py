@@ -134,12 +134,15 @@ class RegionProposalNetwork(nn.Module):
         return boxes_out, scores_out, levels_out
 
     # -------------------------------------------------------------------------------------------------------- train
-    def assign_targets_to_anchors(self, table, targets: List[Tensor], ori_sizes):
+    def assign_targets_to_anchors(self, table, targets: List[Tensor], ori_sizes, padding_masks: Optional[Tensor] = None):
         labels, matched = [], []
         dev = table.words.device
         for i, gt in enumerate(targets):
             if gt.numel() == 0:
-                labels.append(torch.zeros(table.total, dtype=torch.float32, device=dev))
+                lab = torch.zeros(table.total, dtype=torch.float32, device=dev)
+                if padding_masks is not None:          # anchors in the zero padding of a batched scene are ignored here too (rpn.py:281-283)
+                    lab = lab.masked_fill(~padding_masks[i], -1.0)
+                labels.append(lab)
                 matched.append(torch.zeros(table.total, dtype=torch.int32, device=dev))
                 continue
             gt_aabb = obb2hbb_3d(gt) if gt.size(1) == 7 else gt
@@ -231,7 +234,7 @@ class RegionProposalNetwork(nn.Module):
         else:
             if targets is None:
                 raise ValueError("targets should not be None")
-            labels, matched = self.assign_targets_to_anchors(table, targets, original_mesh_sizes if n > 1 else None)
+            labels, matched = self.assign_targets_to_anchors(table, targets, original_mesh_sizes if n > 1 else None, pad)
             lo, lr, l2 = self.compute_loss(table, logits, deltas, labels, matched, targets, max(mesh_size))
             losses = {"loss_objectness": lo, "loss_rpn_box_reg": lr, "loss_rpn_box_reg_2d": l2}
         return boxes, level_indexes, losses, scores

@@ -81,7 +81,7 @@ def test_eval_matches_reference(name, golden, dev):
 
 
 @pytest.mark.parametrize("name", ["train_aabb", "train_obb", "train_obb_iou", "train_obb_giou", "train_obb_diou", "train_aabb_batch2",
-                                  "train_resnet_aabb", "train_resnet_obb_iou", "train_swin_obb"])
+                                  "train_resnet_aabb", "train_resnet_obb_iou", "train_swin_obb", "train_aabb_batch2_emptygt"])
 def test_train_matches_reference(name, golden, dev):
     g = golden(name)
     rot = bool(g["rotated"])
