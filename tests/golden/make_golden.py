@@ -480,7 +480,9 @@ def gen_fcos():
     only = os.environ.get("GOLDEN_ONLY")
     evals = [("fcos_eval_aabb_vgg", False, "vgg", [(64, 56, 48)], {}),
              ("fcos_eval_obb_swin", True, "swin", [(80, 56, 48)], {}),
-             ("fcos_eval_obb_batch2", True, "vgg", [(64, 48, 48), (48, 40, 32)], {"pre_nms_top_n": 300, "fpn_post_nms_top_n": 400})]
+             ("fcos_eval_obb_batch2", True, "vgg", [(64, 48, 48), (48, 40, 32)], {"pre_nms_top_n": 300, "fpn_post_nms_top_n": 400}),
+             # candidate threshold on sigmoid(cls) and the small-box filter (inference.py:76-78, 134-136)
+             ("fcos_eval_aabb_thresh", False, "vgg", [(64, 56, 48)], {"pre_nms_thresh": 0.2, "min_size": 4.0})]
     for name, rot, bbk, shapes, kw in evals:
         if only and only not in name:
             continue
@@ -491,7 +493,8 @@ def gen_fcos():
             boxes, _, scores = ref([x.clone() for x in xs])
             oboxes, _, oscores, aux = orc([x.clone() for x in xs])
         arrs = {"shapes": shapes, "rotated": rot, "backbone": bbk, "pre_nms_top_n": kw.get("pre_nms_top_n", 2500),
-                "fpn_post_nms_top_n": kw.get("fpn_post_nms_top_n", 2500)}
+                "fpn_post_nms_top_n": kw.get("fpn_post_nms_top_n", 2500), "pre_nms_thresh": kw.get("pre_nms_thresh", 0.0),
+                "min_size": kw.get("min_size", 0.0)}
         for key in ("box_cls", "box_reg", "centerness"):
             for l, t in enumerate(aux[key]):
                 idx, val = subsample(t, 1024)

@@ -122,11 +122,12 @@ def test_targets_match_reference(name, golden, dev):
     assert torch.allclose(got[pos], ref[pos], atol=2e-5, rtol=1e-5), (got[pos] - ref[pos]).abs().max()
 
 
-@pytest.mark.parametrize("name", ["fcos_eval_aabb_vgg", "fcos_eval_obb_swin", "fcos_eval_obb_batch2"])
+@pytest.mark.parametrize("name", ["fcos_eval_aabb_vgg", "fcos_eval_obb_swin", "fcos_eval_obb_batch2", "fcos_eval_aabb_thresh"])
 def test_eval_matches_reference(name, golden, dev):
     g = golden(name)
     rot = bool(g["rotated"])
-    m = build(rot, str(g["backbone"]), dev, pre_nms_top_n=int(g["pre_nms_top_n"]), fpn_post_nms_top_n=int(g["fpn_post_nms_top_n"])).eval()
+    extra = {k: float(g[k]) for k in ("pre_nms_thresh", "min_size") if k in g}
+    m = build(rot, str(g["backbone"]), dev, pre_nms_top_n=int(g["pre_nms_top_n"]), fpn_post_nms_top_n=int(g["fpn_post_nms_top_n"]), **extra).eval()
     xs = [scene(s, 300 + i).to(dev) for i, s in enumerate(g["shapes"])]
     with torch.no_grad():
         boxes, losses, scores = m(xs)
