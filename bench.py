@@ -125,41 +125,153 @@ class ConvProbe:
         total_ms = sum(v[1] for _, v in rows)
         total_fl = sum(v[0] * v[2] for _, v in rows)
         vox, cin_, cout_, _k = shape
-        if name == "conv3d_fwd":     # tile selection of launch_conv (csrc/conv3d.hip)
-            big = cout_ >= 256 and -(-vox // 256) * -(-cout_ // 256) >= 200
-            kernel = "conv_igemm_big_kernel" if big else "conv_igemm_kernel"
+        code = self.lib.BF16 if dtype_name == "bf16" else self.lib.F32
+        if name == "conv3d_fwd":     # ask the library which kernel launch_conv selects for this shape
+            plan = self.lib.query("conv3d_fwd_plan", 1, vox, 1, 1, cin_, cout_, _k, code)
+            kernel = {0: "conv_igemm_kernel", 1: "conv_igemm_big_kernel", 2: "conv_igemm_big_kernel (K slices)",
+                      3: "conv_igemm_kernel (K slices)", 4: "conv_igemm_ws_kernel"}[plan]
         else:
-            kernel = "conv_wgrad_big_kernel" if (cin_ >= 256 and cout_ >= 256) else "conv_wgrad_kernel"
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_256x256_40c.json")
+            kernel = "conv_wgrad_big_kernel" if self.lib.query("conv3d_wgrad_plan", 1, vox, 1, 1, cin_, cout_, cout_, _k, code) else "conv_wgrad_kernel"
+        es = 2 if dtype_name == "bf16" else 4
+        algo_bytes = vox * cin_ * es + vox * cout_ * es + (_k ** 3) * cin_ * cout_ * es      # x + y + w, each once
+        traffic, note = None, "no PMC collection for this kernel in profiles/ (null = not measured)"
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_conv_256x256_40c.json")
         if os.path.exists(pmc) and shape == (64000, 256, 256, 3):
-            for kname, vals in json.load(open(pmc))["kernels"].items():
-                if kname.startswith(kernel):
-                    traffic = vals.get("l2_miss_bytes (TCC_MISS_sum*128)", vals.get("hbm_bytes_est (FETCH_SIZE*2*1024 + WRITE_SIZE*1024)"))
+            d = json.load(open(pmc))
+            k = d.get("kernels", {}).get(kernel.split(" ")[0])
+            if k and k.get("hbm_bytes") is not None:
+                traffic, note = k["hbm_bytes"], d.get("method", "")
         roof = {"bound": "mfma", "kernel": kernel,
                 "shape": {"voxels": shape[0], "cin": shape[1], "cout": shape[2], "k": shape[3]}, "launches": cnt,
                 "avg_ms": round(avg_ms, 4), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_note": "bytes beyond L2 (MALL+HBM) per launch = TCC_MISS_sum x 128 B from rocprofv3 --pmc "
-                                "(profiles/r01_pmc_conv_256x256_40c.json); algorithmic bytes of this launch = 69 MB (x 32.8 + w 3.5 + y 32.8)",
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note, "algorithmic_bytes": algo_bytes,
                 "timed_heavy_launches": {"tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2), "ms_per_step": None}}
         return roof, rows
 
 
+# Algorithmic work of one 160^3 scene: FLOPs = 2 * MACs of every conv; bytes = each activation read
+# once per consumer and written once, weights once, BN/ReLU fused.
+FWD_VGG_FPN_GFLOP = 1713.2
+FWD_VGG_FPN_GB = {"bf16": 0.974, "f32": 1.947}
+STEP_GFLOP = 8168.0
+HBM_PEAK_GBS = 8000.0
+
+
+def forward_only(model, x, dtype_name, iters=10):
+    """VGG19-3D + FPN forward alone (north_star's forward roofline): eval-mode backbone on the resident scene, HIP events."""
+    was = model.training
+    model.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            model.backbone(x.unsqueeze(0))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            model.backbone(x.unsqueeze(0))
+        b.record()
+        torch.cuda.synchronize()
+    model.train(was)
+    ms = a.elapsed_time(b) / iters
+    tf = FWD_VGG_FPN_GFLOP / ms            # GFLOP / ms = TFLOP/s
+    gbs = FWD_VGG_FPN_GB[dtype_name] / (ms * 1e-3)
+    return {"ms": round(ms, 3), "scenes_per_s": round(1e3 / ms, 2), "gflop": FWD_VGG_FPN_GFLOP, "tflops": round(tf, 1),
+            "mfma_frac": round(tf / MFMA_PEAK_TFLOPS[dtype_name], 4), "algorithmic_gb": FWD_VGG_FPN_GB[dtype_name],
+            "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+            "hbm_frac_ceiling": 0.18 if dtype_name == "bf16" else None,
+            "note": "MFMA-bound (1760 FLOP/B bf16 >> ridge 310): the whole-forward HBM fraction cannot exceed ~18 % even at 100 % "
+                    "of the dense MFMA peak (SURVEY 8d); eval-mode BatchNorm (running statistics)"}
+
+
+def hbm_stages(dtype, dev):
+    """Achieved HBM GB/s of the HBM-bound kernels of the step, each on its largest shape in the 160^3 VGG19 configuration (fresh
+    buffers, 20 back-to-back launches between HIP events; bytes = algorithmic: every operand read / written once)."""
+    from nerf_rpn_amd import lib, ops
+    es = 2 if dtype == torch.bfloat16 else 4
+    out = []
+
+    def timed(name, shape, nbytes, fn, iters=20):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = 1e3 * a.elapsed_time(b) / iters
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out.append({"kernel": name, "shape": shape, "bytes": int(nbytes), "avg_us": round(us, 1), "gbs": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)})
+
+    def P(t):
+        return t.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    for rows, c in ((80 ** 3, 64), (40 ** 3, 256)):
+        x = torch.randn(rows, c, device=dev).to(dtype)
+        y, dy, dx = torch.empty_like(x), torch.randn(rows, c, device=dev).to(dtype), torch.empty_like(x)
+        mean, var = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ws = torch.empty(lib.query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=dev)
+        code = ops._dt(x)
+        timed("bn_stats", f"{c}@{rows}", rows * c * es, lambda: lib.call("bn_stats", P(x), rows, c, code, P(mean), P(var), 0, 0, 0.1, P(ws), st))
+        timed("bn_apply+relu", f"{c}@{rows}", 2 * rows * c * es,
+              lambda: lib.call("bn_apply", P(x), P(y), rows, c, code, P(mean), P(var), P(g), P(bta), 1e-5, 1, st))
+        timed("bn_backward", f"{c}@{rows}", 5 * rows * c * es,
+              lambda: lib.call("bn_backward", P(x), 0, P(dy), P(dx), rows, c, code, P(mean), P(var), P(g), P(bta), 1e-5, 1, P(dg), P(db), 0, 0,
+                               P(ws), st))
+    for (gx, c, k, s_, p_, ceil) in ((80, 64, 3, 2, 1, 0), (40, 256, 2, 2, 0, 1)):
+        x = torch.randn(1, gx, gx, gx, c, device=dev).to(dtype)
+        o = lib.query("pool_out_size", gx, k, s_, p_, ceil)
+        y = torch.empty(1, o, o, o, c, device=dev, dtype=dtype)
+        arg = torch.empty(y.shape, dtype=torch.int8, device=dev)
+        dx = torch.empty_like(x)
+        code = ops._dt(x)
+        timed("maxpool3d_fwd", f"{c}@{gx}^3 k{k}s{s_}", x.numel() * es + y.numel() * (es + 1),
+              lambda: lib.call("maxpool3d_fwd", P(x), P(y), P(arg), 1, gx, gx, gx, c, k, s_, p_, ceil, code, st))
+        timed("maxpool3d_bwd", f"{c}@{gx}^3 k{k}s{s_}", x.numel() * es + y.numel() * (es + 1),
+              lambda: lib.call("maxpool3d_bwd", P(y), P(arg), P(dx), 1, gx, gx, gx, c, k, s_, p_, ceil, code, st))
+    fine = torch.randn(1, 40, 40, 40, 256, device=dev).to(dtype)
+    coarse = torch.randn(1, 20, 20, 20, 256, device=dev).to(dtype)
+    code = ops._dt(fine)
+    timed("upsample_add_fwd", "256@40^3 += 256@20^3", 2 * fine.numel() * es + coarse.numel() * es,
+          lambda: lib.call("upsample_add_fwd", P(fine), P(coarse), 1, 40, 40, 40, 20, 20, 20, 256, code, st))
+    timed("upsample_add_bwd", "256@40^3 -> 256@20^3", fine.numel() * es + coarse.numel() * es,
+          lambda: lib.call("upsample_add_bwd", P(fine), P(coarse), 1, 40, 40, 40, 20, 20, 20, 256, code, 0, st))
+    n = 74_815_925
+    pa, ga, m, v = (torch.zeros(n, device=dev) for _ in range(4))
+    ga.normal_()
+    ss = torch.zeros(lib.query("grad_sumsq_floats"), device=dev)
+    timed("grad_sumsq", f"{n} f32", 4 * n, lambda: ops.grad_sumsq(ga, ss, 1.0))
+    timed("adamw_step", f"{n} f32 (p,m,v rw + g r)", 28 * n, lambda: ops.adamw_step(pa, ga, m, v, ss, 0.1, 1e-4, (0.9, 0.999), 1e-8, 0.01, 1))
+    slices = lib.query("conv3d_wgrad_slices", 1, 40, 40, 40, 256, 256, 256, 3, ops._dt(fine))
+    gwp = torch.randn(slices, 27, 256, 256, device=dev)
+    gw = torch.zeros(256, 256, 27, device=dev)
+    timed("unpack_conv_wgrad", f"256x256x27, {slices} slices -> arena (+=)", (slices + 2) * 27 * 256 * 256 * 4,
+          lambda: lib.call("unpack_conv_wgrad", P(gwp), 256, 256, 27, 256, 0, P(gw), 1, slices, st))
+    return out
+
+
 def cpu_baseline():
-    """The oracle (CPU restatement of the reference, torch fp32 on the host cores): one fwd+bwd of the same 160^3 scene."""
+    """The oracle (CPU restatement of the reference, torch fp32 on the host cores): fwd+bwd of the same 160^3 scene, one untimed
+    warm-up pass then one timed pass (each ~15 s on the GPU box's cores)."""
     from oracle import nets as ON, rpn as OR
     torch.manual_seed(0)
     bb, hd = ON.VGGFPN("EF", 4, GRID), ON.RPNHead(256, 13, 4, True)
     det = OR.Detector(bb, OR.RPN(hd, rotated=True))
     bb.train()
     x, gt = synthetic_scene(0, "cpu")
-    t0 = time.time()
-    _, losses, _, _ = det([x], [gt], training=True)
-    (losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"]).backward()
-    dt = time.time() - t0
+    times = []
+    for _ in range(2):
+        det.zero_grad(set_to_none=True) if hasattr(det, "zero_grad") else None
+        t0 = time.time()
+        _, losses, _, _ = det([x], [gt], training=True)
+        (losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"]).backward()
+        times.append(time.time() - t0)
+    dt = times[-1]
     return {"value": round(1.0 / dt, 5), "unit": "scenes/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 fwd+bwd of one {GRID}^3x4 scene (VGG19-EF+FPN+RPN, OBB, fp32, no optimiser step), {dt:.1f} s"}
+            "sample": f"1 warm-up ({times[0]:.1f} s) + 1 timed fwd+bwd of one {GRID}^3x4 scene (VGG19-EF+FPN+RPN, OBB, fp32, no optimiser "
+                      f"step), {dt:.1f} s; n=1"}
 
 
 def main():
@@ -174,9 +286,21 @@ def main():
                     help="vgg_rpn = the BASELINE.json metric (default); the others are secondary workloads for profiling")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N ranks (one per GPU) over RCCL ourselves
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -212,6 +336,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     probe.enabled = not args.no_probe
+    from nerf_rpn_amd import ops as _ops0
+    packs0 = _ops0.PACK_COUNT["conv"] + _ops0.PACK_COUNT["stem"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -220,6 +346,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
+    from nerf_rpn_amd import ops as _ops
+    packs_per_step = (_ops.PACK_COUNT["conv"] + _ops.PACK_COUNT["stem"] - packs0) / args.steps
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,13 +359,22 @@ def main():
         if roof is not None:
             conv_ms = sum(v[1] for _, v in rows) / args.steps
             roof["timed_heavy_launches"]["ms_per_step"] = round(conv_ms, 3)
+            if args.model == "vgg_rpn":
+                step_tf = STEP_GFLOP / (1e3 * elapsed / args.steps)
+                roof["step"] = {"gflop": STEP_GFLOP, "tflops": round(step_tf, 1), "mfma_frac": round(step_tf / MFMA_PEAK_TFLOPS[args.dtype], 4),
+                                "note": "whole training step (fwd + dgrad + wgrad + everything else) against the dense MFMA peak"}
+                roof["forward_vgg19_fpn"] = forward_only(model, x, args.dtype)
+                roof["hbm_stages"] = hbm_stages(dtype, dev)
         out = {
             "metric": "scenes/sec (160^3x4 grids, VGG19-3D+FPN+RPN fwd+bwd)", "value": round(world * args.steps / elapsed, 4),
             "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: one 160x160x160x4 rgb-sigma grid per GPU, VGG19-EF 3D + FPN + anchor RPN (OBB, 16 GT "
-                                   "boxes), fwd+bwd+clip+AdamW, random-init weights", "scenes_per_gpu": 1, "parallelism": f"dp{world}"},
+                                   "boxes), fwd+bwd+clip+AdamW (weights repacked every step), random-init weights", "scenes_per_gpu": 1,
+                       "parallelism": f"dp{world}", "world_size_seen": world,
+                       "backend": (dist.get_backend() if world > 1 else "single process")},
+            "weight_packs_per_step": packs_per_step,
             "final_loss": round(final_loss, 5),
             "roofline": roof,
         }

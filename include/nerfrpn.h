@@ -180,15 +180,17 @@ int nrpn_pack_conv_weight(const float *w_ref, int cout, int cin, int taps, int d
 int nrpn_unpack_conv_wgrad(const float *gw_packed, int cout, int cin, int taps, int rows_total, int row_offset,
                            float *gw_ref, int accumulate, int slices, nrpn_stream_t stream);
 /* `workspace` (nrpn_conv3d_fwd_workspace_bytes; may be NULL = never split): for small grids the K loop is split over
- * blockIdx.z and fp32 partials are reduced through it so the 10^3 / 5^3 pyramid levels still fill 256 CUs. */
+ * K slices whose fp32 partials are stored to it and summed in slice order (deterministic, no atomics) so the 10^3 / 5^3
+ * pyramid levels still fill 256 CUs. */
 size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
 int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
                     int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream);
 /* wgrad: the voxel axis is cut into S = nrpn_conv3d_wgrad_slices(...) slices; every (tile, tap, slice) workgroup writes
  * its partial with plain stores into gw_packed f32 [S][taps][wrows][Cin] (fully overwritten: no memset, no atomics --
  * cross-XCD fp32 atomics were ~1/3 of the kernel time); nrpn_unpack_conv_wgrad sums the slices.
- * optional gbias f32 [Cout] = column sums of dy. */
-size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int ksize);
+ * optional gbias f32 [Cout] = column sums of dy (per-slice partials in the workspace, summed in slice order: deterministic).
+ * `workspace` (always required) = k3 tap masks + the bias partials. */
+size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 /* accumulate_bias != 0: the column sums are ADDED to gbias (e.g. a slot of a flat gradient arena) instead of overwriting. */
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
@@ -203,6 +205,10 @@ int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, voi
 int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, float *gbias, int nseg, const int32_t *dims,
                              int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
                              nrpn_stream_t stream);
+/* kernel selection of a forward / dgrad launch: 0 = 128-row tile, 1 = 256x256 tile, 2 = 256x256 tile on K slices, 3 = 128-row tile on
+ * K slices, 4 = wave-specialised 256x128;  of a wgrad launch: 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */
+int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
+int nrpn_conv3d_wgrad_plan(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 /* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
 int nrpn_set_conv_kstep_bytes(int kb);
 /* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */
@@ -212,7 +218,6 @@ int nrpn_set_conv_lds_dma(int on);
 int nrpn_set_conv_tile_m(int bm);
 /* tuning knob: 1 (default) = 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256; 0 = always the 128x128 kernel */
 int nrpn_set_wgrad_big_tile(int on);
-int nrpn_colsum(const void *dy, long long rows, int c, int dtype, float *out, nrpn_stream_t stream);
 /* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
 int nrpn_set_wgrad_transpose_read(int on);
 /* Stem: Conv3d(4 -> Cout, k7, pad 3, stride 1|2) on [N,X,Y,Z,4] (feature_extractor.py:336,341) as an im2col GEMM
@@ -226,8 +231,9 @@ int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *g
                            nrpn_stream_t stream);
 int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz,
                          int cout, int stride, int dtype, int flags, nrpn_stream_t stream);
+size_t nrpn_stem_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cout, int stride, int dtype);
 int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
-                           int cout, int stride, int dtype, int accumulate_bias, nrpn_stream_t stream);
+                           int cout, int stride, int dtype, int accumulate_bias, void *workspace, nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm3d / ReLU / MaxPool3d / nearest-upsample-add, channels-last.  [a3, a4, a21]
@@ -370,9 +376,12 @@ int nrpn_fcos_decode_f32(const int32_t *idx, const float *score, int64_t count, 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 arena.  [a21]  (clip_grad_norm_ + AdamW, run_rpn.py:345-349,390-395)
  *   grad_scale folds the 1/world_size of the data-parallel mean into both kernels (sum all-reduce, no extra pass).
- *   sumsq: f32 device scalar = sum((g*grad_scale)^2) (zeroed by nrpn_grad_sumsq); step applies g *= grad_scale * min(1, max_norm/(sqrt(sumsq)+1e-6)),
+ *   sumsq: f32 device buffer of nrpn_grad_sumsq_floats() elements; [0] = sum((g*grad_scale)^2), the rest is scratch of the
+ *   deterministic two-level reduction (fixed-size block partials summed in index order: bit-identical from run to run);
+ *   step applies g *= grad_scale * min(1, max_norm/(sqrt(sumsq[0])+1e-6)),
  *   then decoupled-weight-decay Adam with bias correction (torch.optim.AdamW semantics).
  * ---------------------------------------------------------------------------------------------- */
+int nrpn_grad_sumsq_floats(void);
 int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scale, float *sumsq, nrpn_stream_t stream);
 int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count,
                     const float *sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,

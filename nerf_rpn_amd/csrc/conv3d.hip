@@ -131,9 +131,9 @@ struct ConvArgs {
   int stride;         // MODE 1 only
   int flags;
   unsigned x_bytes, w_bytes;   // extents for the raw-buffer descriptors (out-of-range lanes read 0)
-  int ksplit;         // > 1: blockIdx.z owns a slice of the K loop and atomically adds fp32 partials into `ws`
-  float *ws;          // [M][Cout] fp32, zero-filled by the launcher (split-K only)
-  int slices;         // 1: split-K partials go to ws[z][M][Cout] with plain stores (256x256 kernel); 0: atomics into ws[M][Cout]
+  int ksplit;         // > 1: workgroup id / tiles owns a slice of the K loop and stores its fp32 partial into ws[slice][M][Cout]
+  float *ws;          // [ksplit][M][Cout] fp32 partials (plain stores, summed in slice order by splitk_epilogue_kernel: deterministic)
+  int slices;         // 1: the K slices run on the 256x256 kernel (mid-size grids, conv_big_split); 0: on the 128-row kernel
   Segs segs;          // MODE 0 only: ragged voxel list (n > 0) instead of N copies of X*Y*Z
 };
 
@@ -214,11 +214,10 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
 
   // split-K: this workgroup runs K-steps [ks_begin, ks_end)
   int ks_begin = 0, ks_end = nk;
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1) {   // the launcher trims ksplit so that no slice is empty (every partial is fully written)
     const int per = (nk + p.ksplit - 1) / p.ksplit;
     ks_begin = zsplit * per;
     ks_end = min(nk, ks_begin + per);
-    if (ks_begin >= ks_end) return;
   }
 
   // MODE 0: byte offsets for the raw-buffer loads (loop invariant); kOOB marks rows that must read zeros
@@ -398,7 +397,9 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     }
   }
 
-  if (p.ksplit > 1) {   // partial sums; bias / ReLU / cast happen in splitk_epilogue_kernel
+  if (p.ksplit > 1) {   // fp32 partial of this K slice, plain stores (deterministic); the slices are summed in order, then bias /
+                        // ReLU / cast, by splitk_epilogue_kernel
+    float *wsz = p.ws + (long long)zsplit * p.M * p.Cout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + fr;
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, lane);
-          if (v < p.M) atomicAdd(p.ws + v * p.Cout + col, acc[i][j][r]);
+          if (v < p.M) wsz[v * p.Cout + col] = acc[i][j][r];
         }
     }
     return;
@@ -845,6 +846,9 @@ static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes)
   long long s = (384 + tiles - 1) / tiles;
   if (s > nk / 8) s = nk / 8;
   if (s > 64) s = 64;
+  if (s < 2) return 1;
+  const long long per = (nk + s - 1) / s;
+  s = (nk + per - 1) / per;                  // no empty slice: every slice writes its whole partial
   return s < 2 ? 1 : (int)s;
 }
 
@@ -944,7 +948,23 @@ extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz,
   const int bs = conv_big_split(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
   if (bs) return (size_t)bs * M * cout * 4;
   const int s = conv_ksplit(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
-  return s > 1 ? (size_t)(M * cout * 4) : 0;
+  return s > 1 ? (size_t)s * M * cout * 4 : 0;
+}
+
+// Which kernel a forward / dgrad launch of this shape selects (mirrors launch_conv + conv3d_fwd_impl; lets tests assert that a
+// shape really exercises the kernel they claim to cover): 0 = 128-row tile, 1 = 256x256 tile, 2 = 256x256 tile on K slices,
+// 3 = 128-row tile on K slices, 4 = wave-specialised 256x128 (opt-in).
+extern "C" int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
+  const long long M = (long long)n * gx * gy * gz;
+  const int es = dtype == NRPN_F32 ? 4 : 2, taps = ksize == 3 ? 27 : 1;
+  if (conv_big_split(M, cout, cin, taps, es)) return 2;
+  if (conv_ksplit(M, cout, cin, taps, es) > 1) return 3;
+  const bool wide = g_conv_kb == 128 && (cin * es) % 128 == 0;
+  const bool can = g_conv_glds && wide && cout > 64 && es == 2;
+  const long long tiles_big = cdiv64(M, 256) * ((cout + 255) / 256);
+  if (can && cout >= 256 && (g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200))) return 1;
+  if (can && g_conv_bm == 256) return 4;
+  return 0;
 }
 
 static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, void *y, long long M, int gx, int gy, int gz, const Segs *segs,
@@ -971,12 +991,9 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, voi
     a.ksplit = bs; a.slices = 1; a.ws = reinterpret_cast<float *>(workspace);
   } else {
     a.ksplit = workspace ? conv_ksplit(a.M, cout, cin, a.taps, es) : 1;
-    if (a.ksplit > 1) {
-      a.ws = reinterpret_cast<float *>(workspace);
-      NRPN_HIP(hipMemsetAsync(workspace, 0, (size_t)(a.M * cout * 4), st));
-    }
+    if (a.ksplit > 1) a.ws = reinterpret_cast<float *>(workspace);
   }
-  const int nsl = a.slices ? a.ksplit : 1;
+  const int nsl = a.ksplit;
   int rc = (dtype == NRPN_F32) ? launch_conv<float, 0>(a, true, st) : launch_conv<bf16s, 0>(a, out_f32, st);
   if (rc || a.ksplit <= 1) return rc;
   const long long total = a.M * cout;
@@ -1047,7 +1064,8 @@ struct WgradArgs {
   int ntiles_n;       // cin (MODE 0) / k (MODE 1) tiles
   const unsigned *vmask;   // MODE 0, taps == 27: per-voxel 27-bit mask of in-bounds taps (built by tap_mask_kernel)
   unsigned x_bytes, dy_bytes;
-  float *gbias;       // optional: column sums of dY, accumulated by the (centre tap, first n-tile) workgroups from their LDS A tiles
+  float *gbias;       // optional: per-slice column sums of dY [ksplit][wrows], written (plain stores) by the (centre tap, first n-tile)
+                      // workgroups from their LDS A tiles; bias_finalize_kernel sums the slices in order (deterministic)
   long long slice_stride;   // elements between the partial gradients of consecutive voxel slices ([ksplit][...] layout of gw)
   Segs segs;          // MODE 0: ragged voxel list (n > 0); the tap-mask word then carries the segment id in bits 27-31
 };
@@ -1303,7 +1321,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     buf ^= 1;
   }
 
-  if (do_bias) {   // reduce the row groups through LDS (free after the loop's last barrier): one atomic per column per workgroup
+  if (do_bias) {   // reduce the row groups through LDS (free after the loop's last barrier): one partial per column per workgroup
     constexpr int EPP = 16 / (int)sizeof(T), NRG = 256 / PIECES_ROW;
     float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
@@ -1314,7 +1332,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
       float sum = 0.f;
 #pragma unroll
       for (int rg = 0; rg < NRG; ++rg) sum += red[(rg * PIECES_ROW + (g ^ ((rg & 3) << 2))) * 8 + e];   // thread holding logical slot g of row group rg
-      if (m0 + tid < p.Cout) atomicAdd(p.gbias + m0 + tid, sum);
+      if (m0 + tid < p.Cout) p.gbias[(long long)slice * p.wrows + m0 + tid] = sum;
     }
   }
   const int fr = lane & 31;
@@ -1487,7 +1505,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
     buf ^= 1;
   }
 
-  if (do_bias) {   // reduce the 32 row groups through LDS: one atomic per column per workgroup
+  if (do_bias) {   // reduce the 32 row groups through LDS: one partial per column per workgroup
     float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1499,7 +1517,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
       float sum = 0.f;
 #pragma unroll 8
       for (int rg = 0; rg < 32; ++rg) sum += red[((rg * PIECES_ROW + (g ^ ((rg & 3) << 2))) * 2 + t) * 8 + e];
-      if (m0 + tid < p.Cout) atomicAdd(p.gbias + m0 + tid, sum);
+      if (m0 + tid < p.Cout) p.gbias[(long long)slice * p.wrows + m0 + tid] = sum;
     }
   }
   int elane = lane;
@@ -1517,6 +1535,15 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
         if (row < p.wrows) p.gw[slice * p.slice_stride + ((long long)tap * p.wrows + row) * p.Cin + col] = acc[i][j][r];
       }
   }
+}
+
+// bias gradient = ordered sum of the per-slice column sums the wgrad workgroups left in the workspace
+__global__ void bias_finalize_kernel(const float *__restrict__ part, int slices, int wrows, int cout, float *__restrict__ gbias, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cout) return;
+  float s = 0.f;
+  for (int k = 0; k < slices; ++k) s += part[(long long)k * wrows + c];
+  gbias[c] = accumulate ? gbias[c] + s : s;
 }
 
 // bit t of mask[v] = 1 iff voxel v shifted by tap t = (dx+1)*9 + (dy+1)*3 + (dz+1) stays inside its own grid; bits 27..31 = the
@@ -1591,63 +1618,12 @@ static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
   return NRPN_OK;
 }
 
-// per-channel column sums of dY (bias gradient): rows x C -> C.  256-row slabs per block; a thread owns 4 consecutive
-// channels (8/16-byte loads) of every (256 / (C/4))-th row, LDS reduces the row lanes, one atomic per channel per block.
-template <typename T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T *__restrict__ dy, long long rows, int c, float *__restrict__ out) {
-  __shared__ float red[256][4];
-  const int ct = c / 4, lanes = 256 / ct;
-  const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
-  const long long r0 = (long long)blockIdx.x * 256, r1 = min(rows, r0 + 256);
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (ty < lanes)
-    for (long long r = r0 + ty; r < r1; r += lanes) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) s[k] += elem<T>::ld(dy + r * c + tx * 4 + k);
-    }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = s[k];
-  __syncthreads();
-  if (threadIdx.x < ct) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = 0.f;
-      for (int q = 0; q < lanes; ++q) a += red[q * ct + threadIdx.x][k];
-      atomicAdd(out + threadIdx.x * 4 + k, a);
-    }
-  }
-}
-
-template <typename T>
-__global__ void colsum_generic_kernel(const T *__restrict__ dy, long long rows, int c, float *__restrict__ out) {
-  const long long per = (rows + gridDim.x - 1) / gridDim.x;
-  const long long r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
-  for (int ch = threadIdx.x; ch < c; ch += 64) {
-    float s = 0.f;
-    for (long long r = r0 + threadIdx.y; r < r1; r += 4) s += elem<T>::ld(dy + r * c + ch);
-    atomicAdd(out + ch, s);
-  }
-}
-
-extern "C" int nrpn_colsum(const void *dy, long long rows, int c, int dtype, float *out, nrpn_stream_t stream) {
-  NRPN_REQUIRE(dy && out && rows > 0 && c > 0, "colsum: bad args");
-  hipStream_t st = as_stream(stream);
-  NRPN_HIP(hipMemsetAsync(out, 0, (size_t)c * 4, st));
-  if (c % 4 == 0 && c <= 1024 && 256 % (c / 4) == 0) {
-    const int blocks = (int)((rows + 255) / 256);
-    if (dtype == NRPN_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)dy, rows, c, out);
-    else hipLaunchKernelGGL(colsum_kernel<bf16s>, dim3(blocks), dim3(256), 0, st, (const bf16s *)dy, rows, c, out);
-  } else {
-    const int blocks = (int)min((long long)1024, (rows + 63) / 64);
-    if (dtype == NRPN_F32) hipLaunchKernelGGL(colsum_generic_kernel<float>, dim3(blocks), dim3(64, 4), 0, st, (const float *)dy, rows, c, out);
-    else hipLaunchKernelGGL(colsum_generic_kernel<bf16s>, dim3(blocks), dim3(64, 4), 0, st, (const bf16s *)dy, rows, c, out);
-  }
-  NRPN_LAUNCH_CHECK("colsum");
-  return NRPN_OK;
-}
-
-extern "C" size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int ksize) {
-  return ksize == 3 ? (size_t)n * gx * gy * gz * 4 : 0;
+// workspace = [tap mask: M u32 (k3 only)][bias partials: slices * wrows f32]
+static size_t wgrad_mask_bytes(long long M, int ksize) { return ksize == 3 ? (size_t)((M * 4 + 255) / 256 * 256) : 0; }
+extern "C" size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype) {
+  const long long M = (long long)n * gx * gy * gz;
+  const int slices = wgrad_plan(M, wrows, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, 0, cout, cin).ksplit;
+  return wgrad_mask_bytes(M, ksize) + (size_t)slices * wrows * 4;
 }
 
 static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, float *gbias, long long M, int gx, int gy, int gz,
@@ -1665,20 +1641,22 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
   if (segs) a.segs = *segs;
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.kpad = 0;
   hipStream_t st = as_stream(stream);
-  NRPN_REQUIRE(ksize == 1 || workspace, "conv3d_wgrad: k3 needs the tap-mask workspace (nrpn_conv3d_wgrad_workspace_bytes)");
+  NRPN_REQUIRE(workspace, "conv3d_wgrad: needs its workspace (nrpn_conv3d_wgrad_workspace_bytes)");
   NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && a.M * cout * es < (1ll << 31), "conv3d_wgrad: tensors must stay below 2 GiB");
   a.x_bytes = (unsigned)(a.M * cin * es); a.dy_bytes = (unsigned)(a.M * cout * es);
   a.vmask = reinterpret_cast<const unsigned *>(workspace);
   if (ksize == 3)
     hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz,
                        a.segs);
-  a.gbias = gbias;
-  if (gbias && !accumulate_bias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  float *bias_part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + wgrad_mask_bytes(a.M, ksize));
+  a.gbias = gbias ? bias_part : nullptr;
   const WgPlan pl = wgrad_plan(a.M, wrows, cin, a.taps, es, 0, cout, cin);
   a.ksplit = pl.ksplit;
   a.slice_stride = (long long)a.taps * wrows * cin;
-  if (dtype == NRPN_F32) return launch_wgrad<float, 0>(a, (cin + 127) / 128, st);
-  if (pl.big) {
+  int rc = NRPN_OK;
+  if (dtype == NRPN_F32) rc = launch_wgrad<float, 0>(a, (cin + 127) / 128, st);
+  else if (!pl.big) rc = launch_wgrad<bf16s, 0>(a, (cin + 127) / 128, st);
+  else {
     a.ntiles_n = (cin + 255) / 256;
     const int tiles = ((wrows + 255) / 256) * a.ntiles_n * a.taps;
     const size_t lds = 2 * 4 * (size_t)64 * 256;
@@ -1689,9 +1667,12 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
     }
     hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
     NRPN_LAUNCH_CHECK("conv_wgrad_big");
-    return NRPN_OK;
   }
-  return launch_wgrad<bf16s, 0>(a, (cin + 127) / 128, st);
+  if (rc || !gbias) return rc;
+  hipLaunchKernelGGL(bias_finalize_kernel, dim3((unsigned)((cout + 255) / 256)), dim3(256), 0, st, bias_part, a.ksplit, wrows, cout, gbias,
+                     accumulate_bias);
+  NRPN_LAUNCH_CHECK("bias_finalize");
+  return NRPN_OK;
 }
 
 extern "C" int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz, int cin,
@@ -1710,6 +1691,11 @@ extern "C" int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw
   return conv3d_wgrad_impl(x, dy, gw_packed, gbias, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, accumulate_bias, workspace, stream);
 }
 
+// 1 when a wgrad launch of this shape runs conv_wgrad_big_kernel (256x256 tile), 0 for the 128x128 kernel
+extern "C" int nrpn_conv3d_wgrad_plan(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype) {
+  return wgrad_plan((long long)n * gx * gy * gz, wrows, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, 0, cout, cin).big ? 1 : 0;
+}
+
 extern "C" int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype) {
   return wgrad_plan((long long)n * gx * gy * gz, wrows, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, 0, cout, cin).ksplit;
 }
@@ -1722,8 +1708,12 @@ extern "C" int nrpn_stem_wgrad_slices(int n, int gx, int gy, int gz, int cout, i
   return wgrad_plan(stem_out_voxels(n, gx, gy, gz, stride), cout, nrpn_stem_kpad(dtype), 1, dtype == NRPN_F32 ? 4 : 2, 1, cout, 4).ksplit;
 }
 
+extern "C" size_t nrpn_stem_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cout, int stride, int dtype) {
+  return (size_t)nrpn_stem_wgrad_slices(n, gx, gy, gz, cout, stride, dtype) * cout * 4;
+}
+
 extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
-                                      int cout, int stride, int dtype, int accumulate_bias, nrpn_stream_t stream) {
+                                      int cout, int stride, int dtype, int accumulate_bias, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(stride == 1 || stride == 2, "stem wgrad: stride must be 1 or 2 (got %d)", stride);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "stem wgrad: bad dtype %d", dtype);
   const int es = dtype == NRPN_F32 ? 4 : 2;
@@ -1743,12 +1733,16 @@ extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_p
     NRPN_REQUIRE(xb < (1ll << 31) && db < (1ll << 31), "stem wgrad: tensors must stay below 2 GiB");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db; a.vmask = nullptr;
   }
-  a.gbias = gbias;
-  if (gbias && !accumulate_bias) NRPN_HIP(hipMemsetAsync(gbias, 0, (size_t)cout * 4, st));
+  NRPN_REQUIRE(!gbias || workspace, "stem wgrad: the bias gradient needs the workspace (nrpn_stem_wgrad_workspace_bytes)");
+  a.gbias = gbias ? reinterpret_cast<float *>(workspace) : nullptr;
   a.ksplit = wgrad_plan(a.M, cout, a.kpad, 1, es, 1, cout, 4).ksplit;
   a.slice_stride = (long long)cout * a.kpad;
-  if (dtype == NRPN_F32) return launch_wgrad<float, 1>(a, (a.kpad + 127) / 128, st);
-  return launch_wgrad<bf16s, 1>(a, (a.kpad + 127) / 128, st);
+  const int rc = (dtype == NRPN_F32) ? launch_wgrad<float, 1>(a, (a.kpad + 127) / 128, st) : launch_wgrad<bf16s, 1>(a, (a.kpad + 127) / 128, st);
+  if (rc || !gbias) return rc;
+  hipLaunchKernelGGL(bias_finalize_kernel, dim3((unsigned)((cout + 255) / 256)), dim3(256), 0, st, a.gbias, a.ksplit, cout, cout, gbias,
+                     accumulate_bias);
+  NRPN_LAUNCH_CHECK("bias_finalize");
+  return NRPN_OK;
 }
 
 // =====================================================================================================================

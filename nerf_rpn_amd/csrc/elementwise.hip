@@ -635,23 +635,66 @@ extern "C" int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtyp
 // =====================================================================================================================
 // optimiser on the flat fp32 arena
 // =====================================================================================================================
-__global__ void sumsq_kernel(const float *__restrict__ g, long long count, float scale, float *__restrict__ out) {
-  __shared__ float sh[4];
-  float s = 0.f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) { const float t = g[i] * scale; s += t * t; }
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+// Deterministic sum of squares: kSumsqBlocks fixed-size partials (each a fixed-order tree), and the block that takes the last
+// ticket adds the partials in index order -- the result does not depend on which block finishes last.
+// buf: [0] result, [1] ticket counter (u32, zeroed by the launcher), [2 .. 2 + kSumsqBlocks) partials.
+constexpr int kSumsqBlocks = 1024;
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *__restrict__ g, long long count, float scale, float *__restrict__ buf) {
+  __shared__ float sh[256];
+  __shared__ bool last;
+  const long long n4 = count / 4;
+  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long b0 = (long long)blockIdx.x * per, b1 = min(n4, b0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const f4 *g4 = reinterpret_cast<const f4 *>(g);
+  long long i = b0 + threadIdx.x;
+  for (; i + 768 < b1; i += 1024) {       // four independent 16-byte loads in flight per lane
+    const f4 a = g4[i], b = g4[i + 256], c = g4[i + 512], d = g4[i + 768];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float ta = a[k] * scale, tb = b[k] * scale, tc = c[k] * scale, td = d[k] * scale;
+      s0 += ta * ta; s1 += tb * tb; s2 += tc * tc; s3 += td * td;
+    }
+  }
+  for (; i < b1; i += 256) {
+    const f4 a = g4[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float ta = a[k] * scale; s0 += ta * ta; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(count - n4 * 4)) { const float t = g[n4 * 4 + threadIdx.x] * scale; s1 += t * t; }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    buf[2 + blockIdx.x] = sh[0];
+    __threadfence();
+    last = atomicAdd(reinterpret_cast<unsigned *>(buf + 1), 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int k = threadIdx.x; k < (int)gridDim.x; k += 256) t += buf[2 + k];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) buf[0] = sh[0];
 }
+
+extern "C" int nrpn_grad_sumsq_floats(void) { return 2 + kSumsqBlocks; }
 
 extern "C" int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scale, float *sumsq, nrpn_stream_t stream) {
   NRPN_REQUIRE(grad && sumsq && count > 0, "grad_sumsq: bad args");
+  NRPN_REQUIRE((reinterpret_cast<uintptr_t>(grad) & 15) == 0, "grad_sumsq: the gradient arena must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  NRPN_HIP(hipMemsetAsync(sumsq, 0, 4, st));
-  int blocks = ew_blocks(count);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grad, (long long)count, grad_scale, sumsq);
+  NRPN_HIP(hipMemsetAsync(sumsq, 0, 8, st));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, st, grad, (long long)count, grad_scale, sumsq);
   NRPN_LAUNCH_CHECK("grad_sumsq");
   return NRPN_OK;
 }
@@ -660,7 +703,7 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
                              const float *__restrict__ sumsq, float grad_scale, float max_norm, float lr, float b1, float b2, float eps, float wd,
                              float bc1, float bc2_sqrt) {
   float coef = grad_scale;
-  if (sumsq && max_norm > 0.f) {
+  if (sumsq && max_norm > 0.f) {   // sumsq[0] = the ordered total left by nrpn_grad_sumsq
     const float norm = sqrtf(*sumsq);
     coef = grad_scale * fminf(1.0f, max_norm / (norm + 1e-6f));
   }

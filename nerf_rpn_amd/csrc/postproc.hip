@@ -18,7 +18,7 @@ int nrpn_fail(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *nrpn_last_error(void) { return g_nrpn_err; }
-extern "C" int nrpn_abi_version(void) { return 1; }
+extern "C" int nrpn_abi_version(void) { return 2; }
 
 extern "C" int nrpn_check_device(int ordinal) {
   hipDeviceProp_t p;

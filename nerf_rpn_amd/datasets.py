@@ -47,7 +47,9 @@ class RawScene:
 def _grid_from_npz(path, normalize_density, raw=False):
     with np.load(path) as f:
         g = f["rgbsigma"]
-        if raw and not (normalize_density and g.dtype == np.uint8):      # uint8 + alpha follows numpy's casts: host path only
+        # device ingest takes float32 grids, and uint8 grids without density_to_alpha (uint8 + alpha follows numpy's casts);
+        # every other dtype the reference's host path accepts (float16 / float64 npz) goes through the host path below
+        if raw and (g.dtype == np.float32 or (g.dtype == np.uint8 and not normalize_density)):
             return RawScene(torch.from_numpy(np.ascontiguousarray(g)), 1 if normalize_density else 0)
         if normalize_density:
             g[..., -1] = density_to_alpha(g[..., -1])

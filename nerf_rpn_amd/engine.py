@@ -40,8 +40,9 @@ def one_cycle(step, total_steps, max_lr, pct_start=0.3, div_factor=25.0, final_d
 
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, betas=(0.9, 0.999), eps=1e-8, total_steps=None,
-                 bucket_bytes=64 << 20, process_group=None):
+                 bucket_bytes=64 << 20, process_group=None, static_graph=True):
         self.model = model
+        self.static_graph = static_graph
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -51,7 +52,7 @@ class FlatTrainer:
         self.g_arena = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev) if dev.type == "cuda" else None
+        self.sumsq = torch.zeros(ops.query("grad_sumsq_floats"), dtype=torch.float32, device=dev) if dev.type == "cuda" else None
         off = 0
         self.slices = []
         for p in self.params:
@@ -93,13 +94,22 @@ class FlatTrainer:
                     self.bucket_params.append(members)
                     end, members = o, []
         self.launched = [False] * len(self.buckets)
+        self.early = [False] * len(self.buckets)
 
     def _make_notify(self, i):
         def notify():
             self.seen[i] += 1
             if self.world > 1 and self.expected is not None:
                 b = self.bucket_of[i]
-                if not self.launched[b] and all(self.seen[j] >= self.expected[j] for j in self.bucket_params[b] if self.expected[j] > 0):
+                if self.launched[b]:
+                    # the bucket's all-reduce is already in flight: a late accumulation would race with it and mix un-reduced
+                    # local gradients into the result (graph differs from the one the counts were learned on)
+                    raise RuntimeError(f"FlatTrainer: parameter {i} received gradient notification {self.seen[i]} but {self.expected[i]} were "
+                                       "learned on the first step; the autograd graph changed between steps -- construct the trainer "
+                                       "with static_graph=False (all buckets are then reduced at the end of backward)")
+                # a bucket is launched early only when EVERY member is known to receive gradients and all have arrived; buckets with
+                # a parameter that was unused on the learning step wait for sync_gradients()
+                if self.early[b] and all(self.seen[j] >= self.expected[j] for j in self.bucket_params[b]):
                     self._launch(b)
         return notify
 
@@ -127,6 +137,7 @@ class FlatTrainer:
             self.launched = [False] * len(self.buckets)
         if self.expected is None:
             self.expected = list(self.seen)
+            self.early = [self.static_graph and all(self.expected[j] > 0 for j in members) for members in self.bucket_params]
         self.seen = [0] * len(self.params)
 
     def step(self):
@@ -143,6 +154,7 @@ class FlatTrainer:
         else:
             raise RuntimeError("FlatTrainer.step needs CUDA tensors (the optimiser kernels have no CPU fallback); "
                                "CPU use is limited to the gloo gradient-exchange tests via sync_gradients()")
+        ops.weights_changed()       # the raw-pointer update is invisible to tensor._version: invalidate every GEMM-layout weight copy
         self.g_arena.zero_()
         return lr
 

@@ -89,6 +89,9 @@ class RegionProposalNetwork(nn.Module):
         self._post_nms_top_n = post_nms_top_n
         self.nms_thresh = nms_thresh
         self.score_thresh = score_thresh
+        if not rotated_bbox and reg_loss_type != "smooth_l1":
+            # the reference builds RotatedIOULoss regardless and crashes in its 7-column box maths on 6-column AABBs (rpn.py:133-164)
+            raise ValueError(f"reg_loss_type={reg_loss_type!r} needs --rotated_bbox (axis-aligned boxes train with smooth_l1 only)")
         self.reg_loss_type = reg_loss_type
         self.rotated_iou_loss = RotatedIOULoss(reg_loss_type) if rotated_bbox and reg_loss_type != "smooth_l1" else None
         self.min_size = 1e-3
@@ -111,7 +114,13 @@ class RegionProposalNetwork(nn.Module):
         logits = logits.detach()
         if padding_masks is not None:
             logits = logits.masked_fill(~padding_masks, float("-inf"))
-        k = min(self.pre_nms_top_n(), 16384)
+        k = self.pre_nms_top_n()
+        L0 = len(table.counts)
+        if k * L0 > 16384 or self.post_nms_top_n() > 16384:
+            # the candidate sort / NMS / selection kernels work on at most 16384 rows (one workgroup's LDS); the reference has no
+            # such limit, so refuse loudly instead of silently clamping
+            raise ValueError(f"rpn_pre_nms_top_n ({k}) x pyramid levels ({L0}) and rpn_post_nms_top_n ({self.post_nms_top_n()}) must "
+                             "each stay <= 16384 on the HIP path")
         L = len(table.counts)
         dev = logits.device
         slot_level = torch.arange(L, dtype=torch.int32, device=dev).repeat_interleave(k).contiguous()
@@ -125,7 +134,7 @@ class RegionProposalNetwork(nn.Module):
             fb, fs, fl, cnt = ops.filter_candidates(boxes, val.reshape(-1).contiguous(), slot_level, valid, mesh_shapes[n], self.min_size,
                                                     self.score_thresh, self.fix_obb_clip)
             keep = ops.nms3d_sorted(fb, fl, self.nms_thresh, cnt)
-            pending.append(ops.select_kept(fb, fs, fl, keep, cnt, min(self.post_nms_top_n(), 16384)))
+            pending.append(ops.select_kept(fb, fs, fl, keep, cnt, self.post_nms_top_n()))
         for ob, os_, ol, oc in pending:
             m = int(oc.item())   # the one device->host read-back per scene
             boxes_out.append(ob[:m])

@@ -353,9 +353,21 @@ def _sink(t):
     return getattr(t, "_nrpn_sink", None) if t is not None else None
 
 
+# Parameters can be rewritten behind autograd's back (engine.FlatTrainer updates its flat arena through the raw-pointer AdamW
+# kernel, which never bumps tensor._version), so every GEMM-layout cache is also keyed on this epoch; whoever writes
+# parameter memory outside torch calls ``weights_changed()``.
+_weight_epoch = 0
+PACK_COUNT = {"conv": 0, "stem": 0}      # pack launches so far (tests assert packs == modules x optimiser steps)
+
+
+def weights_changed():
+    global _weight_epoch
+    _weight_epoch += 1
+
+
 class PackedWeight:
     """GEMM-layout copies of one or more reference-layout conv weights sharing a GEMM (rows_total rows), refreshed when
-    the parameters change (tensor._version)."""
+    the parameters change (tensor._version for torch-side writes, the module weight epoch for raw-pointer writes)."""
 
     def __init__(self):
         self.key = None
@@ -363,9 +375,10 @@ class PackedWeight:
         self.dgrad = None
 
     def get(self, weights, dtype, rows_total, need_dgrad, cin=None):
-        key = tuple((w.data_ptr(), w._version) for w in weights) + (dtype, rows_total, need_dgrad)
+        key = tuple((w.data_ptr(), w._version) for w in weights) + (dtype, rows_total, need_dgrad, _weight_epoch)
         if key == self.key:
             return self.fwd, self.dgrad
+        PACK_COUNT["conv"] += 1
         cin = weights[0].shape[1] if cin is None else cin     # nn.Linear [out,in] and a flattened patch conv are taps == 1
         taps = weights[0][0].numel() // cin
         dev = weights[0].device
@@ -457,8 +470,8 @@ class ConvFn(torch.autograd.Function):
         gwp = torch.empty((slices, taps, rows_total, cin), dtype=torch.float32, device=x.device)     # per-slice partials, summed by the unpack
         direct_bias = has_bias and nw == 1 and bsinks[0] is not None
         gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
-        wsb = query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, ksize)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+        ws = torch.empty(query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x)), dtype=torch.uint8,
+                         device=x.device)      # tap masks + per-slice bias partials
         if segs is None or ksize == 1:
             call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), int(direct_bias),
                  _p(ws), _s())
@@ -498,8 +511,9 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, cache):
         _chk(x)
-        key = (weight.data_ptr(), weight._version, x.dtype)
+        key = (weight.data_ptr(), weight._version, x.dtype, _weight_epoch)
         if cache.get("key") != key:
+            PACK_COUNT["stem"] += 1
             kpad = query("stem_kpad", _dt(x))
             wp = torch.empty((weight.shape[0], kpad), dtype=x.dtype, device=x.device)
             call("pack_stem_weight", _p(weight.detach().contiguous()), weight.shape[0], _dt(x), _p(wp), _s())
@@ -529,7 +543,8 @@ class StemFn(torch.autograd.Function):
         wsink, bsink = ctx.sinks
         direct_bias = has_bias and bsink is not None
         gb = bsink.slot if direct_bias else (torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None)
-        call("conv3d_stem_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cout, stride, _dt(x), int(direct_bias), _s())
+        ws = torch.empty(query("stem_wgrad_workspace_bytes", n, gx, gy, gz, cout, stride, _dt(x)), dtype=torch.uint8, device=x.device) if has_bias else None
+        call("conv3d_stem_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cout, stride, _dt(x), int(direct_bias), _p(ws), _s())
         if wsink is not None:
             call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(wsink.slot), 1, slices, _s())
             wsink.notify()

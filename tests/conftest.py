@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Kernel-level oracle / torch parity first, composed paths after: with `-x` one red end-to-end test must not hide the kernel tests.
+_ORDER = ["test_oracle_golden", "test_abi_and_host", "test_harness_cpu", "test_dist_gloo", "test_gpu_postproc", "test_gpu_conv",
+          "test_gpu_geomloss", "test_gpu_swin", "test_gpu_fcos", "test_gpu_aug", "test_gpu_roialign", "test_gpu_e2e", "test_gpu_trainer",
+          "test_gpu_fullsize", "test_gpu_harness", "test_gpu_rccl"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(mod) if mod in _ORDER else len(_ORDER)
+    items.sort(key=key)        # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -312,7 +312,7 @@ def scene(shape, seed):
 
 def subsample(t, n=4096):
     f = t.reshape(-1)
-    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel()), dtype=torch.float64).long().clamp_(max=f.numel() - 1)
     return idx, f[idx]
 
 
@@ -373,6 +373,48 @@ def record_grads(arrs, rp, op, p64):
             arrs["gidx/" + k], arrs["gval/" + k] = idx, val
             arrs["gval64/" + k] = g64.reshape(-1)[idx]
     return worst
+
+
+def raw_scene_wlh4(shape, seed):
+    """On-disk layout (W,L,H,4) f32: rgb U[0,1), density U[-5,5) (SURVEY 8d synthetic input for --normalize_density)."""
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.rand(*shape, 4, generator=g)
+    raw[..., 3] = raw[..., 3] * 10.0 - 5.0
+    return raw
+
+
+def gen_fullsize():
+    """BASELINE configs[1] at its real size (160^3, VGG19-EF, OBB, --normalize_density) and the reference's own benchmark shape
+    200x200x130 (run_rpn.py:596).  Inputs are regenerated from seeds by the tests (a 160^3x4 grid is 65 MB); the fixture holds the
+    expected outputs: sampled features, proposals, scores, levels."""
+    print("full-size eval")
+    import datasets as R_ds
+    cases = [("eval_obb_160_cfg1", (160, 160, 160), True), ("eval_obb_200x200x130", (200, 200, 130), False)]
+    only = os.environ.get("GOLDEN_ONLY")
+    for name, shape, normalize in cases:
+        if only and only not in name:
+            continue
+        ref = build_ref(True, 160).eval()
+        orc = build_oracle(True, 160)
+        orc.backbone.eval()
+        raw = raw_scene_wlh4(shape, 300).numpy()
+        if normalize:        # reference load_single_scene (datasets.py:39-63): alpha on channel 3, then (W,L,H,4) -> (4,W,L,H)
+            raw = raw.copy()
+            raw[..., 3] = R_ds.BaseDataset.density_to_alpha(raw[..., 3])
+        x = torch.from_numpy(np.ascontiguousarray(np.transpose(raw, (3, 0, 1, 2)))).float()
+        with torch.no_grad():
+            (feats, props, lvls), _, scores = ref([x.clone()])
+            (ofeats, oprops, olvls), _, oscores, aux = orc([x.clone()])
+        arrs = {"shape": list(shape), "seed": 300, "normalize_density": normalize, "rotated": True, "resolution": 160, "pre": 2500}
+        for i, (f, of) in enumerate(zip(feats, ofeats)):
+            close(of, f, 5e-4, f"{name} feat{i}")
+            idx, val = subsample(f, 16384)
+            arrs[f"feat{i}_shape"], arrs[f"feat{i}_idx"], arrs[f"feat{i}_val"], arrs[f"feat{i}_absmax"] = list(f.shape), idx, val, f.abs().max()
+        assert props[0].shape == oprops[0].shape, (name, props[0].shape, oprops[0].shape)
+        close(oprops[0], props[0], 2e-3, f"{name} proposals"); close(oscores[0], scores[0], 1e-5, f"{name} scores")
+        arrs["proposals0"], arrs["scores0"], arrs["levels0"] = props[0], scores[0], lvls[0]
+        print(f"   {name}: {props[0].shape[0]} proposals, score range {scores[0].min():.4f}..{scores[0].max():.4f}")
+        save(name, **arrs)
 
 
 def gen_train():
@@ -552,6 +594,6 @@ def gen_fcos():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "eval", "train", "fcos"]
+    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "eval", "fullsize", "train", "fcos"]
     for w in which:
         globals()["gen_" + w]()

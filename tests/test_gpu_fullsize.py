@@ -1,0 +1,105 @@
+"""GPU parity at the sizes BASELINE.json's metric is quoted on: configs[1] = one 160^3 x 4 grid, VGG19-EF + FPN + anchor RPN (OBB),
+--normalize_density (device ingest), fp32 against the golden vectors captured from the reference and bf16 with a stated bound;
+plus the reference's own benchmark shape 200 x 200 x 130 (run_rpn.py:596).  At these sizes launch_conv selects the 256x256
+implicit-GEMM tile, its K-sliced form and (in training) the 256x256 wgrad tile.
+
+The fixtures hold expected OUTPUTS only (tests/golden/make_golden.py::gen_fullsize); the 65 MB inputs are regenerated from the
+seed with the same torch generator calls."""
+import pytest
+import torch
+
+from test_gpu_e2e import T, assert_eval_matches, build
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["eval_obb_160_cfg1", "eval_obb_200x200x130"]
+
+
+def raw_scene_wlh4(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.rand(*[int(s) for s in shape], 4, generator=g)
+    raw[..., 3] = raw[..., 3] * 10.0 - 5.0
+    return raw
+
+
+def _ingest(g, dev, dtype):
+    from nerf_rpn_amd import ops
+    raw = raw_scene_wlh4(g["shape"], int(g["seed"])).to(dev)
+    return ops.ingest_rgbsigma(raw, alpha_mode=1 if bool(g["normalize_density"]) else 0, dtype=dtype)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fullsize_fp32_matches_reference(name, golden, dev):
+    from nerf_rpn_amd import lib
+    g = golden(name)
+    X, Y, Z = [int(v) for v in g["shape"]]
+    m = build(True, 160, dev).eval()
+    with torch.no_grad():
+        (feats, props, lvls), losses, scores = m([_ingest(g, dev, torch.float32)])
+    assert losses == {}
+    assert_eval_matches(name, g, feats, props, lvls, scores, 1, dev)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fullsize_bf16_within_stated_bound(name, golden, dev):
+    """bf16 activations / weights with fp32 accumulation (the throughput path bench.py times).  Bound: every sampled feature within
+    2e-2 of the level's absolute maximum; >= 95 % of the reference's top-300 proposals have a bf16 proposal with rotated IoU > 0.9
+    (IoU by the CPU oracle)."""
+    from nerf_rpn_amd import lib
+    from oracle import boxes as OB
+    g = golden(name)
+    X, Y, Z = [int(v) for v in g["shape"]]
+    # the 40^3-class maps of these shapes must run on the 256x256 tile, the 20^3-class maps on its K-sliced form
+    l0 = [-(-(-(-v // 2)) // 2) for v in (X, Y, Z)]             # stem stride 2 + max-pool 3/2/1
+    l1 = [-(-v // 2) for v in l0]
+    assert lib.query("conv3d_fwd_plan", 1, *l0, 256, 256, 3, lib.BF16) == 1
+    assert lib.query("conv3d_fwd_plan", 1, *l1, 512, 512, 3, lib.BF16) == 2
+    m = build(True, 160, dev).eval()
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        (feats, props, lvls), _, scores = m([_ingest(g, dev, torch.bfloat16)])
+    for i, f in enumerate(feats):
+        assert list(f.shape) == g[f"feat{i}_shape"].tolist()
+        got = f.float().contiguous().reshape(-1)[T(g[f"feat{i}_idx"], dev)].cpu()
+        ref = T(g[f"feat{i}_val"])
+        err = (got - ref).abs().max().item() / float(g[f"feat{i}_absmax"])
+        assert err <= 2e-2, (name, i, err)
+    rp, gp = T(g["proposals0"])[:300], props[0].float().cpu()
+    assert gp.shape[0] > 0 and torch.isfinite(scores[0]).all()
+    iou = OB.iou_matrix(rp, gp)
+    frac = (iou.max(dim=1).values > 0.9).float().mean().item()
+    assert frac >= 0.95, (name, frac)
+
+
+def test_fullsize_train_step_is_finite_and_deterministic(dev):
+    """One 160^3 training pass in bf16 (the bench configuration: 16 OBB ground-truth boxes): finite loss and gradients, and a
+    second identical pass reproduces the gradient arena bit for bit (ordered reductions at the sizes that select the 256x256
+    wgrad tile)."""
+    import math
+    from nerf_rpn_amd import lib
+    from nerf_rpn_amd.engine import FlatTrainer
+    assert lib.query("conv3d_wgrad_plan", 1, 40, 40, 40, 256, 256, 256, 3, lib.BF16) == 1
+    g1 = torch.Generator().manual_seed(1)
+    ctr = torch.rand(16, 3, generator=g1) * 120 + 20
+    size = torch.rand(16, 3, generator=g1) * 40 + 8
+    theta = (torch.rand(16, 1, generator=g1) - 0.5) * math.pi
+    gt = torch.cat([ctr, size, theta], dim=1).to(dev)
+    x = torch.rand(4, 160, 160, 160, generator=torch.Generator().manual_seed(0)).to(dev)
+    m = build(True, 160, dev).train()
+    m.set_compute_dtype(torch.bfloat16)
+    tr = FlatTrainer(m, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1)
+    labels = {}
+
+    def run():
+        tr.g_arena.zero_()
+        torch.manual_seed(3)          # the device sampler draws from torch's generator
+        _, losses, _ = m([x], [gt])
+        loss = losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"]
+        loss.backward()
+        tr.sync_gradients()
+        return loss.item(), tr.g_arena.clone()
+
+    l0, g0 = run()
+    l1, g1_ = run()
+    assert math.isfinite(l0) and torch.isfinite(g0).all() and g0.abs().max().item() > 0
+    assert l0 == l1 and torch.equal(g0, g1_), (l0, l1, (g0 - g1_).abs().max().item())

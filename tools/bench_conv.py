@@ -28,7 +28,7 @@ def run(grid, cin, cout, k, dtype):
     dt = ops._dt(x)
     wsb = lib.query('conv3d_fwd_workspace_bytes', n, grid, grid, grid, cin, cout, k, dt)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-    wgb = lib.query('conv3d_wgrad_workspace_bytes', n, grid, grid, grid, k)
+    wgb = lib.query('conv3d_wgrad_workspace_bytes', n, grid, grid, grid, cin, cout, cout, k, dt)
     wsg = torch.empty(wgb, dtype=torch.uint8, device=dev) if wgb else None
     res = {}
     for kb, dma in ((128, 0), (64, 1), (128, 1)):

@@ -20,7 +20,7 @@ for grid, cin, cout, k in [(40, 256, 256, 3), (20, 512, 512, 3), (20, 256, 512, 
     x = torch.randn(1, grid, grid, grid, cin, device=dev).bfloat16()
     dy = (torch.randn(1, grid, grid, grid, cout, device=dev) * (torch.rand(1, grid, grid, grid, 1, device=dev) < 0.3)).bfloat16()
     flops = 2.0 * g3 * cin * cout * k ** 3
-    wgb = lib.query('conv3d_wgrad_workspace_bytes', 1, grid, grid, grid, k)
+    wgb = lib.query('conv3d_wgrad_workspace_bytes', 1, grid, grid, grid, cin, cout, cout, k, 1)
     ws = torch.empty(max(wgb, 16), dtype=torch.uint8, device=dev)
     outs = {}
     line = f'{grid}^3 {cin}->{cout} k{k}:'

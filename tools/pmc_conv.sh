@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 root=$(cd "$(dirname "$0")/.." && pwd)
 i=0
 groups=${PMC_GROUPS:-all}
-for grp in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i + 1))
@@ -34,13 +34,17 @@ for f in sorted(glob.glob(os.path.join(out, "pass*.csv"))):
 res = {}
 for k, cs in acc.items():
     d = {c: sum(v) / len(v) for c, v in cs.items()}
-    if "FETCH_SIZE" in d:
-        d["hbm_bytes_est (FETCH_SIZE*2*1024 + WRITE_SIZE*1024)"] = d["FETCH_SIZE"] * 2 * 1024 + d.get("WRITE_SIZE", 0) * 1024
+    if "FETCH_SIZE" in d:      # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads: x2
+        d["hbm_read_bytes"] = d["FETCH_SIZE"] * 2 * 1024
+        d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024 if "WRITE_SIZE" in d else None
+        d["hbm_bytes"] = d["hbm_read_bytes"] + (d["hbm_write_bytes"] or 0) if "WRITE_SIZE" in d else None
     if "TCC_HIT_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
     res[k] = d
-json.dump({"note": "rocprofv3 --pmc (separate passes) on tools/one_conv.py: 256->256 k3 @40^3 bf16, per launch averages. FETCH_SIZE doubled per "
-                   "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads).", "kernels": res}, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+json.dump({"method": "rocprofv3 --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE in separate passes: 3 + 2 of the 4 TCC slots) on "
+                     "tools/one_conv.py: 256->256 k3 @40^3 bf16, per-launch averages; bytes = FETCH_SIZE[KiB] x 1024 x 2 (gfx950 tallies the "
+                     "128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE[KiB] x 1024 (uncalibrated)",
+           "kernels": res}, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:2500])
 PY
 for f in "$out"/pass*.csv; do rm -f "$f"; done
