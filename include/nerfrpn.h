@@ -172,7 +172,10 @@ int nrpn_rpn_sampled_loss_f32(const float *logits, const float *deltas, int dw, 
  *   flags: NRPN_CONV_BIAS (bias f32 [Cout]), NRPN_CONV_RELU, NRPN_CONV_OUT_F32 (bf16 inputs, fp32 output rows).
  *   Cin*elemsize must be a multiple of 64 bytes.
  * ---------------------------------------------------------------------------------------------- */
-enum { NRPN_CONV_BIAS = 1, NRPN_CONV_RELU = 2, NRPN_CONV_OUT_F32 = 4 };
+enum { NRPN_CONV_BIAS = 1, NRPN_CONV_RELU = 2, NRPN_CONV_OUT_F32 = 4,
+       /* timing diagnosis of the 256x256 kernel only -- RESULTS ARE WRONG with these set (tools/bench_tile.py): every tap reads the
+        * centre voxel ("ideal memory"), resp. the per-K-step barrier + DMA drain is skipped ("free-running waves") */
+       NRPN_CONV_DEBUG_ALIAS_TAPS = 256, NRPN_CONV_DEBUG_NO_SYNC = 512 };
 int nrpn_pack_conv_weight(const float *w_ref, int cout, int cin, int taps, int dtype, void *wp_fwd, void *wp_dgrad,
                           int rows_total, int row_offset, nrpn_stream_t stream);
 /* packed fp32 partial weight gradients [slices][taps][rows_total][Cin] (output of nrpn_conv3d_wgrad) -> sum over the
@@ -192,7 +195,10 @@ int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, i
  * `workspace` (always required) = k3 tap masks + the bias partials. */
 size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
-/* accumulate_bias != 0: the column sums are ADDED to gbias (e.g. a slot of a flat gradient arena) instead of overwriting. */
+/* accumulate_bias = flags: NRPN_WGRAD_ACC_BIAS: the column sums are ADDED to gbias (e.g. a slot of a flat gradient arena) instead of
+ * overwriting; NRPN_WGRAD_MASK_READY: `workspace` still holds the tap masks an earlier call wrote for the same (n, gx, gy, gz) grid /
+ * segment list, so they are not rebuilt (callers that keep one workspace per grid shape save a launch per layer). */
+enum { NRPN_WGRAD_ACC_BIAS = 1, NRPN_WGRAD_MASK_READY = 2 };
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
                       int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
                       nrpn_stream_t stream);
@@ -383,9 +389,19 @@ int nrpn_fcos_decode_f32(const int32_t *idx, const float *score, int64_t count, 
  * ---------------------------------------------------------------------------------------------- */
 int nrpn_grad_sumsq_floats(void);
 int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scale, float *sumsq, nrpn_stream_t stream);
+/* shadow_bf16 (optional, bf16 [count]): the updated parameters are also written as bf16 in the same element order -- for master
+ * weights kept in the forward GEMM layout this IS the packed bf16 operand of the next forward (no repack pass). */
 int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count,
                     const float *sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int step, nrpn_stream_t stream);
+                    float weight_decay, int step, void *shadow_bf16, nrpn_stream_t stream);
+/* GEMM-layout master weights inside a flat arena: forward layout [taps][Cout][Cin] per weight.
+ * nrpn_transpose_weights: ONE launch writes the dgrad operand [taps reversed][Cin][Cout] (dtype) of every weight listed in the
+ *   device-side job table (int64 [nweights][4] = arena element offset, taps, Cout, Cin; tile_prefix int32 [nweights+1] = running
+ *   count of 64x64 tiles, total_tiles = tile_prefix[nweights]) at the same arena offsets of `dst`.
+ * nrpn_reduce_slices: dst[i] (+)= sum over the S voxel-slice partials of a wgrad (already in the forward layout), in slice order. */
+int nrpn_transpose_weights(const float *master, void *dst, const int64_t *table, const int32_t *tile_prefix, int nweights,
+                           int total_tiles, int dtype, nrpn_stream_t stream);
+int nrpn_reduce_slices(const float *partials, int slices, int64_t count, float *dst, int accumulate, nrpn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -691,6 +691,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   int l_chunk = ks_begin / p.taps, l_tap = ks_begin - l_chunk * p.taps, l_dx = 0, l_dy = 0, l_dz = 0;
   if (p.taps == 27) { l_dx = l_tap / 9 - 1; l_dy = (l_tap / 3) % 3 - 1; l_dz = l_tap % 3 - 1; }
   const long long w_tap_stride = (long long)p.wrows * p.Cin;
+  const bool dbg_alias = (p.flags & NRPN_CONV_DEBUG_ALIAS_TAPS) != 0, dbg_nosync = (p.flags & NRPN_CONV_DEBUG_NO_SYNC) != 0;
   // branch-free: past the last K-step (`live` false) every lane reads out of range, i.e. deposits zeros in the idle buffer
   auto issue = [&](int buf, bool live) {
     char *A = lds + buf * (A_BYTES + B_BYTES);
@@ -699,10 +700,15 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     const int zshift = (l_dz * p.Cin + c0) * 2;
     const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * 2);
     const unsigned tapbit = live ? (1u << l_tap) : 0u;
+    if (dbg_alias) {      // timing diagnosis only: every tap reads the centre voxel (27x reuse of one activation tile: "ideal memory")
+#pragma unroll
+      for (int i = 0; i < A_RPT; ++i) lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB, live ? a_voff[i] + (unsigned)(c0 * 2) : kOOB);
+    } else {
 #pragma unroll
     for (int i = 0; i < A_RPT; ++i)
       lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB,
                 (a_mask[i] & tapbit) ? a_voff[i] + (unsigned)(l_dx * a_yz[i] + l_dy * a_zs[i] + zshift) : kOOB);
+    }
 #pragma unroll
     for (int i = 0; i < B_RPT; ++i) lds_dma16(wr, B + (wave_u * (64 / PPR) + RSTEP * i) * KB, live ? b_voff[i] + wshift : kOOB);
     // K order: 64-channel chunk OUTER, tap INNER.  All workgroups of an XCD then sweep the 27 shifted views of one 128-byte
@@ -778,7 +784,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
 #pragma unroll 1
   for (int ks = ks_begin; ks < nk; ++ks) {
     compute((ks - ks_begin) & 1, ks + 1 < nk);
-    __syncthreads();
+    if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
   }
 
   const bool has_bias = (p.flags & NRPN_CONV_BIAS) && p.bias;
@@ -980,7 +986,8 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, voi
   a.M = M;
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // classic layout: the kernel splits v into (batch, x, y, z) with these
   if (segs) a.segs = *segs;
-  a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.flags = flags & 3;
+  a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1;
+  a.flags = flags & (3 | NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC);
   NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && (long long)a.taps * wrows * cin * es < (1ll << 31),
                "conv3d_fwd: activation / weight tensors must stay below 2 GiB (32-bit buffer offsets)");
   a.x_bytes = (unsigned)(a.M * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);
@@ -1577,12 +1584,21 @@ static WgPlan wgrad_plan(long long M, int wrows, int ncols, int taps, int elem_b
   const long long chunks = (M + kv - 1) / kv;
   long long ks = 1;
   if (mode == 0 && elem_bytes == 2 && g_wgrad_big && g_wgrad_tr_mode != 0 && cout >= 256 && cin >= 256) {
-    // 256x256 tiles: fewest slices whose workgroup count fills >= 80 % of whole rounds of 256 CUs (one 128 KB-LDS workgroup per CU)
+    // 256x256 tiles, one 128 KB-LDS workgroup per CU: pick the slice count with the lowest modelled time
+    //   t(k) = MFMA time / (fill of whole rounds of 256 CUs) + (k + 1) partial-gradient passes through HBM,
+    // e.g. 256->256 @40^3: 27 tiles x 9 slices = 243 workgroups (95 % of a round) instead of 8 (84 %); 512->512 @20^3 stays at 2
+    // slices because each extra slice costs another 28 MB partial.
     const int tiles = ((wrows + 255) / 256) * ((cin + 255) / 256) * taps;
+    const double flops = 2.0 * (double)M * wrows * cin * taps;
+    const double part_bytes = 4.0 * (double)taps * wrows * cin;
+    double best = 1e30;
     for (long long k = 1; k <= 64 && k <= max(1ll, chunks / 16); ++k) {
       const double rounds = (double)tiles * k / 256.0;
       const long long whole = (long long)rounds + ((double)(long long)rounds < rounds ? 1 : 0);
-      if (rounds / (double)whole >= 0.8) { pl.big = true; ks = k; break; }
+      const double fill = rounds / (double)whole;
+      if (fill < 0.5) continue;
+      const double t = flops / (fill * 9.0e14) + (double)(k + 1) * part_bytes / 3.0e12;
+      if (t < best) { best = t; pl.big = true; ks = k; }
     }
   }
   if (!pl.big) {
@@ -1645,7 +1661,9 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
   NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && a.M * cout * es < (1ll << 31), "conv3d_wgrad: tensors must stay below 2 GiB");
   a.x_bytes = (unsigned)(a.M * cin * es); a.dy_bytes = (unsigned)(a.M * cout * es);
   a.vmask = reinterpret_cast<const unsigned *>(workspace);
-  if (ksize == 3)
+  const bool mask_ready = (accumulate_bias & NRPN_WGRAD_MASK_READY) != 0;     // the caller kept the workspace of an earlier call on this grid
+  accumulate_bias &= NRPN_WGRAD_ACC_BIAS;
+  if (ksize == 3 && !mask_ready)
     hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz,
                        a.segs);
   float *bias_part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + wgrad_mask_bytes(a.M, ksize));

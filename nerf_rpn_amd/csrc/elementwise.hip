@@ -701,7 +701,7 @@ extern "C" int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scal
 
 __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long long count,
                              const float *__restrict__ sumsq, float grad_scale, float max_norm, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt) {
+                             float bc1, float bc2_sqrt, bf16s *__restrict__ shadow) {
   float coef = grad_scale;
   if (sumsq && max_norm > 0.f) {   // sumsq[0] = the ordered total left by nrpn_grad_sumsq
     const float norm = sqrtf(*sumsq);
@@ -717,18 +717,89 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     pi -= (lr / bc1) * (mi / denom);
     p[i] = pi;
+    if (shadow) shadow[i] = f32_to_bf16_bits(pi);      // bf16 copy of the updated master weight, same element order
   }
 }
 
 extern "C" int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count, const float *sumsq,
                                float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                               nrpn_stream_t stream) {
+                               void *shadow_bf16, nrpn_stream_t stream) {
   NRPN_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, "adamw_step: bad args");
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, (long long)count,
-                     sumsq, grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+                     sumsq, grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), reinterpret_cast<bf16s *>(shadow_bf16));
   NRPN_LAUNCH_CHECK("adamw_step");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
+// GEMM-layout master weights.  A trainer that keeps conv weights in the forward GEMM layout [taps][Cout][Cin] inside its flat
+// arena needs (a) the dgrad operand [taps reversed][Cin][Cout] of every weight -- ONE batched launch per optimiser step over a
+// device-side job table instead of one pack launch per layer -- and (b) the sum of a wgrad's voxel-slice partials, which are
+// already in that layout, added straight into the gradient arena (contiguous; no layout shuffle).
+// table: int64 [nweights][4] = (element offset in the arena, taps, cout, cin); tile_prefix: int32 [nweights + 1] = first 64x64-tile
+// job of each weight (jobs of a weight: taps * ceil(cout/64) * ceil(cin/64)).
+// =====================================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_weights_kernel(const float *__restrict__ master, T *__restrict__ dst, const long long *__restrict__ table,
+                                                                const int *__restrict__ tile_prefix, int nweights) {
+  __shared__ float tile[64][65];
+  const int job = blockIdx.x;
+  int lo = 0, hi = nweights - 1;                 // last weight whose first job <= this job
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_prefix[mid] <= job) lo = mid; else hi = mid - 1;
+  }
+  const long long off = table[lo * 4];
+  const int taps = (int)table[lo * 4 + 1], cout = (int)table[lo * 4 + 2], cin = (int)table[lo * 4 + 3];
+  int j = job - tile_prefix[lo];
+  const int tn = (cin + 63) / 64, tm = (cout + 63) / 64;
+  const int c0 = (j % tn) * 64; j /= tn;
+  const int o0 = (j % tm) * 64; j /= tm;
+  const int tap = j;
+  const float *src = master + off + (long long)tap * cout * cin;
+  T *out = dst + off + (long long)(taps - 1 - tap) * cin * cout;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4)
+    tile[r][tx] = (o0 + r < cout && c0 + tx < cin) ? src[(long long)(o0 + r) * cin + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4)
+    if (c0 + r < cin && o0 + tx < cout) elem<T>::st(out + (long long)(c0 + r) * cout + o0 + tx, tile[tx][r]);
+}
+
+extern "C" int nrpn_transpose_weights(const float *master, void *dst, const int64_t *table, const int32_t *tile_prefix, int nweights,
+                                      int total_tiles, int dtype, nrpn_stream_t stream) {
+  NRPN_REQUIRE(master && dst && table && tile_prefix && nweights > 0 && total_tiles > 0, "transpose_weights: bad args");
+  NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "transpose_weights: bad dtype %d", dtype);
+  hipStream_t st = as_stream(stream);
+  if (dtype == NRPN_F32)
+    hipLaunchKernelGGL(transpose_weights_kernel<float>, dim3(total_tiles), dim3(256), 0, st, master, (float *)dst, (const long long *)table, tile_prefix, nweights);
+  else
+    hipLaunchKernelGGL(transpose_weights_kernel<bf16s>, dim3(total_tiles), dim3(256), 0, st, master, (bf16s *)dst, (const long long *)table, tile_prefix, nweights);
+  NRPN_LAUNCH_CHECK("transpose_weights");
+  return NRPN_OK;
+}
+
+// dst[i] (+)= sum_s part[s][i]   (ordered: deterministic)
+__global__ void __launch_bounds__(256) reduce_slices_kernel(const float *__restrict__ part, int slices, long long count4, long long stride4,
+                                                            float *__restrict__ dst, int accumulate) {
+  const f4 *p4 = reinterpret_cast<const f4 *>(part);
+  f4 *d4 = reinterpret_cast<f4 *>(dst);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (long long)gridDim.x * blockDim.x) {
+    f4 a = p4[i];
+    for (int s = 1; s < slices; ++s) { const f4 b = p4[(long long)s * stride4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+    if (accumulate) { const f4 o = d4[i]; a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3]; }
+    d4[i] = a;
+  }
+}
+
+extern "C" int nrpn_reduce_slices(const float *partials, int slices, int64_t count, float *dst, int accumulate, nrpn_stream_t stream) {
+  NRPN_REQUIRE(partials && dst && slices > 0 && count > 0 && count % 4 == 0, "reduce_slices: count must be a positive multiple of 4");
+  NRPN_REQUIRE(((reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "reduce_slices: 16-byte alignment required");
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3(ew_blocks(count / 4)), dim3(256), 0, as_stream(stream), partials, slices, (long long)(count / 4),
+                     (long long)(count / 4), dst, accumulate);
+  NRPN_LAUNCH_CHECK("reduce_slices");
   return NRPN_OK;
 }
 

@@ -38,6 +38,22 @@ def one_cycle(step, total_steps, max_lr, pct_start=0.3, div_factor=25.0, final_d
     return cos(max_lr, minimum, pct), cos(base_momentum, max_momentum, pct)
 
 
+def _packable_weights(model):
+    """{id(weight): (taps, Cout, Cin)} of the weights that feed a single-weight GEMM of the HIP path: nn.Conv3d k1 / k3 (groups 1)
+    and nn.Linear.  Modules whose weights are concatenated into a fused multi-weight GEMM (RPN / FCOS output convs) carry
+    ``_nrpn_fused_gemm`` and keep the reference layout."""
+    from torch import nn
+    out = {}
+    for mod in model.modules():
+        if mod.__dict__.get("_nrpn_fused_gemm", False):
+            continue
+        if isinstance(mod, nn.Conv3d) and mod.groups == 1 and tuple(mod.kernel_size) in ((1, 1, 1), (3, 3, 3)) and mod.weight.requires_grad:
+            out[id(mod.weight)] = (mod.kernel_size[0] ** 3, mod.out_channels, mod.in_channels)
+        elif isinstance(mod, nn.Linear) and mod.weight.requires_grad:
+            out[id(mod.weight)] = (1, mod.out_features, mod.in_features)
+    return out
+
+
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, betas=(0.9, 0.999), eps=1e-8, total_steps=None,
                  bucket_bytes=64 << 20, process_group=None, static_graph=True):
@@ -47,21 +63,43 @@ class FlatTrainer:
         dev = self.params[0].device
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.group = process_group
-        total = sum(p.numel() for p in self.params)
-        self.p_arena = torch.empty(total, dtype=torch.float32, device=dev)
+        # Every slot starts on a 64-float (256-byte) boundary (16-byte vector kernels on single slots); the zero padding is inert in
+        # AdamW (p = g = m = v = 0 stays 0) and in the norm.
+        # Conv / linear weights that feed a single-weight GEMM are stored in the FORWARD GEMM LAYOUT [taps][Cout][Cin] ("packable",
+        # see _packable_weights): the fp32 master (or the bf16 shadow the AdamW kernel writes next to it) is the forward operand as
+        # it stands, wgrad partials are summed into the gradient slot without a layout shuffle, and the dgrad operands of all
+        # weights are refreshed by one batched launch per step (ops.ArenaWeights).  The nn.Parameter keeps the reference's logical
+        # shape [Cout,Cin,k,k,k] as a strided view, so state_dict / checkpoints / torch code see the reference layout.
+        packable = _packable_weights(model)
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.p_arena = torch.zeros(total, dtype=torch.float32, device=dev)
         self.g_arena = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(ops.query("grad_sumsq_floats"), dtype=torch.float32, device=dev) if dev.type == "cuda" else None
-        off = 0
+        self.weights = ops.ArenaWeights(self.p_arena)
         self.slices = []
-        for p in self.params:
+        self.flat_grad = []
+        for p, off in zip(self.params, offs):
             n = p.numel()
-            self.p_arena[off:off + n].copy_(p.data.reshape(-1).float())
-            p.data = self.p_arena[off:off + n].view_as(p)
-            p.grad = self.g_arena[off:off + n].view_as(p)
+            geom = packable.get(id(p))
+            if geom is not None and geom[0] > 1:
+                taps, cout, cin = geom
+                k = round(taps ** (1.0 / 3.0))
+                self.p_arena[off:off + n].view(taps, cout, cin).copy_(p.data.float().reshape(cout, cin, taps).permute(2, 0, 1))
+                p.data = self.p_arena[off:off + n].view(taps, cout, cin).permute(1, 2, 0).view(cout, cin, k, k, k)
+                p.grad = self.g_arena[off:off + n].view(taps, cout, cin).permute(1, 2, 0).view(cout, cin, k, k, k)
+            else:
+                self.p_arena[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = self.p_arena[off:off + n].view_as(p)
+                p.grad = self.g_arena[off:off + n].view_as(p)
+            if geom is not None:
+                self.weights.add(p, off, *geom)
+            self.flat_grad.append(self.g_arena[off:off + n] if geom is not None else None)
             self.slices.append((off, n))
-            off += n
         self.lr, self.wd, self.clip, self.betas, self.eps = lr, weight_decay, clip_grad_norm, betas, eps
         self.total_steps = total_steps
         self.step_count = 0
@@ -73,7 +111,7 @@ class FlatTrainer:
         self.expected = None
         self.seen = [0] * len(self.params)
         for i, p in enumerate(self.params):
-            p._nrpn_sink = ops.GradSink(p.grad, self._make_notify(i))
+            p._nrpn_sink = ops.GradSink(p.grad, self._make_notify(i), self.flat_grad[i])
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         # buckets in reverse parameter order (gradients arrive roughly back to front)
         self.buckets = []       # (start, end) element ranges of g_arena
@@ -149,14 +187,24 @@ class FlatTrainer:
         scale = 1.0 / self.world
         if self.g_arena.is_cuda:
             ops.grad_sumsq(self.g_arena, self.sumsq, scale)
+            shadow = self.weights.shadow_ptr()
             ops.adamw_step(self.p_arena, self.g_arena, self.m, self.v, self.sumsq if self.clip and self.clip > 0 else None, self.clip or 0.0,
-                           lr, (beta1, self.betas[1]), self.eps, self.wd, self.step_count, scale)
+                           lr, (beta1, self.betas[1]), self.eps, self.wd, self.step_count, scale, shadow)
+            self.weights.bump(shadow_written=shadow is not None)
         else:
             raise RuntimeError("FlatTrainer.step needs CUDA tensors (the optimiser kernels have no CPU fallback); "
                                "CPU use is limited to the gloo gradient-exchange tests via sync_gradients()")
         ops.weights_changed()       # the raw-pointer update is invisible to tensor._version: invalidate every GEMM-layout weight copy
         self.g_arena.zero_()
         return lr
+
+    def flat_params(self):
+        """All parameters in the reference's logical element order (a copy), for comparisons / export."""
+        return torch.cat([p.detach().reshape(-1) for p in self.params])
+
+    def flat_grads(self):
+        """All gradients in the reference's logical element order (a copy)."""
+        return torch.cat([p.grad.reshape(-1) for p in self.params])
 
     def reduce_scalars(self, *tensors):
         """One fused all-reduce (mean) of the logging scalars."""

@@ -77,6 +77,8 @@ class RPNHead(nn.Module):
                 torch.nn.init.normal_(layer.weight, std=0.01)
                 if layer.bias is not None:
                     torch.nn.init.constant_(layer.bias, 0)
+        for m in (self.cls_logits, self.bbox_pred):      # rows of ONE fused GEMM: a trainer must keep these in the reference layout
+            m.__dict__["_nrpn_fused_gemm"] = True
         used = num_anchors * (1 + self.delta_width)
         self.head_rows = ((used + 63) // 64) * 64      # padded GEMM width (128 for 13 anchors)
         self._pack = ops.PackedWeight()

@@ -55,6 +55,8 @@ class FCOSHead(nn.Module):
         torch.nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_prob) / prior_prob))
         self.scales = nn.ModuleList([Scale(init_value=1.0) for _ in range(5)])
         self.__dict__["_packs"] = (ops.PackedWeight(), ops.PackedWeight())
+        for m in (self.cls_logits, self.bbox_pred, self.centerness):     # rows of fused GEMMs: reference layout in a trainer's arena
+            m.__dict__["_nrpn_fused_gemm"] = True
 
     @property
     def reg_dim(self):

@@ -342,11 +342,88 @@ class FlattenHeadFn(torch.autograd.Function):
 class GradSink:
     """Direct gradient destination of a parameter inside a flat gradient arena (set by engine.FlatTrainer as
     ``param._nrpn_sink``).  Backward kernels accumulate straight into ``slot`` and call ``notify()`` instead of returning a
-    gradient tensor for autograd to add -- this removes one elementwise kernel per parameter per use."""
-    __slots__ = ("slot", "notify")
+    gradient tensor for autograd to add -- this removes one elementwise kernel per parameter per use.
+    ``flat``: for weights the trainer keeps in the forward GEMM layout [taps][Cout][Cin], the contiguous 1-D arena range of the
+    gradient in THAT layout (the sum of a wgrad's slice partials goes there without any layout shuffle); None otherwise."""
+    __slots__ = ("slot", "notify", "flat")
 
-    def __init__(self, slot, notify):
-        self.slot, self.notify = slot, notify
+    def __init__(self, slot, notify, flat=None):
+        self.slot, self.notify, self.flat = slot, notify, flat
+
+
+class ArenaWeights:
+    """GEMM operands of the weights a trainer keeps in the forward GEMM layout inside its flat fp32 arena (engine.FlatTrainer).
+
+    forward operand  = the master arena itself (fp32) or its bf16 shadow -- the same element order, written by the AdamW kernel as a
+                       second output, so there is no per-step repack;
+    dgrad operand    = [taps reversed][Cin][Cout] copies of ALL weights, refreshed by ONE batched launch per optimiser step.
+    ``epoch`` counts parameter updates (optimiser steps, or torch-side writes noticed through tensor._version)."""
+
+    def __init__(self, master):
+        self.master = master
+        self.entries = []             # (offset, taps, cout, cin, param)
+        self.versions = []
+        self.epoch = 0
+        self.shadow = None            # bf16 [len(master)]
+        self.shadow_epoch = -1
+        self.trans = {}               # dtype -> [tensor, epoch]
+        self.table = None
+        self.launches = {"cast": 0, "transpose": 0}
+
+    def add(self, param, offset, taps, cout, cin):
+        param._nrpn_arena = (self, len(self.entries))
+        self.entries.append((int(offset), int(taps), int(cout), int(cin), param))
+        self.versions.append(param._version)
+        self.table = None
+
+    def bump(self, shadow_written=False):
+        """The master arena was rewritten (optimiser step)."""
+        self.epoch += 1
+        if shadow_written and self.shadow is not None:
+            self.shadow_epoch = self.epoch
+
+    def _check(self, idx):
+        if self.entries[idx][4]._version != self.versions[idx]:      # torch-side write (load_state_dict, manual init): everything is stale
+            self.versions = [e[4]._version for e in self.entries]
+            self.epoch += 1
+
+    def shadow_ptr(self):
+        """bf16 shadow for the AdamW kernel to refresh (None until a bf16 forward asked for it)."""
+        return self.shadow
+
+    def fwd(self, idx, dtype):
+        self._check(idx)
+        off, taps, cout, cin, _ = self.entries[idx]
+        if dtype == torch.float32:
+            return self.master[off:off + taps * cout * cin].view(taps, cout, cin)
+        if self.shadow is None:
+            self.shadow = torch.empty(self.master.numel(), dtype=torch.bfloat16, device=self.master.device)
+        if self.shadow_epoch != self.epoch:
+            call("cast", _p(self.master), _p(self.shadow), self.master.numel(), F32, BF16, _s())
+            self.launches["cast"] += 1
+            self.shadow_epoch = self.epoch
+        return self.shadow[off:off + taps * cout * cin].view(taps, cout, cin)
+
+    def dgrad(self, idx, dtype):
+        self._check(idx)
+        off, taps, cout, cin, _ = self.entries[idx]
+        ent = self.trans.get(dtype)
+        if ent is None:
+            ent = [torch.empty(self.master.numel(), dtype=dtype, device=self.master.device), -1]
+            self.trans[dtype] = ent
+        if ent[1] != self.epoch:
+            if self.table is None:
+                rows, prefix = [], [0]
+                for (o, t, co, ci, _) in self.entries:
+                    rows.append([o, t, co, ci])
+                    prefix.append(prefix[-1] + t * ((co + 63) // 64) * ((ci + 63) // 64))
+                dev = self.master.device
+                self.table = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int32, device=dev), prefix[-1])
+            tab, prefix, total = self.table
+            call("transpose_weights", _p(self.master), _p(ent[0]), _p(tab), _p(prefix), len(self.entries), total, F32 if dtype == torch.float32 else BF16, _s())
+            self.launches["transpose"] += 1
+            ent[1] = self.epoch
+        return ent[0][off:off + taps * cout * cin].view(taps, cin, cout)
 
 
 def _sink(t):
@@ -375,12 +452,17 @@ class PackedWeight:
         self.dgrad = None
 
     def get(self, weights, dtype, rows_total, need_dgrad, cin=None):
+        cin = weights[0].shape[1] if cin is None else cin     # nn.Linear [out,in] and a flattened patch conv are taps == 1
+        taps = weights[0][0].numel() // cin
+        arena = getattr(weights[0], "_nrpn_arena", None) if len(weights) == 1 else None
+        if arena is not None and rows_total == weights[0].shape[0] and arena[0].entries[arena[1]][1:4] == (taps, rows_total, cin):
+            # master weights already live in the GEMM layout inside the trainer's arena: no packing at all
+            aw, idx = arena
+            return aw.fwd(idx, dtype), (aw.dgrad(idx, dtype) if need_dgrad else None)
         key = tuple((w.data_ptr(), w._version) for w in weights) + (dtype, rows_total, need_dgrad, _weight_epoch)
         if key == self.key:
             return self.fwd, self.dgrad
         PACK_COUNT["conv"] += 1
-        cin = weights[0].shape[1] if cin is None else cin     # nn.Linear [out,in] and a flattened patch conv are taps == 1
-        taps = weights[0][0].numel() // cin
         dev = weights[0].device
         padded = rows_total != sum(w.shape[0] for w in weights)
         alloc = torch.zeros if padded else torch.empty
@@ -419,6 +501,22 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None):
         call("conv3d_fwd_ragged", _p(x), _p(wp), _p(bias), _p(y), len(segs), ctypes.addressof(dims), cin, cout, wrows, ksize, _dt(x), flags,
              _p(ws), _s())
     return y
+
+
+# wgrad workspace = [27-bit tap mask per voxel (k3) | per-slice bias partials]; the masks depend only on the grid, so one workspace per
+# grid shape is kept and the masks are built once (NRPN_WGRAD_MASK_READY afterwards).  All launches of a process go to one stream
+# per device here; the bias partials are consumed by the same C call that writes them.
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device, key, nbytes):
+    key = (device.index,) + key
+    ent = _WGRAD_WS.get(key)
+    if ent is None or ent[0].numel() < nbytes:
+        ent = [torch.empty(nbytes, dtype=torch.uint8, device=device), False]
+        _WGRAD_WS[key] = ent
+    ready, ent[1] = ent[1], True
+    return ent[0], ready
 
 
 class ConvFn(torch.autograd.Function):
@@ -470,19 +568,26 @@ class ConvFn(torch.autograd.Function):
         gwp = torch.empty((slices, taps, rows_total, cin), dtype=torch.float32, device=x.device)     # per-slice partials, summed by the unpack
         direct_bias = has_bias and nw == 1 and bsinks[0] is not None
         gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
-        ws = torch.empty(query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x)), dtype=torch.uint8,
-                         device=x.device)      # tap masks + per-slice bias partials
+        ws, mask_ready = _wgrad_workspace(x.device, (n, gx, gy, gz, ksize, segs),
+                                          query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x)))
+        wflags = int(direct_bias) | (2 if mask_ready else 0)
         if segs is None or ksize == 1:
-            call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), int(direct_bias),
-                 _p(ws), _s())
+            call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), wflags, _p(ws), _s())
         else:
             import ctypes
             dims = _seg_dims(segs)
             call("conv3d_wgrad_ragged", _p(x), _p(dy), _p(gwp), _p(gb), len(segs), ctypes.addressof(dims), cin, rows_total, rows_total, ksize,
-                 _dt(x), int(direct_bias), _p(ws), _s())
+                 _dt(x), wflags, _p(ws), _s())
         gws, gbs, row = [], [], 0
         for i, w in enumerate(weights):
-            if wsinks[i] is not None:
+            if wsinks[i] is not None and wsinks[i].flat is not None and nw == 1 and rows_total == w.shape[0]:
+                # the arena keeps this gradient in the partials' own layout: ordered sum of the slices, added in place
+                call("reduce_slices", _p(gwp), slices, gwp[0].numel(), _p(wsinks[i].flat), 1, _s())
+                wsinks[i].notify()
+                gws.append(None)
+            elif wsinks[i] is not None:
+                if not wsinks[i].slot.is_contiguous():
+                    raise lib.NrpnError("a GEMM-layout arena weight reached a fused multi-weight GEMM (mark the module _nrpn_fused_gemm)")
                 call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(wsinks[i].slot), 1, slices, _s())
                 wsinks[i].notify()
                 gws.append(None)
@@ -1100,6 +1205,6 @@ def grad_sumsq(grad_flat, out, grad_scale=1.0):
     call("grad_sumsq", _p(grad_flat), grad_flat.numel(), float(grad_scale), _p(out), _s())
 
 
-def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step, grad_scale=1.0):
+def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step, grad_scale=1.0, shadow=None):
     call("adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), float(grad_scale), float(max_norm), float(lr), float(betas[0]), float(betas[1]),
-         float(eps), float(wd), int(step), _s())
+         float(eps), float(wd), int(step), _p(shadow), _s())

@@ -46,7 +46,7 @@ def _worker(rank, world, port, bucket_bytes, q):
         tr.g_arena.zero_()
         ((model(xs) - ys) ** 2).sum().backward()
         tr.sync_gradients()
-    q.put((rank, w0, tr.g_arena.clone() / world, len(tr.buckets)))
+    q.put((rank, w0, tr.flat_grads() / world, len(tr.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,7 +127,7 @@ def _sink_worker(rank, world, port, q):
         ((model(xs) - ys) ** 2).sum().backward()
         early.append(sum(tr.launched))
         tr.sync_gradients()
-    q.put((rank, tr.g_arena.clone() / world, list(tr.expected), early))
+    q.put((rank, tr.flat_grads() / world, list(tr.expected), early))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -49,7 +49,8 @@ def test_flat_trainer_arena_equals_autograd_grads(golden, dev):
         tr.g_arena.zero_()
         _loss(m, xs, gts, pos, neg).backward()
         tr.sync_gradients()
-        assert torch.equal(tr.g_arena, plain), (tr.g_arena - plain).abs().max().item() / plain.abs().max().item()
+        got = tr.flat_grads()
+        assert torch.equal(got, plain), (got - plain).abs().max().item() / plain.abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -60,7 +61,7 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
     from nerf_rpn_amd import ops
     from nerf_rpn_amd.engine import FlatTrainer
     xs, gts, pos, neg = _batch(golden, dev)
-    lr, steps = 1e-3, 3
+    lr, steps = 3e-4, 3
 
     ref = build(True, 160, dev).train()
     ref.set_compute_dtype(dtype)
@@ -86,18 +87,19 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
         loss.backward()
         tr.step()
         losses.append(loss.item())
-    packed_modules = sum(1 for mod in m.modules() if "_nrpn_pack" in mod.__dict__) + sum(1 for mod in m.modules() if isinstance(getattr(mod, "_pack", None), ops.PackedWeight))
-    stems = sum(1 for mod in m.modules() if "_nrpn_stem" in mod.__dict__)
-    assert packed_modules >= 20 and stems == 1
-    assert ops.PACK_COUNT["conv"] - before["conv"] == packed_modules * steps, (ops.PACK_COUNT, before, packed_modules)
-    assert ops.PACK_COUNT["stem"] - before["stem"] == stems * steps
+    # single-weight GEMMs read the arena (fp32 master / bf16 shadow written by AdamW) directly: only the fused cls+bbox head GEMM and
+    # the 7^3 stem still repack, exactly once per step; the dgrad operands of all arena weights are refreshed by ONE launch per step
+    assert ops.PACK_COUNT["conv"] - before["conv"] == steps, (ops.PACK_COUNT, before)
+    assert ops.PACK_COUNT["stem"] - before["stem"] == steps
+    assert tr.weights.launches["transpose"] == steps and tr.weights.launches["cast"] == (1 if dtype == torch.bfloat16 else 0), tr.weights.launches
+    assert len(tr.weights.entries) >= 28
     with torch.no_grad():
         final = _loss(m, xs, gts, pos, neg).item()
     # the optimiser must visibly move the loss (a forward on stale weights would reproduce losses[0] exactly) ...
-    assert abs(ref_losses[-1] - ref_losses[0]) > 20 * 2e-3 * abs(ref_losses[0]) or abs(ref_final - ref_losses[0]) > 20 * 2e-3 * abs(ref_losses[0])
+    assert abs(ref_final - ref_losses[0]) > 0.2 * abs(ref_losses[0]), (ref_losses, ref_final)
     # ... and both trainers must follow the same trajectory.  fp32: identical gradients (deterministic kernels), the only difference
     # is the rounding of the AdamW formula; bf16 adds re-rounding of the updated weights.
-    tol = 2e-3 if dtype == torch.float32 else 2e-2
+    tol = 2e-3 if dtype == torch.float32 else 5e-2
     for a, b in zip(losses + [final], ref_losses + [ref_final]):
         assert abs(a - b) <= tol * max(1.0, abs(b)), (losses, final, ref_losses, ref_final)
     after_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
@@ -107,5 +109,5 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
     # BatchNorm: exact gradient 0) may step in opposite directions; compare the entries that moved consistently (> 2 lr in 3 steps)
     sig = moved > 2.0 * lr
     assert sig.float().mean().item() > 0.05
-    err = (tr.p_arena - after_ref)[sig].abs().max().item()
+    err = (tr.flat_params() - after_ref)[sig].abs().max().item()
     assert err < (0.05 if dtype == torch.float32 else 0.5) * lr * steps, err
