@@ -66,11 +66,14 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
     ref = build(True, 160, dev).train()
     ref.set_compute_dtype(dtype)
     opt = torch.optim.AdamW(ref.parameters(), lr=lr, weight_decay=0.01)
-    ref_losses = []
+    ref_losses, sig = [], None
     for _ in range(steps):
         opt.zero_grad(set_to_none=True)
         loss = _loss(ref, xs, gts, pos, neg)
         loss.backward()
+        # entries whose gradient is well above their tensor's rounding noise on EVERY step (see the weight comparison below)
+        step_sig = torch.cat([(p.grad.abs() > 1e-2 * p.grad.abs().max()).reshape(-1) for p in ref.parameters()])
+        sig = step_sig if sig is None else (sig & step_sig)
         torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
         opt.step()
         ref_losses.append(loss.item())
@@ -103,11 +106,9 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
     for a, b in zip(losses + [final], ref_losses + [ref_final]):
         assert abs(a - b) <= tol * max(1.0, abs(b)), (losses, final, ref_losses, ref_final)
     after_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
-    init = torch.cat([p.detach().reshape(-1) for p in build(True, 160, dev).parameters()])
-    moved = (after_ref - init).abs()
-    # Adam normalises every entry to a +-lr-sized step, so entries whose gradient is rounding noise (conv biases in front of
-    # BatchNorm: exact gradient 0) may step in opposite directions; compare the entries that moved consistently (> 2 lr in 3 steps)
-    sig = moved > 2.0 * lr
-    assert sig.float().mean().item() > 0.05
+    # Adam normalises every entry to a +-lr-sized step, so entries whose gradient is rounding noise (e.g. conv biases in front of
+    # BatchNorm: exact gradient 0) step in directions that depend on the last bit of the clip coefficient; the weights are compared
+    # where the gradient was significant (> 1 % of its tensor's maximum) on all three steps.
+    assert sig.float().mean().item() > 0.02, sig.float().mean().item()
     err = (tr.flat_params() - after_ref)[sig].abs().max().item()
     assert err < (0.05 if dtype == torch.float32 else 0.5) * lr * steps, err
