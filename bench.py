@@ -90,7 +90,7 @@ class ConvProbe:
             if not self.enabled or name not in ("conv3d_fwd", "conv3d_wgrad"):
                 return orig(name, *args)
             n_, gx_, gy_, gz_, cin_, _, wrows_, k_ = args[4:12]
-            if 2.0 * n_ * gx_ * gy_ * gz_ * cin_ * wrows_ * (k_ ** 3) < 1e11:     # only the heavy launches are timed
+            if 2.0 * n_ * gx_ * gy_ * gz_ * cin_ * wrows_ * (k_ ** 3) < 1e10:     # only the heavy launches (>= 10 GFLOP) are timed
                 return orig(name, *args)
             a = torch.cuda.Event(enable_timing=True)
             b = torch.cuda.Event(enable_timing=True)
@@ -146,6 +146,9 @@ class ConvProbe:
                 "avg_ms": round(avg_ms, 4), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note, "algorithmic_bytes": algo_bytes,
                 "timed_heavy_launches": {"tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2), "ms_per_step": None}}
+        # per (call, shape) breakdown of every timed conv launch class: launches per step are filled in by main()
+        roof["conv_breakdown"] = [{"call": k[0], "voxels": k[1][0], "cin": k[1][1], "cout": k[1][2], "k": k[1][3], "launches": v[0],
+                                   "avg_us": round(1e3 * v[1] / v[0], 1), "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 1)} for k, v in rows]
         return roof, rows
 
 

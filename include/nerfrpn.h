@@ -197,8 +197,10 @@ size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cin,
 int nrpn_conv3d_wgrad_slices(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 /* accumulate_bias = flags: NRPN_WGRAD_ACC_BIAS: the column sums are ADDED to gbias (e.g. a slot of a flat gradient arena) instead of
  * overwriting; NRPN_WGRAD_MASK_READY: `workspace` still holds the tap masks an earlier call wrote for the same (n, gx, gy, gz) grid /
- * segment list, so they are not rebuilt (callers that keep one workspace per grid shape save a launch per layer). */
-enum { NRPN_WGRAD_ACC_BIAS = 1, NRPN_WGRAD_MASK_READY = 2 };
+ * segment list, so they are not rebuilt (callers that keep one workspace per grid shape save a launch per layer);
+ * NRPN_WGRAD_DEFER_BIAS: gbias must still be non-NULL to request the partial sums, but it is not written by this call. */
+enum { NRPN_WGRAD_ACC_BIAS = 1, NRPN_WGRAD_MASK_READY = 2,
+       NRPN_WGRAD_DEFER_BIAS = 4 /* leave the bias partials in the workspace: nrpn_reduce_slices finishes them */ };
 int nrpn_conv3d_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
                       int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
                       nrpn_stream_t stream);
@@ -401,7 +403,11 @@ int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_
  * nrpn_reduce_slices: dst[i] (+)= sum over the S voxel-slice partials of a wgrad (already in the forward layout), in slice order. */
 int nrpn_transpose_weights(const float *master, void *dst, const int64_t *table, const int32_t *tile_prefix, int nweights,
                            int total_tiles, int dtype, nrpn_stream_t stream);
-int nrpn_reduce_slices(const float *partials, int slices, int64_t count, float *dst, int accumulate, nrpn_stream_t stream);
+/* bias_partials (optional): the per-slice column sums a nrpn_conv3d_wgrad call with NRPN_WGRAD_DEFER_BIAS left in its workspace at
+ * byte offset nrpn_conv3d_wgrad_bias_offset(...) ([slices][wrows] f32); the same launch then also writes / accumulates gbias[cout]. */
+int nrpn_reduce_slices(const float *partials, int slices, int64_t count, float *dst, int accumulate, const float *bias_partials,
+                       int wrows, int cout, float *gbias, int accumulate_bias, nrpn_stream_t stream);
+size_t nrpn_conv3d_wgrad_bias_offset(int n, int gx, int gy, int gz, int ksize);
 
 #ifdef __cplusplus
 }

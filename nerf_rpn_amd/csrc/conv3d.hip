@@ -1636,6 +1636,7 @@ static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
 
 // workspace = [tap mask: M u32 (k3 only)][bias partials: slices * wrows f32]
 static size_t wgrad_mask_bytes(long long M, int ksize) { return ksize == 3 ? (size_t)((M * 4 + 255) / 256 * 256) : 0; }
+extern "C" size_t nrpn_conv3d_wgrad_bias_offset(int n, int gx, int gy, int gz, int ksize) { return wgrad_mask_bytes((long long)n * gx * gy * gz, ksize); }
 extern "C" size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype) {
   const long long M = (long long)n * gx * gy * gz;
   const int slices = wgrad_plan(M, wrows, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, 0, cout, cin).ksplit;
@@ -1662,6 +1663,7 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
   a.x_bytes = (unsigned)(a.M * cin * es); a.dy_bytes = (unsigned)(a.M * cout * es);
   a.vmask = reinterpret_cast<const unsigned *>(workspace);
   const bool mask_ready = (accumulate_bias & NRPN_WGRAD_MASK_READY) != 0;     // the caller kept the workspace of an earlier call on this grid
+  const bool defer_bias = (accumulate_bias & NRPN_WGRAD_DEFER_BIAS) != 0;     // nrpn_reduce_slices will sum the bias partials
   accumulate_bias &= NRPN_WGRAD_ACC_BIAS;
   if (ksize == 3 && !mask_ready)
     hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz,
@@ -1686,7 +1688,7 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
     hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
     NRPN_LAUNCH_CHECK("conv_wgrad_big");
   }
-  if (rc || !gbias) return rc;
+  if (rc || !gbias || defer_bias) return rc;
   hipLaunchKernelGGL(bias_finalize_kernel, dim3((unsigned)((cout + 255) / 256)), dim3(256), 0, st, bias_part, a.ksplit, wrows, cout, gbias,
                      accumulate_bias);
   NRPN_LAUNCH_CHECK("bias_finalize");

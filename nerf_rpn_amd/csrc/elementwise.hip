@@ -781,12 +781,23 @@ extern "C" int nrpn_transpose_weights(const float *master, void *dst, const int6
   return NRPN_OK;
 }
 
-// dst[i] (+)= sum_s part[s][i]   (ordered: deterministic)
+// dst[i] (+)= sum_s part[s][i]   (ordered: deterministic).  The last block optionally finishes the bias gradient of the same wgrad
+// (per-slice column sums left in its workspace), so weight + bias gradients of a layer cost one launch.
 __global__ void __launch_bounds__(256) reduce_slices_kernel(const float *__restrict__ part, int slices, long long count4, long long stride4,
-                                                            float *__restrict__ dst, int accumulate) {
+                                                            float *__restrict__ dst, int accumulate, const float *__restrict__ bias_part,
+                                                            int wrows, int cout, float *__restrict__ gbias, int accumulate_bias) {
+  if (bias_part && blockIdx.x == gridDim.x - 1) {
+    for (int c = threadIdx.x; c < cout; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < slices; ++k) s += bias_part[(long long)k * wrows + c];
+      gbias[c] = accumulate_bias ? gbias[c] + s : s;
+    }
+    return;
+  }
   const f4 *p4 = reinterpret_cast<const f4 *>(part);
   f4 *d4 = reinterpret_cast<f4 *>(dst);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (long long)gridDim.x * blockDim.x) {
+  const long long nb = gridDim.x - (bias_part ? 1 : 0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += nb * blockDim.x) {
     f4 a = p4[i];
     for (int s = 1; s < slices; ++s) { const f4 b = p4[(long long)s * stride4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
     if (accumulate) { const f4 o = d4[i]; a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3]; }
@@ -794,11 +805,13 @@ __global__ void __launch_bounds__(256) reduce_slices_kernel(const float *__restr
   }
 }
 
-extern "C" int nrpn_reduce_slices(const float *partials, int slices, int64_t count, float *dst, int accumulate, nrpn_stream_t stream) {
+extern "C" int nrpn_reduce_slices(const float *partials, int slices, int64_t count, float *dst, int accumulate, const float *bias_partials,
+                                  int wrows, int cout, float *gbias, int accumulate_bias, nrpn_stream_t stream) {
   NRPN_REQUIRE(partials && dst && slices > 0 && count > 0 && count % 4 == 0, "reduce_slices: count must be a positive multiple of 4");
   NRPN_REQUIRE(((reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "reduce_slices: 16-byte alignment required");
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3(ew_blocks(count / 4)), dim3(256), 0, as_stream(stream), partials, slices, (long long)(count / 4),
-                     (long long)(count / 4), dst, accumulate);
+  NRPN_REQUIRE(!bias_partials || (gbias && cout > 0 && wrows >= cout), "reduce_slices: bad bias arguments");
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3(ew_blocks(count / 4) + (bias_partials ? 1 : 0)), dim3(256), 0, as_stream(stream), partials, slices,
+                     (long long)(count / 4), (long long)(count / 4), dst, accumulate, bias_partials, wrows, cout, gbias, accumulate_bias);
   NRPN_LAUNCH_CHECK("reduce_slices");
   return NRPN_OK;
 }

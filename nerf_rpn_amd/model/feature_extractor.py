@@ -77,6 +77,18 @@ class VGG_FPN(nn.Module):
         x = ops.to_channels_last(X, self.compute_dtype)
         return tuple(hip_nn.as_ncdhw(o) for o in self.forward_cl(x))
 
+    def feature_grids(self, size):
+        """(X, Y, Z) of the 4 output maps for an input grid ``size`` -- shape arithmetic only, so target assignment can be queued
+        before the backbone runs."""
+        mods = list(self.layers)
+        stages = [m for m in mods if isinstance(m, nn.Sequential)]
+        size = hip_nn.module_out_size(mods[:len(mods) - len(stages)], tuple(size))
+        grids = []
+        for st in stages:
+            size = hip_nn.module_out_size(list(st), size)
+            grids.append(size)
+        return grids[-4:]
+
 
 class Bottleneck(nn.Module):
     """ResNet bottleneck for 3D grids; stride sits on the first 1x1x1 conv (reference feature_extractor.py:31-68)."""
@@ -165,6 +177,17 @@ class ResNet_FPN_256(nn.Module):
 
     def forward(self, x):
         return [hip_nn.as_ncdhw(o) for o in self.forward_cl(ops.to_channels_last(x, self.compute_dtype))]
+
+    def feature_grids(self, size):
+        size = hip_nn.conv_out(size, 7, 2, 3)
+        if self.is_max_pool:
+            size = hip_nn.module_out_size([self._pool], size)
+        grids = []
+        for i in range(len(self.layers)):
+            if i > 0:
+                size = tuple((g - 1) // 2 + 1 for g in size)        # stride-2 1x1x1 conv of the stage's first bottleneck
+            grids.append(size)
+        return grids
 
 
 def _unbuilt(name):
@@ -368,3 +391,11 @@ class SwinTransformer_FPN(nn.Module):
     def forward(self, X):
         x = ops.to_channels_last(X, self.compute_dtype)
         return tuple(hip_nn.as_ncdhw(o) for o in self.forward_cl(x))
+
+    def feature_grids(self, size):
+        size = tuple(int(g) // self.patch_size for g in size)
+        grids = [size]
+        for _ in range(len(self.stages) - 1):
+            size = tuple((g + 1) // 2 for g in size)                # PatchMerging pads odd sizes
+            grids.append(size)
+        return grids

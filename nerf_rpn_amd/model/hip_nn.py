@@ -57,10 +57,21 @@ def ragged_split(x, feats):
     return outs
 
 
+def _flush_bn_counter(mod, *_):
+    pending = mod.__dict__.get("_nrpn_pending_batches", 0)
+    if pending:
+        mod.num_batches_tracked.add_(pending)
+        mod.__dict__["_nrpn_pending_batches"] = 0
+
+
 def batch_norm(mod, x, relu):
     training = mod.training or mod.running_mean is None
     if mod.training and mod.track_running_stats and mod.num_batches_tracked is not None:
-        mod.num_batches_tracked.add_(1)
+        # num_batches_tracked only feeds state_dict (momentum is fixed here): count on the host and materialise the buffer when a
+        # state_dict is taken, instead of one int64 add launch per BatchNorm per step
+        if "_nrpn_pending_batches" not in mod.__dict__:
+            mod.register_state_dict_pre_hook(_flush_bn_counter)
+        mod.__dict__["_nrpn_pending_batches"] = mod.__dict__.get("_nrpn_pending_batches", 0) + 1
     return ops.BatchNormFn.apply(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, training,
                                  mod.momentum if mod.momentum is not None else 0.1, mod.eps, relu)
 
@@ -105,6 +116,25 @@ def run_modules(mods, x):
         else:
             raise NotImplementedError(f"no HIP kernel mapping for module {type(m).__name__}")
     return x
+
+
+def conv_out(size, k, s, p):
+    return tuple((int(g) + 2 * p - k) // s + 1 for g in size)
+
+
+def module_out_size(mods, size):
+    """Spatial size after a flat list of Conv3d / MaxPool3d / Sequential / pointwise modules (shape arithmetic only)."""
+    for m in mods:
+        if isinstance(m, nn.Sequential):
+            size = module_out_size(list(m), size)
+        elif isinstance(m, nn.Conv3d):
+            size = conv_out(size, m.kernel_size[0], m.stride[0], m.padding[0])
+        elif isinstance(m, nn.MaxPool3d):
+            k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+            st = m.stride if isinstance(m.stride, int) else m.stride[0]
+            pd = m.padding if isinstance(m.padding, int) else m.padding[0]
+            size = tuple(ops.query("pool_out_size", int(g), k, st, pd, int(bool(m.ceil_mode))) for g in size)
+    return size
 
 
 def as_ncdhw(x):

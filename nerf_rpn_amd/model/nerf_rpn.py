@@ -88,7 +88,14 @@ class NeRFRegionProposalNetwork(nn.Module):
         meshes, targets = self.transform(list(meshes), targets)
         self.check_bbox_degeneration(targets)
         mesh_tensors = ops.stack_scenes(meshes)
+        prepared = None
+        if self.training and hasattr(self.backbone, "feature_grids"):
+            # target assignment + sampling (the only host read-backs of a training step) are issued before the backbone: the rest
+            # of the step is then enqueued without a synchronisation (see RegionProposalNetwork.prepare_targets)
+            size = tuple(int(v) for v in mesh_tensors.shape[-3:])
+            prepared = self.rpn.prepare_targets(size, [tuple(g) for g in self.backbone.feature_grids(size)], targets,
+                                                original_mesh_sizes, mesh_tensors.device)
         features = list(self.backbone(mesh_tensors))
         proposals, level_index, proposal_losses, scores = self.rpn(mesh_tensors, features, original_mesh_sizes, targets,
-                                                                   objectness_output_paths)
+                                                                   objectness_output_paths, prepared)
         return [features, proposals, level_index], proposal_losses, scores

@@ -570,7 +570,11 @@ class ConvFn(torch.autograd.Function):
         gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
         ws, mask_ready = _wgrad_workspace(x.device, (n, gx, gy, gz, ksize, segs),
                                           query("conv3d_wgrad_workspace_bytes", n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x)))
-        wflags = int(direct_bias) | (2 if mask_ready else 0)
+        # arena path: weight-slice sum and bias-slice sum of this layer go out as ONE launch (reduce_slices), so the wgrad call leaves
+        # the bias partials in the workspace
+        fused_reduce = nw == 1 and wsinks[0] is not None and wsinks[0].flat is not None and rows_total == weights[0].shape[0]
+        defer_bias = fused_reduce and direct_bias
+        wflags = int(direct_bias) | (2 if mask_ready else 0) | (4 if defer_bias else 0)
         if segs is None or ksize == 1:
             call("conv3d_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x), wflags, _p(ws), _s())
         else:
@@ -582,7 +586,9 @@ class ConvFn(torch.autograd.Function):
         for i, w in enumerate(weights):
             if wsinks[i] is not None and wsinks[i].flat is not None and nw == 1 and rows_total == w.shape[0]:
                 # the arena keeps this gradient in the partials' own layout: ordered sum of the slices, added in place
-                call("reduce_slices", _p(gwp), slices, gwp[0].numel(), _p(wsinks[i].flat), 1, _s())
+                bias_part = ws.data_ptr() + query("conv3d_wgrad_bias_offset", n, gx, gy, gz, ksize) if defer_bias else 0
+                call("reduce_slices", _p(gwp), slices, gwp[0].numel(), _p(wsinks[i].flat), 1, bias_part, rows_total, rows_total,
+                     _p(gb) if defer_bias else 0, 1, _s())
                 wsinks[i].notify()
                 gws.append(None)
             elif wsinks[i] is not None:
