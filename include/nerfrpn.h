@@ -53,6 +53,14 @@ int nrpn_sort_vertices_f32(const float *vertices, const uint8_t *mask, const int
                            int32_t *idx, int64_t bn, int m, nrpn_stream_t stream);
 /* paired: b1,b2 [n,7] (x,y,z,w,h,d,theta) -> iou [n]            (cal_iou_3d, oriented_iou_loss.py:82-107) */
 int nrpn_iou3d_obb_pair_f32(const float *b1, const float *b2, float *iou, int64_t n, nrpn_stream_t stream);
+/* Differentiable IoU-type regression losses of RotatedIOULoss (model/rpn.py:133-164, fcos/loss.py:137-173) on paired boxes:
+ *   pred, target [n,7] -> loss [n], grad [n,7] = d loss / d pred (target is a constant), iou [n] (optional).
+ *   mode 0 'iou': -log((iou*union+1)/(union+1)); 1 'linear_iou': 1 - that ratio; 2 'giou' (cal_giou_3d, oriented_iou_loss.py:109-127);
+ *   3 'diou' (cal_diou_3d, :129-148), enclosing box = smallest_bounding_box (min_enclosing_box.py:54-125).
+ * Forward and gradient come out of ONE launch: the reference's arithmetic is evaluated on dual numbers (value + 7 partials), masks /
+ * vertex sort / arg-min selections on the values, which is what autograd differentiates in the reference's 40-kernel chain. */
+int nrpn_rotated_iou_loss_f32(const float *pred, const float *target, int64_t n, int mode, float *loss, float *grad, float *iou,
+                              nrpn_stream_t stream);
 /* all pairs: a [n,w], b [m,w] -> iou [n,m]; w = 6 (AABB x1..z2) or 7 (OBB)   (box_iou_3d, model/utils.py:387-458) */
 int nrpn_iou3d_matrix_f32(const float *a, const float *b, float *iou, int64_t n, int64_t m, int box_dim,
                           nrpn_stream_t stream);

@@ -62,6 +62,12 @@ class RotatedIOULoss(nn.Module):
     def forward(self, pred, target, weight=None):
         dummy = torch.zeros(pred.shape[0], 3, device=pred.device)
         pb, tb = decode_fcos_obb(dummy, pred).unsqueeze(0), decode_fcos_obb(dummy, target).unsqueeze(0)
+        if pb.is_cuda and not tb.requires_grad and self.loss_type in ("iou", "linear_iou", "giou", "diou"):
+            losses = ops.rotated_iou_loss(pb[0], tb[0], self.loss_type)[0]        # fused forward + gradient (csrc/geomloss.hip)
+            if weight is not None and weight.sum() > 0:
+                return (losses * weight).sum()
+            assert losses.numel() != 0
+            return losses.sum()
         if self.loss_type in ("iou", "linear_iou"):
             ious, _, _, _, unions = cal_iou_3d(pb, tb, verbose=True)
             ious = (ious * unions + 1.0) / (unions + 1.0)

@@ -66,10 +66,13 @@ class VGG_FPN(nn.Module):
         mods = list(self.layers)
         stages = [m for m in mods if isinstance(m, nn.Sequential)]
         head = mods[:len(mods) - len(stages)]
-        x = hip_nn.run_modules(head, x)
+        counted = self.training
+        if counted:
+            hip_nn.bn_counters(self).step()      # all 17 num_batches_tracked buffers in one launch
+        x = hip_nn.run_modules(head, x, counted)
         taps = []
         for st in stages:
-            x = hip_nn.run_modules(st, x)
+            x = hip_nn.run_modules(st, x, counted)
             taps.append(x)
         return self.fpn_neck.forward_cl(taps[-4:])
 

@@ -57,21 +57,46 @@ def ragged_split(x, feats):
     return outs
 
 
-def _flush_bn_counter(mod, *_):
-    pending = mod.__dict__.get("_nrpn_pending_batches", 0)
-    if pending:
-        mod.num_batches_tracked.add_(pending)
-        mod.__dict__["_nrpn_pending_batches"] = 0
+class BNCounters:
+    """``num_batches_tracked`` of every BatchNorm3d under ``root`` as 0-dim views of ONE int64 tensor, so a training forward bumps
+    all of them with a single launch (``step()``) instead of one tiny add per layer.  The buffers keep their names, values and
+    state-dict behaviour; the caller then runs the layers with ``counted=True`` so they skip their own increment."""
+
+    def __init__(self, root):
+        self.root, self.flat, self.mods = root, None, None
+
+    def step(self):
+        if self.mods is None:
+            self.mods = [m for m in self.root.modules()
+                         if isinstance(m, nn.BatchNorm3d) and m.track_running_stats and m.num_batches_tracked is not None]
+        if not self.mods:
+            return
+        stale = self.flat is None or any(m.num_batches_tracked.data_ptr() != self.flat[i].data_ptr() for i, m in enumerate(self.mods))
+        if stale:      # first use, or the module was moved / reloaded with fresh buffers
+            self.flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in self.mods]).contiguous()
+            for i, m in enumerate(self.mods):
+                m.num_batches_tracked = self.flat[i]
+        if all(m.training for m in self.mods):
+            self.flat.add_(1)
+        else:          # some BatchNorm layers are frozen (eval mode inside a training backbone): only the live ones count
+            for m in self.mods:
+                if m.training:
+                    m.num_batches_tracked.add_(1)
 
 
-def batch_norm(mod, x, relu):
+def bn_counters(root):
+    c = root.__dict__.get("_nrpn_bn_counters")
+    if c is None:
+        c = BNCounters(root)
+        root.__dict__["_nrpn_bn_counters"] = c
+    return c
+
+
+def batch_norm(mod, x, relu, counted=False):
+    """``counted``: the caller already bumped this module's num_batches_tracked through a BNCounters.step() of this forward."""
     training = mod.training or mod.running_mean is None
-    if mod.training and mod.track_running_stats and mod.num_batches_tracked is not None:
-        # num_batches_tracked only feeds state_dict (momentum is fixed here): count on the host and materialise the buffer when a
-        # state_dict is taken, instead of one int64 add launch per BatchNorm per step
-        if "_nrpn_pending_batches" not in mod.__dict__:
-            mod.register_state_dict_pre_hook(_flush_bn_counter)
-        mod.__dict__["_nrpn_pending_batches"] = mod.__dict__.get("_nrpn_pending_batches", 0) + 1
+    if mod.training and mod.track_running_stats and mod.num_batches_tracked is not None and not counted:
+        mod.num_batches_tracked.add_(1)
     return ops.BatchNormFn.apply(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, training,
                                  mod.momentum if mod.momentum is not None else 0.1, mod.eps, relu)
 
@@ -83,8 +108,9 @@ def max_pool(mod, x):
     return ops.MaxPoolFn.apply(x, k, s, p, bool(mod.ceil_mode))
 
 
-def run_modules(mods, x):
-    """Run a flat list of nn modules on a channels-last tensor, fusing conv -> [BN] -> [ReLU] runs."""
+def run_modules(mods, x, counted=False):
+    """Run a flat list of nn modules on a channels-last tensor, fusing conv -> [BN] -> [ReLU] runs.
+    ``counted``: see batch_norm."""
     mods = list(mods)
     i = 0
     while i < len(mods):
@@ -95,7 +121,7 @@ def run_modules(mods, x):
             if isinstance(nxt, nn.BatchNorm3d):
                 x = conv3d(m, x)
                 fuse = isinstance(nxt2, nn.ReLU)
-                x = batch_norm(nxt, x, fuse)
+                x = batch_norm(nxt, x, fuse, counted)
                 i += 3 if fuse else 2
             elif isinstance(nxt, nn.ReLU):
                 x = conv3d(m, x, relu=True)
@@ -107,11 +133,11 @@ def run_modules(mods, x):
             x = max_pool(m, x)
             i += 1
         elif isinstance(m, nn.Sequential):
-            x = run_modules(m, x)
+            x = run_modules(m, x, counted)
             i += 1
         elif isinstance(m, nn.BatchNorm3d):
             fuse = isinstance(nxt, nn.ReLU)
-            x = batch_norm(m, x, fuse)
+            x = batch_norm(m, x, fuse, counted)
             i += 2 if fuse else 1
         else:
             raise NotImplementedError(f"no HIP kernel mapping for module {type(m).__name__}")

@@ -66,6 +66,14 @@ class RotatedIOULoss(nn.Module):
         self.loss_type = loss_type
 
     def forward(self, pred, target, weight=None):
+        if pred.is_cuda and not target.requires_grad and self.loss_type in ("iou", "linear_iou", "giou", "diou"):
+            # one fused kernel: loss and d loss / d pred of every pair (ops.RotatedIoULossFn); the torch formulation below remains for
+            # the case where the target also needs a gradient
+            losses = ops.rotated_iou_loss(pred, target, self.loss_type)[0]
+            if weight is not None and weight.sum() > 0:
+                return (losses * weight).sum()
+            assert losses.numel() != 0
+            return losses.sum()
         p, t = pred.unsqueeze(0), target.unsqueeze(0)
         if self.loss_type in ('iou', 'linear_iou'):
             ious, _, _, _, unions = cal_iou_3d(p, t, verbose=True)

@@ -72,6 +72,39 @@ def iou3d_pair(b1, b2):
     return out.reshape(shape)
 
 
+_IOU_LOSS_MODES = {"iou": 0, "linear_iou": 1, "giou": 2, "diou": 3}
+
+
+class RotatedIoULossFn(torch.autograd.Function):
+    """Per-pair IoU-type regression loss of RotatedIOULoss (reference model/rpn.py:133-164, fcos/loss.py:137-173): pred, target
+    [n,7] -> (loss [n], iou [n]).  Forward and the gradient w.r.t. ``pred`` come out of one kernel (dual numbers over the reference's
+    arithmetic, csrc/geomloss.hip); ``target`` is a constant."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mode):
+        p, t = _f32(pred).reshape(-1, 7).contiguous(), _f32(target).detach().reshape(-1, 7).contiguous()
+        _chk(p, t)
+        n = p.shape[0]
+        loss = torch.empty(n, dtype=torch.float32, device=p.device)
+        iou = torch.empty(n, dtype=torch.float32, device=p.device)
+        grad = torch.empty((n, 7), dtype=torch.float32, device=p.device)
+        call("rotated_iou_loss_f32", _p(p), _p(t), n, _IOU_LOSS_MODES[mode], _p(loss), _p(grad), _p(iou), _s())
+        ctx.save_for_backward(grad)
+        ctx.shape = pred.shape
+        ctx.mark_non_differentiable(iou)
+        return loss.reshape(pred.shape[:-1]), iou.reshape(pred.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_iou):
+        (grad,) = ctx.saved_tensors
+        return (grad * g_loss.reshape(-1, 1)).reshape(ctx.shape), None, None
+
+
+def rotated_iou_loss(pred, target, mode):
+    """-> (per-pair loss, per-pair IoU); differentiable in ``pred``."""
+    return RotatedIoULossFn.apply(pred, target, mode)
+
+
 def iou3d_matrix(a, b):
     """All-pairs IoU [n,w] x [m,w] -> [n,m], w = 6 (AABB) or 7 (OBB) (reference box_iou_3d)."""
     if a.shape[1] != b.shape[1] or a.shape[1] not in (6, 7):
