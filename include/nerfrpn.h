@@ -292,6 +292,12 @@ int nrpn_add_relu(const void *a, const void *b, void *y, int64_t count, int relu
  * clip(1-exp(-exp(s)/100),0,1), 2 the ScanNet variant clip(1-exp(-max(s,0)/100),0,1) on channel 3.  One pass instead of
  * numpy alpha + host transpose + H2D of fp32 + device transpose. */
 int nrpn_ingest_rgbsigma(const void *src, int src_is_u8, void *dst, int64_t voxels, int alpha_mode, int dtype, nrpn_stream_t stream);
+/* Ingest + training augmentation in one pass (datasets.py:109-163, 291-329): rot90 (z_up: transpose(x,y)+flip x, else transpose(x,z)+
+ * flip z), flips of axis 0 and axis 1 (z_up) / 2, then -- if h_xform (host, 9 floats = R(angle)*scale row-major) is not NULL --
+ * rotate_and_scale_scene's trilinear resample (grid_sample align_corners=True, zero padding) of the alpha-converted scene.
+ * src (W,L,H,4) f32|u8 -> dst [OW,OL,OH,4] dtype, (OW,OL,OH) = (L,W,H) / (H,L,W) when rotated (z_up / not), else (W,L,H). */
+int nrpn_ingest_augment(const void *src, int src_is_u8, void *dst, int w, int l, int h, int alpha_mode, int dtype, int rot90,
+                        int z_up, int flip0, int flip1, const float *h_xform, nrpn_stream_t stream);
 /* layout / dtype conversion between the reference's [N,C,X,Y,Z] f32 and channels-last f32|bf16 */
 int nrpn_ncdhw_to_ndhwc(const float *src, void *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
 int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);

@@ -834,6 +834,108 @@ __global__ void ingest_kernel(const S *__restrict__ src, T *__restrict__ dst, lo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ingest + augmentation in one pass (reference datasets.py:109-163, 291-329): the 90-degree rotation and the axis flips are index
+// remaps, rotate_and_scale_scene is a trilinear resample (F.grid_sample, align_corners=True, zero padding) of the scene AFTER
+// density_to_alpha -- so every tap of the interpolation goes through the same load + alpha conversion as the plain ingest.
+// Output voxel (i,j,k) of the augmented grid [OW,OL,OH]:  rotate-scale (optional) -> flips -> rotation -> source voxel (w,l,h).
+// ---------------------------------------------------------------------------------------------------------------------
+struct AugArgs {
+  int W, L, H;          // source grid (on-disk order)
+  int OW, OL, OH;       // augmented grid
+  int rot, z_up;        // rot: 90-degree rotation (z_up: transpose(x,y) + flip x; else transpose(x,z) + flip z)
+  int flip0, flip1;     // flips of axis 0 and of axis 1 (z_up) / 2 (not z_up), applied after the rotation
+  int rs;               // rotate_and_scale_scene active
+  float m[9];           // xform = R(angle) * scale, row-major (datasets.py:294-298)
+};
+
+template <typename S>
+__device__ __forceinline__ f4 aug_fetch(const S *__restrict__ src, const AugArgs &a, int i, int j, int k, int mode) {
+  // undo the flips (they act on the rotated grid [OW,OL,OH]) ...
+  if (a.flip0) i = a.OW - 1 - i;
+  if (a.flip1) { if (a.z_up) j = a.OL - 1 - j; else k = a.OH - 1 - k; }
+  // ... and the rotation: z_up   out[i,j,k] = in[j, L-1-i, k];   else   out[i,j,k] = in[W-1-k, j, i]
+  int w = i, l = j, h = k;
+  if (a.rot) {
+    if (a.z_up) { w = j; l = a.L - 1 - i; h = k; }
+    else { w = a.W - 1 - k; l = j; h = i; }
+  }
+  const long long v = ((long long)w * a.L + l) * a.H + h;
+  float c[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c[q] = sizeof(S) == 1 ? (float)src[v * 4 + q] * (1.0f / 255.0f) : (float)src[v * 4 + q];
+  if (mode == 1) c[3] = fminf(fmaxf(1.0f - expf(-expf(c[3]) / 100.0f), 0.f), 1.f);
+  else if (mode == 2) c[3] = fminf(fmaxf(1.0f - expf(-fmaxf(c[3], 0.f) / 100.0f), 0.f), 1.f);
+  f4 o = {c[0], c[1], c[2], c[3]};
+  return o;
+}
+
+template <typename S, typename T>
+__global__ void ingest_augment_kernel(const S *__restrict__ src, T *__restrict__ dst, AugArgs a, int mode) {
+  const long long total = (long long)a.OW * a.OL * a.OH;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(v % a.OH);
+    const int j = (int)((v / a.OH) % a.OL);
+    const int i = (int)(v / ((long long)a.OH * a.OL));
+    f4 o;
+    if (!a.rs) {
+      o = aug_fetch<S>(src, a, i, j, k, mode);
+    } else {
+      // grid point of the reference: linspace(-1, 1, n)[idx] * n / 2 per axis, times xform^T, normalised by n/2 again
+      const float x = (a.OW > 1 ? -1.0f + (float)i * (2.0f / (float)(a.OW - 1)) : -1.0f) * (float)a.OW / 2;
+      const float y = (a.OL > 1 ? -1.0f + (float)j * (2.0f / (float)(a.OL - 1)) : -1.0f) * (float)a.OL / 2;
+      const float z = (a.OH > 1 ? -1.0f + (float)k * (2.0f / (float)(a.OH - 1)) : -1.0f) * (float)a.OH / 2;
+      const float px = x * a.m[0] + y * a.m[1] + z * a.m[2];
+      const float py = x * a.m[3] + y * a.m[4] + z * a.m[5];
+      const float pz = x * a.m[6] + y * a.m[7] + z * a.m[8];
+      // grid_sample, align_corners=True: index = (g + 1) / 2 * (size - 1)
+      const float fx = ((px / ((float)a.OW / 2)) + 1.f) / 2.f * (float)(a.OW - 1);
+      const float fy = ((py / ((float)a.OL / 2)) + 1.f) / 2.f * (float)(a.OL - 1);
+      const float fz = ((pz / ((float)a.OH / 2)) + 1.f) / 2.f * (float)(a.OH - 1);
+      const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+      const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+      const float wx1 = fx - x0f, wy1 = fy - y0f, wz1 = fz - z0f;
+      const float wx0 = (x0f + 1.f) - fx, wy0 = (y0f + 1.f) - fy, wz0 = (z0f + 1.f) - fz;
+      o = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dz = 0; dz < 2; ++dz) {
+            const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+            if ((unsigned)xi < (unsigned)a.OW && (unsigned)yi < (unsigned)a.OL && (unsigned)zi < (unsigned)a.OH) {
+              const float wgt = (dx ? wx1 : wx0) * (dy ? wy1 : wy0) * (dz ? wz1 : wz0);
+              const f4 t = aug_fetch<S>(src, a, xi, yi, zi, mode);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] += t[q] * wgt;
+            }
+          }
+    }
+    vec4<T>::st(dst + v * 4, o);
+  }
+}
+
+extern "C" int nrpn_ingest_augment(const void *src, int src_is_u8, void *dst, int w, int l, int h, int alpha_mode, int dtype, int rot90,
+                                   int z_up, int flip0, int flip1, const float *h_xform, nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && dst && w > 0 && l > 0 && h > 0 && alpha_mode >= 0 && alpha_mode <= 2, "ingest_augment: bad args");
+  NRPN_REQUIRE(!(src_is_u8 && alpha_mode), "ingest_augment: density_to_alpha on uint8 grids is only available on the host path");
+  AugArgs a{};
+  a.W = w; a.L = l; a.H = h;
+  a.rot = rot90 ? 1 : 0; a.z_up = z_up ? 1 : 0; a.flip0 = flip0 ? 1 : 0; a.flip1 = flip1 ? 1 : 0;
+  if (a.rot) { if (a.z_up) { a.OW = l; a.OL = w; a.OH = h; } else { a.OW = h; a.OL = l; a.OH = w; } }
+  else { a.OW = w; a.OL = l; a.OH = h; }
+  a.rs = h_xform ? 1 : 0;
+  if (h_xform) for (int q = 0; q < 9; ++q) a.m[q] = h_xform[q];
+  const long long total = (long long)w * l * h;
+  const int blocks = (int)min((long long)8192, (total + 255) / 256);
+  hipStream_t st = as_stream(stream);
+  if (src_is_u8) { DISPATCH_T(dtype, hipLaunchKernelGGL((ingest_augment_kernel<unsigned char, T>), dim3(blocks), dim3(256), 0, st, (const unsigned char *)src, (T *)dst, a, alpha_mode)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((ingest_augment_kernel<float, T>), dim3(blocks), dim3(256), 0, st, (const float *)src, (T *)dst, a, alpha_mode)); }
+  NRPN_LAUNCH_CHECK("ingest_augment");
+  return NRPN_OK;
+}
+
 extern "C" int nrpn_ingest_rgbsigma(const void *src, int src_is_u8, void *dst, int64_t voxels, int alpha_mode, int dtype, nrpn_stream_t stream) {
   NRPN_REQUIRE(src && dst && voxels > 0 && alpha_mode >= 0 && alpha_mode <= 2, "ingest_rgbsigma: bad args");
   NRPN_REQUIRE(!(src_is_u8 && alpha_mode), "ingest_rgbsigma: density_to_alpha on uint8 grids follows numpy's float16/uint8 casts in the "

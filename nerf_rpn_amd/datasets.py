@@ -22,18 +22,42 @@ def density_to_alpha_relu(density):
     return np.clip(1.0 - np.exp(-np.clip(density, a_min=0, a_max=None) / 100.0), 0.0, 1.0)
 
 
-class RawScene:
-    """A scene still in its on-disk (W,L,H,4) layout (float32 or uint8), to be finished ON THE DEVICE by
-    ``ops.ingest_rgbsigma`` (uint8 -> /255, density_to_alpha, cast to the compute dtype, channels-last) instead of numpy alpha +
-    host transpose + fp32 conversion.  Produced by datasets built with ``device_ingest=True`` when no augmentation is active."""
-    __slots__ = ("data", "alpha_mode")
+class AugPlan:
+    """One draw of the training augmentation (reference datasets.py:109-163): which of the 90-degree rotation / axis flips /
+    rotate-and-scale apply to a scene.  The host path applies it with torch ops, the device path inside ``nrpn_ingest_augment``."""
+    __slots__ = ("rot90", "flips", "angle", "scale", "z_up")
 
-    def __init__(self, data, alpha_mode):
-        self.data, self.alpha_mode = data, alpha_mode
+    def __init__(self, rot90=False, flips=(False, False), angle=None, scale=None, z_up=True):
+        self.rot90, self.flips, self.angle, self.scale, self.z_up = rot90, tuple(flips), angle, scale, z_up
 
     @property
-    def shape(self):            # the logical [4,W,L,H] shape, so len()/shape based bookkeeping keeps working
-        return torch.Size((4,) + tuple(self.data.shape[:3]))
+    def identity(self):
+        return not (self.rot90 or any(self.flips) or self.angle is not None)
+
+    def xform(self):
+        """R(angle) * scale exactly as the reference builds it (float64 trig -> float32 tensor -> * scale), or None."""
+        if self.angle is None:
+            return None
+        a = self.angle
+        return torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float) * self.scale
+
+
+class RawScene:
+    """A scene still in its on-disk (W,L,H,4) layout (float32 or uint8), to be finished ON THE DEVICE: ``ops.ingest_rgbsigma``
+    (uint8 -> /255, density_to_alpha, cast to the compute dtype, channels-last) or, with an augmentation plan,
+    ``ops.ingest_augment`` (the same plus rotation / flips / rotate-and-scale resampling in the same pass) -- instead of numpy alpha +
+    host transpose + fp32 conversion + torch flips + grid_sample on the host.  Produced by datasets built with ``device_ingest=True``."""
+    __slots__ = ("data", "alpha_mode", "plan")
+
+    def __init__(self, data, alpha_mode, plan=None):
+        self.data, self.alpha_mode, self.plan = data, alpha_mode, plan
+
+    @property
+    def shape(self):            # the logical [4,W,L,H] shape AFTER augmentation, so len()/shape based bookkeeping keeps working
+        w, l, h = (int(v) for v in self.data.shape[:3])
+        if self.plan is not None and self.plan.rot90:
+            w, l, h = (l, w, h) if self.plan.z_up else (h, l, w)
+        return torch.Size((4, w, l, h))
 
     def pin_memory(self):
         self.data = self.data.pin_memory()
@@ -41,7 +65,10 @@ class RawScene:
 
     def to_device(self, dtype=torch.float32):
         from . import ops
-        return ops.ingest_rgbsigma(self.data.cuda(non_blocking=True), self.alpha_mode, dtype)
+        raw = self.data.cuda(non_blocking=True)
+        if self.plan is None or self.plan.identity:
+            return ops.ingest_rgbsigma(raw, self.alpha_mode, dtype)
+        return ops.ingest_augment(raw, self.alpha_mode, dtype, self.plan)
 
 
 def _grid_from_npz(path, normalize_density, raw=False):
@@ -97,8 +124,7 @@ class BaseDataset(torch.utils.data.Dataset):
 
     def load_single_scene(self, scene: str):
         boxes = None if self.boxes_path is None else torch.from_numpy(np.load(os.path.join(self.boxes_path, scene + ".npy")))
-        raw = self.device_ingest and not (self.flip_prob > 0 or self.rotate_prob > 0 or self.rot_scale_prob > 0)
-        return scene, _grid_from_npz(os.path.join(self.features_path, scene + ".npz"), self.normalize_density, raw), boxes
+        return scene, _grid_from_npz(os.path.join(self.features_path, scene + ".npz"), self.normalize_density, self.device_ingest), boxes
 
     def load_scene_data(self, preload: bool = False):
         if self.scene_list is None:
@@ -123,49 +149,83 @@ class BaseDataset(torch.utils.data.Dataset):
             scene = self.scene_list[index]
             _, rgbsigma, boxes = self.load_single_scene(scene)
         if self.flip_prob > 0 or self.rotate_prob > 0 or self.rot_scale_prob > 0:
-            rgbsigma, boxes = self.augment_rpn_inputs(rgbsigma, boxes, self.flip_prob, self.rotate_prob, self.rot_scale_prob, self.z_up)
+            if isinstance(rgbsigma, RawScene):      # device ingest: draw the plan + move the boxes here, the voxels move on the GPU
+                plan, boxes = self.draw_augmentation(rgbsigma.shape[1:], boxes, self.flip_prob, self.rotate_prob, self.rot_scale_prob, self.z_up)
+                rgbsigma = RawScene(rgbsigma.data, rgbsigma.alpha_mode, plan)
+            else:
+                rgbsigma, boxes = self.augment_rpn_inputs(rgbsigma, boxes, self.flip_prob, self.rotate_prob, self.rot_scale_prob, self.z_up)
         return rgbsigma, boxes, scene
 
     def __len__(self) -> int:
         return len(self.scene_list)
 
     @staticmethod
-    def augment_rpn_inputs(rgbsigma: Tensor, boxes: Tensor, flip_prob: float, rotate_prob: float, rot_scale_prob: float,
-                           z_up: bool = True) -> Tuple[Tensor, Tensor]:
-        """90-degree rotation, axis flips, small rotation+scale (datasets.py:109-163); consumes python's ``random``."""
+    def draw_augmentation(shape, boxes, flip_prob: float, rotate_prob: float, rot_scale_prob: float, z_up: bool = True):
+        """Consume python's ``random`` exactly like the reference's augment_rpn_inputs (datasets.py:109-163) and return the drawn
+        ``AugPlan`` together with the transformed boxes; ``shape`` = (W, L, H) of the scene before augmentation."""
         for name, p in (("flip_prob", flip_prob), ("rotate_prob", rotate_prob), ("rotate_and_scale_prob", rot_scale_prob)):
             if p < 0 or p > 1:
                 raise ValueError(f"{name} must be between 0 and 1, but got {p}")
         if boxes is not None:
             assert (z_up and boxes.shape[1] == 7) or boxes.shape[1] == 6, "z_up must be True when boxes are in (x, y, z, w, l, h, t) format"
+        size = [int(v) for v in shape]
+        plan = AugPlan(z_up=z_up)
         if random.random() < rotate_prob:
-            a, b = (1, 2) if z_up else (1, 3)
-            rgbsigma = torch.flip(torch.transpose(rgbsigma, a, b), [a if z_up else 3])
+            plan.rot90 = True
+            size = [size[1], size[0], size[2]] if z_up else [size[2], size[1], size[0]]
             if boxes is not None:
                 boxes = boxes.clone()
                 if boxes.shape[1] == 6:
                     if z_up:
                         boxes[:, [0, 1, 3, 4]] = boxes[:, [1, 0, 4, 3]]
-                        boxes[:, [0, 3]] = rgbsigma.shape[1] - boxes[:, [3, 0]]
+                        boxes[:, [0, 3]] = size[0] - boxes[:, [3, 0]]
                     else:
                         boxes[:, [0, 2, 3, 5]] = boxes[:, [2, 0, 5, 3]]
-                        boxes[:, [2, 5]] = rgbsigma.shape[3] - boxes[:, [5, 2]]
+                        boxes[:, [2, 5]] = size[2] - boxes[:, [5, 2]]
                 else:
                     boxes[:, [0, 1, 3, 4]] = boxes[:, [1, 0, 4, 3]]
-                    boxes[:, 0] = rgbsigma.shape[1] - boxes[:, 0]
-        for axis in ([0, 1] if z_up else [0, 2]):
+                    boxes[:, 0] = size[0] - boxes[:, 0]
+        flips = [False, False]
+        for n, axis in enumerate([0, 1] if z_up else [0, 2]):
             if random.random() < flip_prob:
-                rgbsigma = rgbsigma.flip(dims=[axis + 1])
+                flips[n] = True
                 if boxes is not None:
                     boxes = boxes.clone()
                     if boxes.shape[1] == 6:
-                        boxes[:, [axis, axis + 3]] = rgbsigma.shape[axis + 1] - boxes[:, [axis + 3, axis]]
+                        boxes[:, [axis, axis + 3]] = size[axis] - boxes[:, [axis + 3, axis]]
                     else:
-                        boxes[:, axis] = rgbsigma.shape[axis + 1] - boxes[:, axis]
+                        boxes[:, axis] = size[axis] - boxes[:, axis]
                         boxes[:, -1] = -boxes[:, -1]
+        plan.flips = tuple(flips)
         if boxes is not None and boxes.shape[1] == 7 and random.random() < rot_scale_prob:
-            rgbsigma, boxes = rotate_and_scale_scene(rgbsigma, boxes, random.uniform(-np.pi / 18, np.pi / 18), random.uniform(0.9, 1.1))
-        return rgbsigma, boxes
+            plan.angle, plan.scale = random.uniform(-np.pi / 18, np.pi / 18), random.uniform(0.9, 1.1)
+            xform = plan.xform()
+            boxes = boxes.clone()
+            boxes[:, 6] = boxes[:, 6] - plan.angle
+            boxes[:, 3:6] = boxes[:, 3:6] / plan.scale
+            center = torch.tensor(size).unsqueeze(0) / 2
+            boxes[:, :3] = (boxes[:, :3] - center) @ (xform.to(boxes.dtype) / (plan.scale * plan.scale)) + center
+        return plan, boxes
+
+    @staticmethod
+    def apply_plan_host(rgbsigma: Tensor, plan: "AugPlan") -> Tensor:
+        """The voxel side of an AugPlan with torch ops on the host (the reference's own operations)."""
+        if plan.rot90:
+            a, b = (1, 2) if plan.z_up else (1, 3)
+            rgbsigma = torch.flip(torch.transpose(rgbsigma, a, b), [a if plan.z_up else 3])
+        for on, axis in zip(plan.flips, [0, 1] if plan.z_up else [0, 2]):
+            if on:
+                rgbsigma = rgbsigma.flip(dims=[axis + 1])
+        if plan.angle is not None:
+            rgbsigma, _ = rotate_and_scale_scene(rgbsigma, None, plan.angle, plan.scale)
+        return rgbsigma
+
+    @staticmethod
+    def augment_rpn_inputs(rgbsigma: Tensor, boxes: Tensor, flip_prob: float, rotate_prob: float, rot_scale_prob: float,
+                           z_up: bool = True) -> Tuple[Tensor, Tensor]:
+        """90-degree rotation, axis flips, small rotation+scale (datasets.py:109-163); consumes python's ``random``."""
+        plan, boxes = BaseDataset.draw_augmentation(rgbsigma.shape[1:], boxes, flip_prob, rotate_prob, rot_scale_prob, z_up)
+        return BaseDataset.apply_plan_host(rgbsigma, plan), boxes
 
     @staticmethod
     def collate_fn(batch):

@@ -1221,6 +1221,27 @@ def ingest_rgbsigma(raw, alpha_mode=0, dtype=torch.float32):
     return out.permute(3, 0, 1, 2)
 
 
+def ingest_augment(raw, alpha_mode, dtype, plan):
+    """``ingest_rgbsigma`` + the training augmentation of ``plan`` (datasets.AugPlan) in one pass on the device: 90-degree rotation and
+    flips as index remaps, rotate_and_scale_scene as a trilinear resample (reference datasets.py:109-163, 291-329)."""
+    import ctypes
+    raw = raw.contiguous()
+    _chk(raw)
+    if raw.dim() != 4 or raw.shape[-1] != 4 or raw.dtype not in (torch.float32, torch.uint8):
+        raise lib.NrpnError("ingest_augment expects a (W,L,H,4) float32 or uint8 tensor")
+    w, l, h = (int(v) for v in raw.shape[:3])
+    ow, ol, oh = ((l, w, h) if plan.z_up else (h, l, w)) if plan.rot90 else (w, l, h)
+    out = torch.empty((ow, ol, oh, 4), dtype=dtype, device=raw.device)
+    xf = plan.xform()
+    host, hp = None, 0
+    if xf is not None:
+        host = (ctypes.c_float * 9)(*[float(v) for v in xf.reshape(-1)])
+        hp = ctypes.addressof(host)
+    call("ingest_augment", _p(raw), int(raw.dtype == torch.uint8), _p(out), w, l, h, int(alpha_mode), _dt(out), int(plan.rot90), int(plan.z_up),
+         int(plan.flips[0]), int(plan.flips[1]), hp, _s())
+    return out.permute(3, 0, 1, 2)
+
+
 def stack_scenes(meshes):
     """torch.stack for scene tensors [4,W,L,H]: keeps channels-last memory when every scene has it (no layout round trip)."""
     if all(m.permute(1, 2, 3, 0).is_contiguous() for m in meshes):

@@ -184,11 +184,12 @@ class Trainer:
         aug = dict(flip_prob=a.flip_prob, rotate_prob=a.rotate_prob, rot_scale_prob=a.rot_scale_prob) if augment else {}
         if a.dataset_name in ('hypersim', 'front3d'):
             ds = self.dataset(scene_list=scenes, features_path=a.features_path, boxes_path=a.boxes_path,
-                              normalize_density=a.normalize_density, preload=False if not augment else a.preload, **aug)
-            if not augment:        # evaluation scenes skip the host-side alpha / transpose / float pass (ops.ingest_rgbsigma)
-                ds.device_ingest = True
-                if a.preload:
-                    ds.load_scene_data(preload=True)
+                              normalize_density=a.normalize_density, preload=False, **aug)
+            # scenes stay in their on-disk layout on the host; alpha / layout / dtype -- and for the training set the drawn rotation,
+            # flips and rotate-and-scale resampling -- happen in one pass on the GPU (ops.ingest_rgbsigma / ops.ingest_augment)
+            ds.device_ingest = True
+            if a.preload:
+                ds.load_scene_data(preload=True)
             return ds
         if a.dataset_name == 'scannet':
             return ScanNetRPNDataset(scene_list=scenes, features_path=a.features_path, boxes_path=a.boxes_path, **aug)
