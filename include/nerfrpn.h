@@ -396,6 +396,24 @@ int nrpn_fcos_decode_f32(const int32_t *idx, const float *score, int64_t count, 
                          float min_size, float *boxes, float *out_scores, float *out_levels, nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rotated 3D RoIAlign of the second-stage detector.  [f3]  Replaces the reference's second native op, pybind module rotated_roi_3d:
+ *   roi_align_rotated_3d_forward(input f32[N,C,W,L,H], rois f32[R,8], spatial_scale, pw, pl, ph, sampling_ratio) -> [R,C,pw,pl,ph]
+ *   roi_align_rotated_3d_backward(grad, rois, spatial_scale, pw, pl, ph, N, C, W, L, H, sampling_ratio) -> [N,C,W,L,H]
+ *   (model/rotated_align/src/vision_3d.cpp, cuda_3d/ROIAlignRotated3D_cuda.cu:78-343, roi_align_rotate_3d.py:13-58).
+ *   rois rows = (batch index, cx, cy, cz, w, l, h, theta in DEGREES); sampling_ratio <= 0: ceil(roi extent / pooled extent) samples.
+ * Here: channels-last feature map feat [N][X][Y][Z][C] (dtype), out / grad_out [R][pw][pl][ph][C] (dtype), C % 4 == 0.
+ * The backward accumulates through 64-bit fixed-point integer atomics in `workspace` (nrpn_roi_align_rotated_3d_bwd_workspace_bytes,
+ * zeroed by the call) and converts once: deterministic, unlike the reference's fp32 atomicAdd.
+ * ---------------------------------------------------------------------------------------------- */
+int nrpn_roi_align_rotated_3d_fwd(const void *feat, const float *rois, int num_rois, int n, int x, int y, int z, int c,
+                                  float spatial_scale, int pw, int pl, int ph, int sampling_ratio, void *out, int dtype,
+                                  nrpn_stream_t stream);
+size_t nrpn_roi_align_rotated_3d_bwd_workspace_bytes(int n, int x, int y, int z, int c);
+int nrpn_roi_align_rotated_3d_bwd(const void *grad_out, const float *rois, int num_rois, int n, int x, int y, int z, int c,
+                                  float spatial_scale, int pw, int pl, int ph, int sampling_ratio, void *grad_in, void *workspace,
+                                  int dtype, nrpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 arena.  [a21]  (clip_grad_norm_ + AdamW, run_rpn.py:345-349,390-395)
  *   grad_scale folds the 1/world_size of the data-parallel mean into both kernels (sum all-reduce, no extra pass).
  *   sumsq: f32 device buffer of nrpn_grad_sumsq_floats() elements; [0] = sum((g*grad_scale)^2), the rest is scratch of the

@@ -1221,6 +1221,42 @@ def ingest_rgbsigma(raw, alpha_mode=0, dtype=torch.float32):
     return out.permute(3, 0, 1, 2)
 
 
+def as_channels_last(x):
+    """Logical [N,C,X,Y,Z] (fp32 / bf16) -> channels-last tensor [N,X,Y,Z,C]: a free view when the memory already is channels-last
+    (what the HIP backbones return), one conversion kernel otherwise."""
+    cl = x.permute(0, 2, 3, 4, 1)
+    if cl.is_contiguous():
+        return cl
+    if x.dtype == torch.float32 or x.dtype == torch.bfloat16:
+        return to_channels_last(x.float(), x.dtype)
+    raise lib.NrpnError(f"unsupported dtype {x.dtype}")
+
+
+def roi_align_rotated_3d_fwd(feat_cl, rois, spatial_scale, output_size, sampling_ratio):
+    """feat_cl [N,X,Y,Z,C], rois f32 [R,8] -> [R,pw,pl,ph,C] in feat's dtype (reference ROIAlignRotated3D_cuda.cu:78-170)."""
+    feat_cl, rois = feat_cl.contiguous(), _f32(rois).contiguous()
+    _chk(feat_cl, rois)
+    n, x, y, z, c = feat_cl.shape
+    pw, pl, ph = output_size
+    out = torch.empty((rois.shape[0], pw, pl, ph, c), dtype=feat_cl.dtype, device=feat_cl.device)
+    call("roi_align_rotated_3d_fwd", _p(feat_cl), _p(rois), rois.shape[0], n, x, y, z, c, float(spatial_scale), pw, pl, ph, int(sampling_ratio),
+         _p(out), _dt(feat_cl), _s())
+    return out
+
+
+def roi_align_rotated_3d_bwd(grad_cl, rois, feat_shape, spatial_scale, output_size, sampling_ratio):
+    """grad_cl [R,pw,pl,ph,C] -> gradient of the feature map [N,X,Y,Z,C] (deterministic fixed-point accumulation)."""
+    grad_cl, rois = grad_cl.contiguous(), _f32(rois).contiguous()
+    _chk(grad_cl, rois)
+    n, x, y, z, c = feat_shape
+    pw, pl, ph = output_size
+    gi = torch.empty(feat_shape, dtype=grad_cl.dtype, device=grad_cl.device)
+    ws = torch.empty(query("roi_align_rotated_3d_bwd_workspace_bytes", n, x, y, z, c), dtype=torch.uint8, device=grad_cl.device)
+    call("roi_align_rotated_3d_bwd", _p(grad_cl), _p(rois), rois.shape[0], n, x, y, z, c, float(spatial_scale), pw, pl, ph, int(sampling_ratio),
+         _p(gi), _p(ws), _dt(grad_cl), _s())
+    return gi
+
+
 def ingest_augment(raw, alpha_mode, dtype, plan):
     """``ingest_rgbsigma`` + the training augmentation of ``plan`` (datasets.AugPlan) in one pass on the device: 90-degree rotation and
     flips as index remaps, rotate_and_scale_scene as a trilinear resample (reference datasets.py:109-163, 291-329)."""
