@@ -66,13 +66,19 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
     ref = build(True, 160, dev).train()
     ref.set_compute_dtype(dtype)
     opt = torch.optim.AdamW(ref.parameters(), lr=lr, weight_decay=0.01)
+    # conv biases that feed a train-mode BatchNorm have an exactly-zero gradient in exact arithmetic: what both implementations see is
+    # rounding noise, which Adam turns into +-lr steps of arbitrary sign -- those tensors are excluded from the weight comparison
+    mods = dict(ref.named_modules())
+    dead = {name for name, _ in ref.named_parameters()
+            if name.startswith("backbone.layers") and name.endswith(".bias") and isinstance(mods[name.rsplit(".", 1)[0]], torch.nn.Conv3d)}
+    assert len(dead) == 17
     ref_losses, sig = [], None
     for _ in range(steps):
         opt.zero_grad(set_to_none=True)
         loss = _loss(ref, xs, gts, pos, neg)
         loss.backward()
         # entries whose gradient is well above their tensor's rounding noise on EVERY step (see the weight comparison below)
-        step_sig = torch.cat([(p.grad.abs() > 1e-2 * p.grad.abs().max()).reshape(-1) for p in ref.parameters()])
+        step_sig = torch.cat([((p.grad.abs() > 1e-2 * p.grad.abs().max()) & (name not in dead)).reshape(-1) for name, p in ref.named_parameters()])
         sig = step_sig if sig is None else (sig & step_sig)
         torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
         opt.step()
@@ -99,7 +105,7 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
     with torch.no_grad():
         final = _loss(m, xs, gts, pos, neg).item()
     # the optimiser must visibly move the loss (a forward on stale weights would reproduce losses[0] exactly) ...
-    assert abs(ref_final - ref_losses[0]) > 0.2 * abs(ref_losses[0]), (ref_losses, ref_final)
+    assert max(abs(v - ref_losses[0]) for v in ref_losses[1:] + [ref_final]) > 0.1 * abs(ref_losses[0]), (ref_losses, ref_final)
     # ... and both trainers must follow the same trajectory.  fp32: identical gradients (deterministic kernels), the only difference
     # is the rounding of the AdamW formula; bf16 adds re-rounding of the updated weights.
     tol = 2e-3 if dtype == torch.float32 else 5e-2
