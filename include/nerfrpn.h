@@ -194,8 +194,11 @@ int nrpn_unpack_conv_wgrad(const float *gw_packed, int cout, int cin, int taps, 
  * K slices whose fp32 partials are stored to it and summed in slice order (deterministic, no atomics) so the 10^3 / 5^3
  * pyramid levels still fill 256 CUs. */
 size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
+/* relu_mask (optional, [N*X*Y*Z][Cout] in x's dtype): outputs are zeroed where relu_mask <= 0 -- used by dgrad launches whose input
+ * gradient feeds a fused conv+ReLU layer: the ReLU backward of that layer costs no extra pass (mask = that layer's activations). */
 int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
-                    int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream);
+                    int cout, int wrows, int ksize, int dtype, int flags, void *workspace, const void *relu_mask,
+                    nrpn_stream_t stream);
 /* wgrad: the voxel axis is cut into S = nrpn_conv3d_wgrad_slices(...) slices; every (tile, tap, slice) workgroup writes
  * its partial with plain stores into gw_packed f32 [S][taps][wrows][Cin] (fully overwritten: no memset, no atomics --
  * cross-XCD fp32 atomics were ~1/3 of the kernel time); nrpn_unpack_conv_wgrad sums the slices.
@@ -243,8 +246,11 @@ int nrpn_stem_kpad(int dtype);
 int nrpn_pack_stem_weight(const float *w_ref, int cout, int dtype, void *wp, nrpn_stream_t stream);
 /* stem wgrad writes S = nrpn_stem_wgrad_slices(...) partials [S][Cout][Kpad]; the unpack sums them */
 int nrpn_stem_wgrad_slices(int n, int gx, int gy, int gz, int cout, int stride, int dtype);
+/* floats of one slice partial: [Cout][Kpad], or -- stride 2, even Z, Cout 64: the "z-row" kernel, 49 GEMMs over contiguous 8-z x 4-c
+ * input runs instead of an im2col gather -- [49][Cout][32]; pass it to the unpack so it knows the layout */
+int64_t nrpn_stem_wgrad_slice_floats(int n, int gx, int gy, int gz, int cout, int stride, int dtype);
 int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *gw_ref, int accumulate, int slices,
-                           nrpn_stream_t stream);
+                           int64_t slice_floats, nrpn_stream_t stream);
 int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz,
                          int cout, int stride, int dtype, int flags, nrpn_stream_t stream);
 size_t nrpn_stem_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cout, int stride, int dtype);

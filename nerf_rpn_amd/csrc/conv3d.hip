@@ -121,6 +121,7 @@ struct ConvArgs {
   const void *x;
   const void *w;      // MODE 0: [taps][wrows][Cin];  MODE 1 (stem): [wrows][Kpad], k = tap*4 + c
   const float *bias;
+  const void *mask;   // optional [M][Cout] (dtype of x): outputs are zeroed where mask <= 0 (ReLU backward of the tensor this dgrad feeds)
   void *y;
   long long M;        // output voxels (N * OX * OY * OZ)
   int X, Y, Z;        // input grid
@@ -431,6 +432,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
         if (v < p.M) {
           float o = acc[i][j][r] + bv;
           if (relu) o = fmaxf(o, 0.f);
+          if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
           if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
           else elem<T>::st(reinterpret_cast<T *>(p.y) + v * p.Cout + col, o);
         }
@@ -615,6 +617,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_ws_kernel(const ConvArgs p)
         if (v < p.M) {
           float o = acc[i][j][r] + bv;
           if (relu) o = fmaxf(o, 0.f);
+          if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
           if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
           else elem<T>::st(reinterpret_cast<T *>(p.y) + v * p.Cout + col, o);
         }
@@ -821,6 +824,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
         if (v < p.M) {
           float o = acc[i][j][r] + bv;
           if (relu) o = fmaxf(o, 0.f);
+          if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
           if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
           else elem<T>::st(reinterpret_cast<T *>(p.y) + v * p.Cout + col, o);
         }
@@ -831,12 +835,13 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
 
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
-                                       int cout, int relu, int nslices) {
+                                       int cout, int relu, int nslices, const T *__restrict__ mask) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     float o = ws[i];
     for (int z = 1; z < nslices; ++z) o += ws[z * total + i];
     o += bias ? bias[i % cout] : 0.f;
     if (relu) o = fmaxf(o, 0.f);
+    if (mask && !(elem<T>::ld(mask + i) > 0.f)) o = 0.f;
     if (OUTF32) reinterpret_cast<float *>(y)[i] = o;
     else elem<T>::st(reinterpret_cast<T *>(y) + i, o);
   }
@@ -973,7 +978,7 @@ extern "C" int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int 
   return 0;
 }
 
-static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, void *y, long long M, int gx, int gy, int gz, const Segs *segs,
+static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, const void *mask, void *y, long long M, int gx, int gy, int gz, const Segs *segs,
                            int cin, int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_fwd: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_fwd: bad dtype %d", dtype);
@@ -982,7 +987,7 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, voi
   NRPN_REQUIRE((cin * es) % 64 == 0, "conv3d_fwd: Cin*elemsize must be a multiple of 64 bytes (Cin=%d)", cin);
   NRPN_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
   ConvArgs a{};
-  a.x = x; a.w = wp; a.bias = bias; a.y = y;
+  a.x = x; a.w = wp; a.bias = bias; a.mask = mask; a.y = y;
   a.M = M;
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // classic layout: the kernel splits v into (batch, x, y, z) with these
   if (segs) a.segs = *segs;
@@ -1008,20 +1013,22 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, voi
   const float *b = (flags & NRPN_CONV_BIAS) ? bias : nullptr;
   const int relu = (flags & NRPN_CONV_RELU) ? 1 : 0;
   if (dtype == NRPN_F32 || out_f32) {
-    if (dtype == NRPN_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl);
-    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl);
+    if (dtype == NRPN_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const float *)a.mask);
+    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)a.mask);
   } else {
-    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)a.mask);
   }
   NRPN_LAUNCH_CHECK("splitk_epilogue");
   return NRPN_OK;
 }
 
 extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
-                               int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
+                               int cout, int wrows, int ksize, int dtype, int flags, void *workspace, const void *relu_mask,
+                               nrpn_stream_t stream) {
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0, "conv3d_fwd: bad sizes");
-  return conv3d_fwd_impl(x, wp, bias, y, (long long)n * gx * gy * gz, gx, gy, gz, nullptr, cin, cout, wrows, ksize, dtype, flags, workspace,
-                         stream);
+  NRPN_REQUIRE(!relu_mask || !(flags & NRPN_CONV_OUT_F32) || dtype == NRPN_F32, "conv3d_fwd: relu_mask needs outputs in the input dtype");
+  return conv3d_fwd_impl(x, wp, bias, relu_mask, y, (long long)n * gx * gy * gz, gx, gy, gz, nullptr, cin, cout, wrows, ksize, dtype, flags,
+                         workspace, stream);
 }
 
 extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, void *y, int nseg, const int32_t *dims, int cin,
@@ -1029,7 +1036,7 @@ extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float
   Segs sg{};
   long long M = 0;
   if (int rc = fill_segs(sg, nseg, dims, M)) return rc;
-  return conv3d_fwd_impl(x, wp, bias, y, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, flags, workspace, stream);
+  return conv3d_fwd_impl(x, wp, bias, nullptr, y, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, flags, workspace, stream);
 }
 
 extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
@@ -1544,6 +1551,227 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem wgrad, stride 2, even Z ("z-row" form).  For a fixed (dx, dy) the 7 dz taps x 4 channels of the stem's 7^3 window are 28
+// CONTIGUOUS elements of the input row (z fastest, then channel), and with stride 2 the row of output voxel oz starts at the even
+// z = 2 oz - 4 when one unused leading z position is included: 8 z x 4 c = 32 elements = one 64-byte (bf16) / 128-byte (fp32)
+// run that LDS-DMA can stage like an ordinary channel row.  The wgrad becomes 49 independent GEMMs
+//     dWz[(dx,dy)][cout][zrel*4 + c] = sum_v dY[v][cout] * X[n, 2ox-3+dx, 2oy-3+dy, 2oz-4+zrel, c]        (zrel = dz + 1; zrel 0 unused)
+// with M = Cout = 64, N = 32, K = voxels -- the structure of conv_wgrad_kernel (LDS tiles [voxel][channel], transpose reads), instead
+// of an im2col gather of 8-byte pieces with per-piece tap decoding (the old path: 141 TFLOP/s, half of its 128-row M tile empty).
+// Workgroup = (dx, voxel slice): the dY tile of a chunk is staged once and shared by the 7 dy taps, wave w owns taps {w, w+4}.
+// Whole 16-byte pieces are either inside the grid or entirely outside (Z even => z pairs never straddle the border), so border
+// handling is the buffer descriptor's zero fill.  Partials: gw[slice][dx*7+dy][cout][32] (plain stores), summed by the unpack.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct ZrCfg;
+template <> struct ZrCfg<bf16s> { static constexpr int KV = 64, RSA = 64 * 2, RSB = 32 * 2, KSUB = 16; };
+template <> struct ZrCfg<float> { static constexpr int KV = 32, RSA = 64 * 4, RSB = 32 * 4, KSUB = 8; };
+
+// 16-byte-slot swizzle of a [voxel][channel] tile with RS-byte rows: keeps the rows one transpose-read group touches on distinct banks
+template <int RS> __device__ __forceinline__ int zr_swz(int row) {
+  if (RS >= 256) return (row & 3) << 2;
+  if (RS == 128) return ((row >> 1) & 1) << 2;
+  return 0;
+}
+template <int RS> __device__ __forceinline__ int zr_off(int row, int byte_in_row) {
+  return row * RS + ((((byte_in_row >> 4) ^ zr_swz<RS>(row))) << 4) + (byte_in_row & 15);
+}
+
+// 32(channel) x 16-byte K fragment out of a [voxel][channel] tile with RS-byte rows (cf. wg_frag)
+template <typename T, int RS>
+__device__ __forceinline__ f4 zr_frag(const char *tile, int ctile0, int kbase, int lane) {
+  const int h = lane >> 5;
+  if (sizeof(T) == 4) {
+    const int c = ctile0 + (lane & 31);
+    f4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float *>(tile + zr_off<RS>(kbase + 4 * h + q, c * 4));
+    return v;
+  } else {
+    const int p = lane & 15;
+    const int cbase = ctile0 + 16 * ((lane >> 4) & 1);
+    const int row = kbase + 8 * h + (p >> 2);              // row + 4 has the same swizzle term: one offset serves both reads
+    const char *a0 = tile + zr_off<RS>(row, (cbase + 4 * (p & 3)) * 2);
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3))) *)(a0 + 4 * RS));
+    typedef __attribute__((ext_vector_type(2))) long long l2v;
+    l2v r = {__builtin_bit_cast(long long, lo), __builtin_bit_cast(long long, hi)};
+    return __builtin_bit_cast(f4, r);
+  }
+}
+
+struct StemZrArgs {
+  const void *x, *dy;
+  float *gw;            // [slices][49][64][32]
+  float *gbias;         // optional per-slice bias partials [slices][64]
+  long long M;          // output voxels
+  int X, Y, Z, OX, OY, OZ;
+  int slices;
+  unsigned x_bytes, dy_bytes;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) stem_wgrad_zrow_kernel(const StemZrArgs p) {
+  constexpr int KV = ZrCfg<T>::KV, RSA = ZrCfg<T>::RSA, RSB = ZrCfg<T>::RSB, KSUB = ZrCfg<T>::KSUB;
+  constexpr int COUT = 64;
+  constexpr int A_BYTES = KV * RSA, B_BYTES = KV * RSB, BUF = A_BYTES + 7 * B_BYTES;
+  constexpr int APR = RSA / 16, BPR = RSB / 16;                 // 16-byte pieces per row: 8 / 4 (bf16), 16 / 8 (fp32)
+  constexpr int A_PIECES = KV * APR / 256;                      // per lane per chunk: 2
+  static_assert(KV * BPR == 256, "one LDS-DMA instruction per tap");
+  extern __shared__ __attribute__((aligned(16))) char lds[];    // [2 buffers][dY tile | 7 X-row tiles]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dx = blockIdx.x % 7, slice = blockIdx.x / 7;
+  const long long chunks = (p.M + KV - 1) / KV;
+  const long long per = (chunks + p.slices - 1) / p.slices;
+  const long long c_begin = slice * per, c_end = min(chunks, c_begin + per);
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // A (dY) pieces of this lane: physical slot tid % APR of rows tid / APR + (256 / APR) * i, holding logical slot (slot ^ swz(row))
+  unsigned a_voff[A_PIECES];
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int pc = tid + 256 * i, row = pc / APR, slot = (pc % APR) ^ zr_swz<RSA>(row);
+    a_voff[i] = (unsigned)(((c_begin * KV + row) * COUT) * (long long)sizeof(T)) + slot * 16;
+  }
+  const unsigned a_step = (unsigned)(KV * COUT * (int)sizeof(T));
+  const int b_row = tid / BPR, b_slot = (tid % BPR) ^ zr_swz<RSB>(tid / BPR);   // X-row piece of this lane (logical slot; the same for every dy tap)
+  constexpr int ZPP = 16 / (4 * (int)sizeof(T));                // z positions per 16-byte piece: 2 (bf16) / 1 (fp32)
+
+  auto issue = [&](int buf, long long ch) {
+    char *A = lds + buf * BUF;
+    char *B = A + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const long long v = ch * KV + (tid + 256 * i) / APR;
+      lds_dma16(dyr, A + (64 * wave_u + 256 * i) * 16, v < p.M ? a_voff[i] : kOOB);
+      a_voff[i] += a_step;
+    }
+    const long long v = ch * KV + b_row;
+    const bool vok = v < p.M;
+    const long long vv = vok ? v : 0;
+    const int oz = (int)(vv % p.OZ);
+    const long long t1 = vv / p.OZ;
+    const int oy = (int)(t1 % p.OY);
+    const long long t2 = t1 / p.OY;
+    const int ox = (int)(t2 % p.OX);
+    const long long nb = t2 / p.OX;
+    const int ix = 2 * ox - 3 + dx;
+    const int zp = 2 * oz - 4 + b_slot * ZPP;                   // first z of this piece (ZPP z positions, never straddling the border: Z even)
+    const bool ok0 = vok && (unsigned)ix < (unsigned)p.X && zp >= 0 && zp + ZPP <= p.Z;
+    const long long rowbase = ((nb * p.X + ix) * p.Y) * (long long)p.Z;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int iy = 2 * oy - 3 + t;
+      const bool ok = ok0 && (unsigned)iy < (unsigned)p.Y;
+      const unsigned off = ok ? (unsigned)(((rowbase + (long long)iy * p.Z + zp) * 4) * (long long)sizeof(T)) : kOOB;
+      lds_dma16(xr, B + t * B_BYTES + 64 * wave_u * 16, off);
+    }
+  };
+
+  const int wm_tiles = 2;                                        // 64 couts = 2 row tiles of 32
+  const int t0 = wave, t1 = wave + 4;                            // dy taps of this wave (t1 < 7 for waves 0..2)
+  const bool two = t1 < 7;
+  f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool do_bias = p.gbias != nullptr && dx == 0;
+  float bias_acc[16 / (int)sizeof(T)];
+#pragma unroll
+  for (int e = 0; e < 16 / (int)sizeof(T); ++e) bias_acc[e] = 0.f;
+
+  if (c_begin < c_end) issue(0, c_begin);
+  __syncthreads();
+  int buf = 0;
+  for (long long ch = c_begin; ch < c_end; ++ch) {
+    if (ch + 1 < c_end) issue(buf ^ 1, ch + 1);
+    const char *A = lds + buf * BUF;
+    const char *B = A + A_BYTES;
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i) {
+        const f4 v = *reinterpret_cast<const f4 *>(A + (tid + 256 * i) * 16);      // this lane's own piece (physical slot order)
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bias_acc[e] += v[e];
+        } else {
+          typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+          const u8v hh = __builtin_bit_cast(u8v, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bias_acc[e] += bf16_bits_to_f32(hh[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KV; kb += KSUB) {
+      f4 af[2], bf0, bf1;
+#pragma unroll
+      for (int i = 0; i < wm_tiles; ++i) af[i] = zr_frag<T, RSA>(A, i * 32, kb, lane);
+      bf0 = zr_frag<T, RSB>(B + t0 * B_BYTES, 0, kb, lane);
+      if (two) bf1 = zr_frag<T, RSB>(B + t1 * B_BYTES, 0, kb, lane);
+#pragma unroll
+      for (int i = 0; i < wm_tiles; ++i) {
+        Mma<T>::run(acc[i][0], af[i], bf0);
+        if (two) Mma<T>::run(acc[i][1], af[i], bf1);
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (do_bias) {   // thread t summed logical slot (t % APR) ^ swz(row) of rows t / APR + k * (256 / APR); reduce the row groups through LDS
+    constexpr int EPP = 16 / (int)sizeof(T), NRG = 256 / APR;
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) red[tid * EPP + e] = bias_acc[e];
+    __syncthreads();
+    if (tid < COUT) {
+      const int g = tid / EPP, e = tid % EPP;
+      float sum = 0.f;
+      for (int rg = 0; rg < NRG; ++rg) sum += red[(rg * APR + (g ^ zr_swz<RSA>(rg))) * EPP + e];
+      p.gbias[(long long)slice * COUT + tid] = sum;
+    }
+  }
+  const int fr = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j == 1 && !two) continue;
+    const int tap = dx * 7 + (j == 0 ? t0 : t1);
+    float *dst = p.gw + ((long long)slice * 49 + tap) * COUT * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(i * 32 + frag_row(r, lane)) * 32 + fr] = acc[i][j][r];
+  }
+}
+
+// z-row partials [slices][49][cout][32] -> reference layout [cout][4][7][7][7] (summed over the slices; zrel 0 is the unused position)
+__global__ void unpack_stem_zrow_kernel(const float *__restrict__ gp, int cout, float *__restrict__ gw, int accumulate, int slices) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)cout * 4 * 343) return;
+  const int tap = (int)(i % 343), c = (int)((i / 343) % 4), o = (int)(i / (343 * 4));
+  const int dz = tap % 7, dxy = tap / 7;
+  const float *src = gp + ((long long)dxy * cout + o) * 32 + (dz + 1) * 4 + c;
+  float v = 0.f;
+  for (int s = 0; s < slices; ++s) v += src[(long long)s * 49 * cout * 32];
+  gw[i] = accumulate ? gw[i] + v : v;
+}
+
+static bool stem_zrow_ok(int gz, int cout, int stride) { return stride == 2 && gz % 2 == 0 && cout == 64; }
+static int stem_zrow_slices(long long M, int elem_bytes) {
+  const long long chunks = (M + (elem_bytes == 2 ? 64 : 32) - 1) / (elem_bytes == 2 ? 64 : 32);
+  long long s = 73;                                   // 7 dx x 73 slices = 511 workgroups = two per CU
+  if (s > chunks / 8) s = chunks / 8;
+  if (s < 1) s = 1;
+  const long long per = (chunks + s - 1) / s;
+  return (int)((chunks + per - 1) / per);             // no empty slice
+}
+
 // bias gradient = ordered sum of the per-slice column sums the wgrad workgroups left in the workspace
 __global__ void bias_finalize_kernel(const float *__restrict__ part, int slices, int wrows, int cout, float *__restrict__ gbias, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1725,7 +1953,14 @@ static long long stem_out_voxels(int n, int gx, int gy, int gz, int stride) {
 }
 
 extern "C" int nrpn_stem_wgrad_slices(int n, int gx, int gy, int gz, int cout, int stride, int dtype) {
+  if (stem_zrow_ok(gz, cout, stride)) return stem_zrow_slices(stem_out_voxels(n, gx, gy, gz, stride), dtype == NRPN_F32 ? 4 : 2);
   return wgrad_plan(stem_out_voxels(n, gx, gy, gz, stride), cout, nrpn_stem_kpad(dtype), 1, dtype == NRPN_F32 ? 4 : 2, 1, cout, 4).ksplit;
+}
+
+// floats of ONE slice partial: z-row form [49][cout][32] (stride 2, even Z, Cout 64), otherwise [cout][Kpad]
+extern "C" int64_t nrpn_stem_wgrad_slice_floats(int n, int gx, int gy, int gz, int cout, int stride, int dtype) {
+  (void)n; (void)gx; (void)gy;
+  return stem_zrow_ok(gz, cout, stride) ? (int64_t)49 * cout * 32 : (int64_t)cout * nrpn_stem_kpad(dtype);
 }
 
 extern "C" size_t nrpn_stem_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cout, int stride, int dtype) {
@@ -1754,6 +1989,28 @@ extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_p
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db; a.vmask = nullptr;
   }
   NRPN_REQUIRE(!gbias || workspace, "stem wgrad: the bias gradient needs the workspace (nrpn_stem_wgrad_workspace_bytes)");
+  if (stem_zrow_ok(gz, cout, stride)) {
+    StemZrArgs z{};
+    z.x = x; z.dy = dy; z.gw = gw_packed; z.gbias = gbias ? reinterpret_cast<float *>(workspace) : nullptr;
+    z.M = a.M; z.X = gx; z.Y = gy; z.Z = gz; z.OX = a.OX; z.OY = a.OY; z.OZ = a.OZ;
+    z.slices = stem_zrow_slices(a.M, es);
+    z.x_bytes = a.x_bytes; z.dy_bytes = a.dy_bytes;
+    const dim3 grid((unsigned)(7 * z.slices));
+    if (dtype == NRPN_F32) {
+      constexpr size_t lds_ = 2 * (size_t)(ZrCfg<float>::KV * ZrCfg<float>::RSA + 7 * ZrCfg<float>::KV * ZrCfg<float>::RSB);
+      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_zrow_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+      hipLaunchKernelGGL(stem_wgrad_zrow_kernel<float>, grid, dim3(256), lds_, st, z);
+    } else {
+      constexpr size_t lds_ = 2 * (size_t)(ZrCfg<bf16s>::KV * ZrCfg<bf16s>::RSA + 7 * ZrCfg<bf16s>::KV * ZrCfg<bf16s>::RSB);
+      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_zrow_kernel<bf16s>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+      hipLaunchKernelGGL(stem_wgrad_zrow_kernel<bf16s>, grid, dim3(256), lds_, st, z);
+    }
+    NRPN_LAUNCH_CHECK("stem_wgrad_zrow");
+    if (!gbias) return NRPN_OK;
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3(1), dim3(256), 0, st, z.gbias, z.slices, cout, cout, gbias, accumulate_bias);
+    NRPN_LAUNCH_CHECK("bias_finalize");
+    return NRPN_OK;
+  }
   a.gbias = gbias ? reinterpret_cast<float *>(workspace) : nullptr;
   a.ksplit = wgrad_plan(a.M, cout, a.kpad, 1, es, 1, cout, 4).ksplit;
   a.slice_stride = (long long)cout * a.kpad;
@@ -1867,8 +2124,14 @@ __global__ void unpack_stem_wgrad_kernel(const float *__restrict__ gp, int cout,
 }
 
 extern "C" int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *gw_ref, int accumulate, int slices,
-                                      nrpn_stream_t stream) {
+                                      int64_t slice_floats, nrpn_stream_t stream) {
   NRPN_REQUIRE(gw_packed && gw_ref && cout > 0 && slices > 0, "unpack_stem_wgrad: bad args");
+  if (slice_floats == (int64_t)49 * cout * 32) {     // z-row partials (nrpn_stem_wgrad_slice_floats)
+    hipLaunchKernelGGL(unpack_stem_zrow_kernel, dim3((unsigned)cdiv64((long long)cout * 4 * 343, 256)), dim3(256), 0, as_stream(stream), gw_packed,
+                       cout, gw_ref, accumulate, slices);
+    NRPN_LAUNCH_CHECK("unpack_stem_zrow");
+    return NRPN_OK;
+  }
   const int kpad = nrpn_stem_kpad(dtype);
   hipLaunchKernelGGL(unpack_stem_wgrad_kernel, dim3((unsigned)cdiv64((long long)cout * 4 * 343, 256)), dim3(256), 0, as_stream(stream),
                      gw_packed, cout, kpad, gw_ref, accumulate, slices);

@@ -102,10 +102,16 @@ class RPNHead(nn.Module):
                                  self.cls_logits.bias, self.bbox_pred.bias)
             return [out0] + hip_nn.ragged_split(h, feats_cl[1:])
         outs = []
+        convs = [m for m in self.conv if isinstance(m, nn.Conv3d)]
         for f in feats_cl:
-            t = hip_nn.run_modules(self.conv, f)
-            outs.append(ops.ConvFn.apply(t, self._pack, self.head_rows, False, True, 2, self.cls_logits.weight, self.bbox_pred.weight,
-                                         self.cls_logits.bias, self.bbox_pred.bias))
+            # conv+ReLU chain private to the head: every intermediate has exactly one consumer, so each layer's ReLU backward rides
+            # in the epilogue of the next layer's dgrad (ops.CHAIN_*) -- no separate relu_backward launches
+            t = f
+            for i, cv in enumerate(convs):
+                chain = ops.CHAIN_GRAD_PREMASKED | (ops.CHAIN_MASK_INPUT_GRAD if i > 0 else 0)
+                t = hip_nn.conv3d(cv, t, relu=True, chain=chain)
+            outs.append(ops.ConvFn.apply(t, self._pack, self.head_rows, (False, ops.CHAIN_MASK_INPUT_GRAD), True, 2, self.cls_logits.weight,
+                                         self.bbox_pred.weight, self.cls_logits.bias, self.bbox_pred.bias))
         return outs
 
     def forward(self, x: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:

@@ -16,7 +16,7 @@ def _pack_of(mod):
     return pk
 
 
-def conv3d(mod, x, relu=False, out_f32=False, segs=None):
+def conv3d(mod, x, relu=False, out_f32=False, segs=None, chain=0):
     """nn.Conv3d (k 1|3, stride 1, same padding; or the 4-channel k7 stem) on a channels-last tensor.
     ``segs``: x is a ragged list [1, sum voxels, 1, 1, C] of grids with these (X, Y, Z) dims (see ``ragged_cat``)."""
     k = mod.kernel_size[0]
@@ -34,7 +34,8 @@ def conv3d(mod, x, relu=False, out_f32=False, segs=None):
         raise NotImplementedError(f"Conv3d k={k} stride={mod.stride} padding={mod.padding} has no HIP kernel yet")
     if segs is not None and (k == 7 or mod.stride[0] != 1):
         raise NotImplementedError("ragged voxel lists are supported by the stride-1 k1 / k3 convolutions only")
-    return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, relu, out_f32, 1 if segs is None else (1, tuple(segs)), mod.weight, mod.bias)
+    return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, (relu, chain) if chain else relu, out_f32, 1 if segs is None else (1, tuple(segs)),
+                            mod.weight, mod.bias)
 
 
 def ragged_cat(feats):

@@ -516,7 +516,7 @@ def _seg_dims(segs):
     return (ctypes.c_int32 * len(flat))(*flat)
 
 
-def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None):
+def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask=None):
     """segs: None, or the (X, Y, Z) dims of the grids laid end to end in x = [1, sum(X*Y*Z), 1, 1, C] (ragged list)."""
     import ctypes
     n, gx, gy, gz, cin = x.shape
@@ -528,7 +528,7 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None):
     wsb = query("conv3d_fwd_workspace_bytes", n, gx, gy, gz, cin, cout, ksize, _dt(x))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if segs is None or ksize == 1:
-        call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), _s())
+        call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), _p(mask), _s())
     else:
         dims = _seg_dims(segs)
         call("conv3d_fwd_ragged", _p(x), _p(wp), _p(bias), _p(y), len(segs), ctypes.addressof(dims), cin, cout, wrows, ksize, _dt(x), flags,
@@ -552,6 +552,13 @@ def _wgrad_workspace(device, key, nbytes):
     return ent[0], ready
 
 
+# Layer-chain hints for ConvFn (passed as relu=(bool, flags) by modules that own a conv+ReLU -> conv chain, e.g. RPNHead):
+#   CHAIN_MASK_INPUT_GRAD  this conv is the ONLY consumer of its input, and the input is the output of a fused conv+ReLU
+#   CHAIN_GRAD_PREMASKED   this conv+ReLU's output goes only to a conv with CHAIN_MASK_INPUT_GRAD: the incoming gradient is
+#                          already multiplied by the ReLU mask, so the separate relu_backward pass is skipped
+CHAIN_MASK_INPUT_GRAD, CHAIN_GRAD_PREMASKED = 1, 2
+
+
 class ConvFn(torch.autograd.Function):
     """Conv3d k in {1,3}, stride 1, 'same' padding, channels-last, optional fused bias + ReLU.
     ``weights``: one or more reference-layout parameters that share the GEMM (their rows are concatenated, then padded to
@@ -560,6 +567,9 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pack, rows_total, relu, out_f32, nw, *wb):
         segs = None
+        chain = 0
+        if isinstance(relu, tuple):        # (relu, chain): see CHAIN_* below
+            relu, chain = relu
         if isinstance(nw, tuple):          # (nw, segs): ragged voxel list, x = [1, sum voxels, 1, 1, C]
             nw, segs = nw
         weights, biases = wb[:nw], wb[nw:]
@@ -575,26 +585,29 @@ class ConvFn(torch.autograd.Function):
         out_dtype = torch.float32 if out_f32 else x.dtype
         y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs)
         ctx.save_for_backward(x, y if relu else None, wpd, *weights)
-        ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None, segs)
+        ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None, segs, chain)
         ctx.sinks = ([_sink(w) for w in weights], [_sink(b) for b in biases])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, wpd, *weights = ctx.saved_tensors
-        rows_total, relu, nw, ksize, has_bias, segs = ctx.meta
+        rows_total, relu, nw, ksize, has_bias, segs, chain = ctx.meta
         n, gx, gy, gz, cin = x.shape
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        if relu:
+        if relu and not (chain & CHAIN_GRAD_PREMASKED):
             dyr = torch.empty_like(dy)
             yy = y if y.dtype == dy.dtype else y.to(dy.dtype)
             call("relu_backward", _p(yy), _p(dy), _p(dyr), dy.numel(), _dt(dy), _s())
             dy = dyr
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype, segs)
+            # CHAIN_MASK_INPUT_GRAD: x is the ReLU output of the layer that receives dx and this conv is its only consumer, so that
+            # layer's ReLU backward is applied in this dgrad's epilogue (dx = 0 where x <= 0) instead of a separate pass
+            mask = x if (chain & CHAIN_MASK_INPUT_GRAD) and segs is None else None
+            dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype, segs, mask)
         taps = ksize ** 3
         wsinks, bsinks = ctx.sinks
         slices = query("conv3d_wgrad_slices", n, gx, gy, gz, cin, rows_total, rows_total, ksize, _dt(x))
@@ -683,19 +696,20 @@ class StemFn(torch.autograd.Function):
         cout = weight.shape[0]
         kpad = query("stem_kpad", _dt(x))
         slices = query("stem_wgrad_slices", n, gx, gy, gz, cout, stride, _dt(x))
-        gwp = torch.empty((slices, cout, kpad), dtype=torch.float32, device=x.device)
+        per = query("stem_wgrad_slice_floats", n, gx, gy, gz, cout, stride, _dt(x))
+        gwp = torch.empty((slices, per), dtype=torch.float32, device=x.device)
         wsink, bsink = ctx.sinks
         direct_bias = has_bias and bsink is not None
         gb = bsink.slot if direct_bias else (torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None)
         ws = torch.empty(query("stem_wgrad_workspace_bytes", n, gx, gy, gz, cout, stride, _dt(x)), dtype=torch.uint8, device=x.device) if has_bias else None
         call("conv3d_stem_wgrad", _p(x), _p(dy), _p(gwp), _p(gb), n, gx, gy, gz, cout, stride, _dt(x), int(direct_bias), _p(ws), _s())
         if wsink is not None:
-            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(wsink.slot), 1, slices, _s())
+            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(wsink.slot), 1, slices, per, _s())
             wsink.notify()
             gw = None
         else:
             gw = torch.empty_like(weight, dtype=torch.float32)
-            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(gw), 0, slices, _s())
+            call("unpack_stem_wgrad", _p(gwp), cout, _dt(x), _p(gw), 0, slices, per, _s())
         if direct_bias:
             bsink.notify()
             gb = None

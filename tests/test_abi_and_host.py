@@ -29,7 +29,7 @@ def test_argument_errors_are_reported_not_fatal():
     with pytest.raises(lib.NrpnError, match="box_dim"):
         lib.call("iou3d_matrix_f32", 0, 0, 0, 1, 1, 5, 0)
     with pytest.raises(lib.NrpnError, match="ksize"):
-        lib.call("conv3d_fwd", 1, 1, 0, 1, 1, 4, 4, 4, 64, 64, 64, 5, 0, 0, 0, 0)
+        lib.call("conv3d_fwd", 1, 1, 0, 1, 1, 4, 4, 4, 64, 64, 64, 5, 0, 0, 0, 0, 0)
 
 
 def test_product_path_has_no_cpu_fallback():

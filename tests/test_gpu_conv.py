@@ -85,7 +85,7 @@ def test_wgrad_bf16_transpose_read_modes(tr, dev):
         lib.call("set_wgrad_transpose_read", 1)
 
 
-@pytest.mark.parametrize("stride,grid", [(2, (16, 14, 13)), (1, (9, 8, 7))])
+@pytest.mark.parametrize("stride,grid", [(2, (16, 14, 13)), (1, (9, 8, 7)), (2, (18, 15, 12)), (2, (34, 26, 20))])    # even Z + stride 2: z-row wgrad kernel
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_stem(stride, grid, dtype, dev):
     from nerf_rpn_amd.model import hip_nn

@@ -34,7 +34,7 @@ def run(grid, cin, cout, k, dtype):
     for kb, dma in ((128, 0), (64, 1), (128, 1)):
         lib.call('set_conv_kstep_bytes', kb)
         lib.call('set_conv_lds_dma', dma)
-        t = timeit(lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), n, grid, grid, grid, cin, cout, cout, k, dt, 0, ws.data_ptr() if ws is not None else 0, ops._s()))
+        t = timeit(lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), n, grid, grid, grid, cin, cout, cout, k, dt, 0, ws.data_ptr() if ws is not None else 0, 0, ops._s()))
         res[f'fwd kb{kb}{"dma" if dma else "reg"}'] = (t, flops / t / 1e9)
     t = timeit(lambda: lib.call('conv3d_wgrad', x.data_ptr(), dy.data_ptr(), gw.data_ptr(), 0, n, grid, grid, grid, cin, cout, cout, k, dt, 0, wsg.data_ptr() if wsg is not None else 0, ops._s()))
     res['wgrad'] = (t, flops / t / 1e9)

@@ -23,7 +23,7 @@ for grid, cin, cout, k in [(40, 256, 256, 3), (20, 512, 512, 3), (20, 256, 512, 
         wsb = lib.query('conv3d_fwd_workspace_bytes', 1, grid, grid, grid, cin, cout, k, ops._dt(x))
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         y = torch.empty(1, grid, grid, grid, cout, device=dev, dtype=torch.bfloat16)
-        fn = lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, ops._dt(x), 0, ws.data_ptr() if wsb else 0, ops._s())
+        fn = lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, ops._dt(x), 0, ws.data_ptr() if wsb else 0, 0, ops._s())
         t = timeit(fn, iters=30)
         outs[bm] = y.float()
         line += f'  bm{bm}(ws {wsb>>20}MB): {t*1e3:.0f} us {flops / t / 1e9:.0f} TF'

@@ -34,7 +34,7 @@ for fill in ('randn', 'zeros'):
     for rnd in range(2):
         line = f'{fill} round {rnd}:'
         for name, fl in (('base', 0), ('alias', 256), ('nosync', 512), ('alias+nosync', 768)):
-            t = timeit(lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, fl, 0,
+            t = timeit(lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, fl, 0, 0,
                                         ops._s()))
             line += f'  {name}: {t*1e3:.1f} us {flops / t / 1e9:.0f} TF'
         print(line, flush=True)
@@ -42,7 +42,7 @@ x = torch.randn(1, grid, grid, grid, cin, device=dev).bfloat16()
 lib.call('set_conv_tile_m', 128)
 for kb in (64, 128):
     lib.call('set_conv_kstep_bytes', kb)
-    t = timeit(lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, 0, 0, ops._s()))
+    t = timeit(lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, 0, 0, 0, ops._s()))
     print(f'128x128 tile, K-step {kb} B: {t*1e3:.1f} us {flops / t / 1e9:.0f} TF', flush=True)
 lib.call('set_conv_kstep_bytes', 128)
 lib.call('set_conv_tile_m', 0)

@@ -13,6 +13,6 @@ y = torch.empty_like(dy)
 gw = torch.empty(lib.query('conv3d_wgrad_slices', 1, grid, grid, grid, cin, cout, cout, k, 1), 27, cout, cin, device=dev)
 wsg = torch.empty(lib.query('conv3d_wgrad_workspace_bytes', 1, grid, grid, grid, cin, cout, cout, k, 1), dtype=torch.uint8, device=dev)
 for _ in range(3):
-    lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, 0, 0, ops._s())
+    lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, 0, 0, 0, ops._s())
     lib.call('conv3d_wgrad', x.data_ptr(), dy.data_ptr(), gw.data_ptr(), 0, 1, grid, grid, grid, cin, cout, cout, k, 1, 0, wsg.data_ptr(), ops._s())
 torch.cuda.synchronize()
