@@ -312,6 +312,12 @@ def main():
     from nerf_rpn_amd import lib
     from nerf_rpn_amd.engine import FlatTrainer
     lib.call("check_device", local)
+    # tuning experiments (not part of the measured configuration unless stated in the output): kernel-selection knobs from the environment
+    knobs = {}
+    for env, fn in (("NRPN_CONV_TILE_M", "set_conv_tile_m"), ("NRPN_CONV_BIG_SPLIT", "set_conv_big_split"), ("NRPN_WGRAD_BIG", "set_wgrad_big_tile")):
+        if env in os.environ:
+            lib.call(fn, int(os.environ[env]))
+            knobs[env] = int(os.environ[env])
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     backbone, head = args.model.split("_")
@@ -377,7 +383,7 @@ def main():
                                    "boxes), fwd+bwd+clip+AdamW (weights repacked every step), random-init weights", "scenes_per_gpu": 1,
                        "parallelism": f"dp{world}", "world_size_seen": world,
                        "backend": (dist.get_backend() if world > 1 else "single process")},
-            "weight_packs_per_step": packs_per_step,
+            "weight_packs_per_step": packs_per_step, **({"tuning_knobs": knobs} if knobs else {}),
             "final_loss": round(final_loss, 5),
             "roofline": roof,
         }

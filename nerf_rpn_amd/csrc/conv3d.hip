@@ -869,10 +869,16 @@ static int g_conv_bm = 0;     // 0: choose per shape; 128 / 256 / 512: force the
 
 // Mid-size grids (20^3: M = 8000) give only 32-64 tiles of 256x256: run the big kernel on K slices whose fp32 partials are
 // written with plain stores to ws[z][M][Cout] and summed by the epilogue (no atomics).  Returns the slice count, 0 = not used.
+static int g_conv_big_split = 1;   // tuning knob: 0 = mid-size grids never use the K-sliced 256x256 kernel
+extern "C" int nrpn_set_conv_big_split(int on) { g_conv_big_split = on ? 1 : 0; return NRPN_OK; }
 static int conv_big_split(long long M, int cout, int cin, int taps, int elem_bytes) {
+  if (!g_conv_big_split) return 0;
   if (elem_bytes != 2 || !g_conv_glds || g_conv_kb_value() != 128 || (g_conv_bm != 0 && g_conv_bm != 512) || cout < 256 || (cin * 2) % 128 != 0) return 0;
   const long long tiles = cdiv64(M, 256) * ((cout + 255) / 256);
-  if (tiles < 16 || tiles >= 200) return 0;
+  // measured inside the bench (20^3 maps): 512->512 (64 tiles, 4 slices) 123 us here vs 204 us on the 128-row kernel, but 256->256
+  // (32 tiles, 8 slices of 13 K-steps) 56 us here vs 49 us there -- below ~48 tiles the slices get too short to amortise the 256 KB
+  // partial-tile epilogue
+  if (tiles < 48 || tiles >= 200) return 0;
   const int nk = taps * (cin / 64);
   int s = (int)((256 + tiles - 1) / tiles);
   if (s > 8) s = 8;

@@ -206,8 +206,8 @@ def test_layout_roundtrip_and_adamw(dev):
 
 
 # (case, forward plan, dgrad plan, wgrad plan): nrpn_conv3d_fwd_plan codes 1 = 256x256 tile, 2 = 256x256 tile on K slices, 0 = 128-row tile
-BIG_CASES = [((1, (40, 40, 33), 256, 256, 3), 1, 1, 1), ((1, (20, 20, 20), 512, 512, 3), 2, 2, 1), ((1, (20, 20, 20), 256, 512, 3), 2, 2, 1),
-             ((1, (24, 20, 18), 320, 256, 3), 2, 2, 1), ((2, (40, 30, 30), 128, 256, 1), 1, 0, 0)]
+BIG_CASES = [((1, (40, 40, 33), 256, 256, 3), 1, 1, 1), ((1, (20, 20, 20), 512, 512, 3), 2, 2, 1), ((1, (20, 20, 20), 256, 512, 3), 2, 3, 1),
+             ((1, (24, 20, 18), 320, 256, 3), 0, 2, 1), ((2, (40, 30, 30), 128, 256, 1), 1, 0, 0)]
 
 
 @pytest.mark.parametrize("case,pf,pd,pw", BIG_CASES)
