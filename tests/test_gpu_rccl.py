@@ -1,0 +1,89 @@
+"""GPU, 2 ranks over RCCL (skipped when fewer than 2 GPUs are visible -- the driver's single-GPU boxes skip it, the 8-GPU scaling node
+runs it): FlatTrainer's bucketed gradient all-reduce on the real model.  After each step both ranks hold identical parameters, and the
+reduced gradient equals the mean of the two ranks' single-GPU gradients (reference semantics: DDP mean all-reduce, run_rpn.py:235-236)."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(rank):
+    g = torch.Generator().manual_seed(500 + rank)
+    x = torch.rand(4, 48, 40, 32, generator=g)
+    gt = torch.tensor([[14., 12., 12., 10., 8., 9., 0.3], [26., 20., 18., 12., 12., 8., -0.6], [30., 10., 10., 8., 9., 7., 0.1]]) + rank
+    return x, gt
+
+
+def _grads(model, x, gt, dev):
+    torch.manual_seed(11)
+    _, losses, _ = model([x.to(dev)], [gt.to(dev)])
+    (losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"]).backward()
+
+
+def _worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from nerf_rpn_amd.engine import FlatTrainer
+    from test_gpu_e2e import build
+    model = build(True, 160, dev).train()
+    tr = FlatTrainer(model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, bucket_bytes=32 << 20)
+    x, gt = _scene(rank)
+    out = []
+    for step in range(2):                 # step 0 learns the notification counts; step 1 launches buckets during backward
+        _grads(model, x, gt, dev)
+        tr.sync_gradients()
+        out.append((tr.flat_grads() / world).cpu())
+        tr.g_arena.zero_() if step == 0 else tr.step()
+    q.put((rank, out, tr.flat_params().cpu(), len(tr.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_rccl_gradient_exchange(dev):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, ga, pa, nb), (_, gb, pb, _) = res
+    assert nb >= 2
+    assert torch.equal(pa, pb)                                          # identical parameters after the step on both ranks
+    for s in range(2):
+        assert torch.equal(ga[s], gb[s])                                # the all-reduce result is the same tensor on both ranks
+    # reference: each rank's gradient computed alone (deterministic kernels), averaged on the host
+    from test_gpu_e2e import build
+    alone = []
+    for rank in range(2):
+        m = build(True, 160, dev).train()
+        x, gt = _scene(rank)
+        _grads(m, x, gt, dev)
+        alone.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu())
+    mean = (alone[0] + alone[1]) / 2
+    assert torch.allclose(ga[0], mean, rtol=1e-6, atol=1e-9 + 1e-6 * mean.abs().max().item())
