@@ -226,14 +226,20 @@ def test_large_tile_kernels_vs_torch_fp32(case, pf, pd, pw, dev):
     conv.weight.data = conv.weight.data.bfloat16().float()
     x = torch.randn(n, cin, *grid).bfloat16().float()
     gy = (torch.randn(n, cout, *grid) * (torch.rand(n, 1, *grid) < 0.3)).bfloat16().float()
-    xr = x.clone().requires_grad_(True)
-    yr = F.relu(conv(xr))
-    yr.backward(gy)
     h = nn.Conv3d(cin, cout, k, padding=k // 2).to(dev)
     h.load_state_dict(conv.state_dict())
     xh = cl(x).to(dev).bfloat16().requires_grad_(True)
     yh = hip_nn.conv3d(h, xh, relu=True)
     yh.backward(cl(gy).to(dev).bfloat16())
+    # The ReLU mask is taken from the kernel's own output: an output that is zero to fp32 rounding can land on either side in two
+    # summation orders, and ONE flipped mask element moves the 320 weight-gradient entries it touches by ~1 % of max|dw| -- that is a
+    # property of ReLU at 0, not of the convolution under test.
+    xr = x.clone().requires_grad_(True)
+    pre = conv(xr)
+    mask = (cf(yh.detach().float().cpu()) > 0).float()
+    yr = pre * mask
+    assert ((pre.detach() > 0).float() != mask).float().mean().item() < 1e-4       # the masks differ on at most a few near-zero outputs
+    yr.backward(gy)
     # y / dx are stored in bf16 (2^-9 relative rounding of each element); dw / db are fp32 sums of bf16 products
     for name, a, b, tol in (("y", cf(yh.detach().float().cpu()), yr.detach(), 1e-2), ("dx", cf(xh.grad.float().cpu()), xr.grad, 1e-2),
                             ("dw", h.weight.grad.cpu(), conv.weight.grad, 2e-3), ("db", h.bias.grad.cpu(), conv.bias.grad, 2e-3)):
