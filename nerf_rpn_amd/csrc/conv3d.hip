@@ -419,6 +419,48 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
   // ---- epilogue: bias / ReLU, store channels-last
   const bool has_bias = (p.flags & NRPN_CONV_BIAS) && p.bias;
   const bool relu = p.flags & NRPN_CONV_RELU;
+  constexpr int PITCH = 144;
+  if (sizeof(T) == 2 && !OUTF32 && 2 * (A_BYTES + B_BYTES) >= 4 * TM * 32 * PITCH && (p.Cout & 7) == 0) {
+    // bf16 output: stage the wave's (TM*32) x 64 block through LDS (free after the loop's last barrier) and store / mask it as
+    // whole 16-byte pieces instead of one 2-byte element per lane per row (see conv_igemm_big_kernel)
+    char *stage = lds + wave * (TM * 32 * PITCH);
+    const T *maskp = reinterpret_cast<const T *>(p.mask);
+    T *yp = reinterpret_cast<T *>(p.y);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + fr;
+      const float bv = (has_bias && col < p.Cout) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float o = acc[i][j][r] + bv;
+          if (relu) o = fmaxf(o, 0.f);
+          *reinterpret_cast<bf16s *>(stage + (i * 32 + frag_row(r, lane)) * PITCH + (j * 32 + fr) * 2) = f32_to_bf16_bits(o);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < TM * 4; ++q) {
+      const int pc = lane + 64 * q;                     // TM*32 rows x 8 pieces of 16 bytes
+      const int row = pc >> 3, seg = pc & 7;
+      const long long v = m0 + wm * (TM * 32) + row;
+      const int col = n0 + wn * 64 + seg * 8;
+      if (v < p.M && col < p.Cout) {
+        f4 val = *reinterpret_cast<const f4 *>(stage + row * PITCH + seg * 16);
+        if (maskp) {
+          typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+          const u8v mk = __builtin_bit_cast(u8v, *reinterpret_cast<const f4 *>(maskp + v * p.Cout + col));
+          u8v ov = __builtin_bit_cast(u8v, val);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (bf16_bits_to_f32(mk[e]) > 0.f) ? ov[e] : (unsigned short)0;
+          val = __builtin_bit_cast(f4, ov);
+        }
+        *reinterpret_cast<f4 *>(yp + v * p.Cout + col) = val;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + fr;
@@ -808,6 +850,57 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
           const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
           if (v < p.M) wsz[v * p.Cout + col] = acc[i][j][r];
         }
+    }
+    return;
+  }
+  if (!OUTF32 && (p.Cout & 7) == 0) {
+    // bf16 output: the C fragment of a lane is one 2-byte element per row -- 128 two-byte global stores (and as many two-byte mask
+    // loads) per wave.  Stage each wave's 128x64 block through LDS instead (free after the K loop: every wave has passed the last
+    // barrier), 64 rows at a time with a 144-byte row pitch (rows 4 apart land on different banks), and move it out as whole
+    // 16-byte pieces: 8 lanes cover one 128-byte row segment, the optional ReLU mask comes in with the same 16-byte loads.
+    constexpr int PITCH = 144;
+    char *stage = lds + wave * (64 * PITCH);
+    const T *maskp = reinterpret_cast<const T *>(p.mask);
+    T *yp = reinterpret_cast<T *>(p.y);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + efr;
+        const float bv = (has_bias && col < p.Cout) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = half * 2 + ii;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float o = acc[i][j][r] + bv;
+            if (relu) o = fmaxf(o, 0.f);
+            *reinterpret_cast<bf16s *>(stage + (ii * 32 + frag_row(r, elane)) * PITCH + (j * 32 + efr) * 2) = f32_to_bf16_bits(o);
+          }
+        }
+      }
+      // same wave wrote and reads: only the LDS counter has to drain
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int pc = elane + 64 * q;                  // 512 pieces: 64 rows x 8 pieces of 16 bytes
+        const int row = pc >> 3, seg = pc & 7;
+        const long long v = m0 + wm * 128 + half * 64 + row;
+        const int col = n0 + wn * 64 + seg * 8;
+        if (v < p.M && col < p.Cout) {
+          f4 val = *reinterpret_cast<const f4 *>(stage + row * PITCH + seg * 16);
+          if (maskp) {
+            typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+            const u8v mk = __builtin_bit_cast(u8v, *reinterpret_cast<const f4 *>(maskp + v * p.Cout + col));
+            u8v ov = __builtin_bit_cast(u8v, val);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (bf16_bits_to_f32(mk[e]) > 0.f) ? ov[e] : (unsigned short)0;
+            val = __builtin_bit_cast(f4, ov);
+          }
+          *reinterpret_cast<f4 *>(yp + v * p.Cout + col) = val;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this half before the next half overwrites the stage
     }
     return;
   }
