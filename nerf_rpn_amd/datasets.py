@@ -272,3 +272,59 @@ class GeneralRPNDataset(BaseDataset):
                 assert os.path.isfile(row.boxes_path), f"{row.boxes_path} does not exist"
                 boxes = torch.from_numpy(np.load(row.boxes_path))
             self.scene_data.append((row.scene, _grid_from_npz(row.rgbsigma_path, normalize_density), boxes))
+
+
+class RPNClassificationDataset(torch.utils.data.Dataset):
+    """Scenes for the second-stage network (reference datasets.py:330-424): per scene either the pre-extracted pyramid features
+    (``level_features`` + ``resolution`` in the feature .npz) or, with ``fine_tune``, the raw rgb-sigma grid; the ground-truth boxes; and the
+    first stage's proposals as RoI rows (level index, box) read from ``roi_path/<scene>.npz`` (keys ``level_indices``, ``proposals``)."""
+
+    def __init__(self, features_path: str, boxes_path: str, roi_path: str, scene_names: Optional[List[str]] = None, fine_tune: bool = False,
+                 normalize_density: bool = True, flip_prob: float = 0.0, rotate_prob: float = 0.0, rotate_scale_prob: float = 0.0):
+        self.features_path, self.boxes_path, self.fine_tune = features_path, boxes_path, fine_tune
+        self.flip_prob, self.rotate_prob, self.rotate_scale_prob = flip_prob, rotate_prob, rotate_scale_prob
+        if scene_names is None:
+            scene_names = [f.split(".")[0] for f in os.listdir(features_path) if f.endswith(".npz")]
+        self.scene_data = []
+        for name in scene_names:
+            name = str(name)
+            if not os.path.isfile(os.path.join(boxes_path, name + ".npy")) or not os.path.isfile(os.path.join(roi_path, name + ".npz")):
+                print(f"{name} does not have a training file")
+                continue
+            with np.load(os.path.join(features_path, name + ".npz"), allow_pickle=True) as f:
+                resolution = f["resolution"]
+                if not fine_tune:
+                    lf = f["level_features"]
+                    feats = [torch.from_numpy(np.asarray(lf[i]).reshape(resolution[i]).astype(np.float32)) for i in range(len(lf))]
+                else:
+                    g = f["rgbsigma"].astype(np.float32)
+                    if normalize_density:
+                        g[..., -1] = density_to_alpha(g[..., -1])
+                    feats = [torch.from_numpy(np.transpose(g, (3, 0, 1, 2)))]
+            boxes = torch.from_numpy(np.load(os.path.join(boxes_path, name + ".npy")))
+            with np.load(os.path.join(roi_path, name + ".npz"), allow_pickle=True) as fr:
+                level_indices, proposals = fr["level_indices"], fr["proposals"]
+            if fine_tune:       # drop proposals covering more than half of the scene (reference :386-395)
+                keep = proposals[:, 3] * proposals[:, 4] * proposals[:, 5] / (resolution[0] * resolution[1] * resolution[2]) <= 0.5
+                level_indices, proposals = level_indices[keep], proposals[keep]
+            rois = torch.from_numpy(np.concatenate([level_indices[..., None], proposals], axis=1))
+            self.scene_data.append((name, feats, boxes, rois))
+
+    density_to_alpha = staticmethod(density_to_alpha)
+    augment_rpn_inputs = staticmethod(BaseDataset.augment_rpn_inputs)
+
+    def __len__(self) -> int:
+        return len(self.scene_data)
+
+    def __getitem__(self, index: int):
+        name, feats, boxes, rois = self.scene_data[index]
+        if self.fine_tune and (self.flip_prob > 0 or self.rotate_prob > 0 or self.rotate_scale_prob > 0):
+            level_indices, n_gt = rois[..., :1], boxes.size(0)
+            grid, moved = self.augment_rpn_inputs(feats[0], torch.cat([boxes, rois[..., 1:]]), self.flip_prob, self.rotate_prob,
+                                                  self.rotate_scale_prob)
+            boxes, rois, feats = moved[:n_gt], torch.cat([level_indices, moved[n_gt:]], dim=-1), [grid]
+        return feats, boxes, rois, name
+
+    @staticmethod
+    def collate_fn(batch):
+        return [b[0] for b in batch], [b[1] for b in batch], [b[2] for b in batch], [b[3] for b in batch]

@@ -375,6 +375,70 @@ def record_grads(arrs, rp, op, p64):
     return worst
 
 
+def gen_detector():
+    """Second stage (reference detector.py, coder/rotated_coder.py, level_mapper.py, run_rpn_detect.py): the pieces that run on the CPU
+    in the reference -- the rotated RoI coder, the FPN level mapper, RoI <-> ground-truth assignment / sampling, the CLI flag table."""
+    print("detector")
+    import argparse, json
+    from model.coder.rotated_coder import RotatedCoder
+    from model.level_mapper import _setup_scales
+    from model import detector as R_det
+    g = torch.Generator().manual_seed(21)
+    rois, gt = rand_obb(200, g, 8, 150, 4, 40), rand_obb(200, g, 8, 150, 4, 40)
+    gt[:100, :3] = rois[:100, :3] + (torch.rand(100, 3, generator=g) - 0.5) * 6
+    coder = RotatedCoder()
+    enc = coder.encode_single(gt, rois)
+    deltas = torch.randn(200, 7, generator=g) * 0.3
+    deltas[:5, 3:6] = 9.0                                        # exercises the log(2000) clamp
+    dec = coder.decode_single(deltas, rois)
+    mapper = _setup_scales([1 / 4, 1 / 8, 1 / 16, 1 / 32], 200, 4)
+    boxes = rand_obb(300, g, 8, 150, 1, 180)
+    levels = mapper(boxes)
+    # RoI <-> GT assignment: rows = (level, box)
+    layer = R_det.ProposalTargetLayer(2, batch_size=64, fg_fraction=0.5, fg_threshold=0.35, bg_threshold=0.15, is_rotated_bbox=True)
+    scene_rois, scene_gt = [], []
+    for k in range(2):
+        gtb = rand_obb(6, g, 20, 120, 10, 40)
+        r = rand_obb(150, g, 10, 140, 6, 50)
+        r[:40] = gtb[torch.randint(0, 6, (40,), generator=g)] + torch.randn(40, 7, generator=g) * torch.tensor([2, 2, 2, 1.5, 1.5, 1.5, 0.1])
+        r[:, 3:6] = r[:, 3:6].clamp_min(2.0)
+        scene_rois.append(torch.cat([torch.randint(0, 4, (150, 1), generator=g).float(), r], dim=1))
+        scene_gt.append(gtb)
+    labels = [torch.ones(6) for _ in range(2)]
+    orig_get_device = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: "cpu"             # fifth shim: the layer does .to(tensor.get_device()), -1 on the CPU
+    try:
+        lab_all, rois_all, gtr_all = layer([r.clone() for r in scene_rois], scene_gt, labels, is_sample=False)
+        np.random.seed(0)
+        lab_s, rois_s, gtr_s = layer([r.clone() for r in scene_rois], scene_gt, labels, is_sample=True)
+    finally:
+        torch.Tensor.get_device = orig_get_device
+    # flag table of the CLI
+    import run_rpn_detect as R_cli
+
+    class Captured(Exception):
+        pass
+
+    def grab(self, *a, **k):
+        raise Captured(self)
+    orig = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = grab
+    try:
+        R_cli.parse_args()
+    except Captured as c:
+        parser = c.args[0]
+    finally:
+        argparse.ArgumentParser.parse_args = orig
+    flags = [dict(options=a.option_strings, dest=a.dest, default=a.default, choices=list(a.choices) if a.choices else None,
+                  type=a.type.__name__ if a.type else None, action=type(a).__name__, nargs=a.nargs)
+             for a in parser._actions if a.option_strings and a.dest != "help"]
+    json.dump(flags, open(os.path.join(HERE, "cli_flags_detect.json"), "w"), indent=1)
+    print("   ", len(flags), "flags")
+    save("detector", rois=rois, gt=gt, encoded=enc, deltas=deltas, decoded=dec, mapper_boxes=boxes, mapper_levels=levels,
+         roi0=scene_rois[0], roi1=scene_rois[1], gt0=scene_gt[0], gt1=scene_gt[1], labels_all0=lab_all[0], labels_all1=lab_all[1],
+         gt_rois_all0=gtr_all[0], labels_sampled=lab_s, rois_sampled=rois_s, gt_rois_sampled=gtr_s)
+
+
 def raw_scene_wlh4(shape, seed):
     """On-disk layout (W,L,H,4) f32: rgb U[0,1), density U[-5,5) (SURVEY 8d synthetic input for --normalize_density)."""
     g = torch.Generator().manual_seed(seed)
@@ -594,6 +658,6 @@ def gen_fcos():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "eval", "fullsize", "train", "fcos"]
+    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "detector", "eval", "fullsize", "train", "fcos"]
     for w in which:
         globals()["gen_" + w]()

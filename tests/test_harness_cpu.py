@@ -56,3 +56,30 @@ def test_oracle_metrics(golden):
         assert abs(OM.recall(P, S, G, torch.arange(0.25, 1.0, 0.05), 100)["ar"].item() - float(g[f"{tag}_ar"])) < 1e-6
         assert abs(OM.average_precision(P, S, G, 0.5)["ap"].item() - float(g[f"{tag}_ap50"])) < 1e-6
         assert abs(OM.average_precision(P, S, G, 0.25, 50)["ap"].item() - float(g[f"{tag}_ap25"])) < 1e-6
+
+
+def test_detect_cli_flags_match_reference():
+    from nerf_rpn_amd.run_rpn_detect import build_parser
+    ref = json.load(open(os.path.join(GOLDEN, "cli_flags_detect.json")))
+    mine = {a.dest: a for a in build_parser()._actions if a.option_strings and a.dest != "help"}
+    for f in ref:
+        a = mine.pop(f["dest"])
+        assert a.option_strings == f["options"], f["dest"]
+        assert a.default == f["default"], (f["dest"], a.default, f["default"])
+        assert (list(a.choices) if a.choices else None) == f["choices"], f["dest"]
+        assert (a.type.__name__ if a.type else None) == f["type"], f["dest"]
+        assert type(a).__name__ == f["action"] and a.nargs == f["nargs"], f["dest"]
+    assert not mine
+
+
+def test_rotated_coder_and_level_mapper_match_reference(golden):
+    """The second stage's CPU-side arithmetic against what the reference produced (tests/golden/make_golden.py::gen_detector)."""
+    from nerf_rpn_amd.model.coder.rotated_coder import RotatedCoder
+    from nerf_rpn_amd.model.level_mapper import _setup_scales
+    g = golden("detector")
+    T = torch.from_numpy
+    coder = RotatedCoder()
+    assert torch.allclose(coder.encode_single(T(g["gt"]), T(g["rois"])), T(g["encoded"]), atol=1e-6)
+    assert torch.allclose(coder.decode_single(T(g["deltas"]), T(g["rois"])), T(g["decoded"]), atol=1e-4, rtol=1e-6)
+    mapper = _setup_scales([1 / 4, 1 / 8, 1 / 16, 1 / 32], 200, 4)
+    assert torch.equal(mapper(T(g["mapper_boxes"])), T(g["mapper_levels"]))
