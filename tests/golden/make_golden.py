@@ -439,6 +439,28 @@ def gen_detector():
          gt_rois_all0=gtr_all[0], labels_sampled=lab_s, rois_sampled=rois_s, gt_rois_sampled=gtr_s)
 
 
+def gen_ngp():
+    """scripts/proposals2ngp.py: proposals -> instant-ngp bounding boxes (format-only consumer of the proposal files)."""
+    print("ngp export")
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location("ref_p2ngp", "/root/reference/nerf_rpn/scripts/proposals2ngp.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(9)
+    feats = dict(resolution=np.array([160, 120, 64]), bbox_min=np.array([-1.5, -2.0, -0.5]), bbox_max=np.array([2.5, 1.0, 1.5]),
+                 scale=np.float64(0.33), offset=np.array([0.5, 0.4, 0.6]))
+    aabb = np.concatenate([rng.random((5, 3)) * 60, rng.random((5, 3)) * 40 + 70], axis=1)
+    obb = np.concatenate([rng.random((5, 3)) * 100 + 10, rng.random((5, 3)) * 30 + 5, rng.random((5, 1)) * 3 - 1.5], axis=1)
+    out = {}
+    for mitsuba in (False, True):
+        f = dict(feats, from_mitsuba=mitsuba)
+        out[f"aabb_{int(mitsuba)}"] = ref.proposals_to_ngp_boxes(aabb, f)
+        out[f"obb_{int(mitsuba)}"] = ref.obb_to_ngp_boxes(obb, f)
+    json.dump(dict(features={k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in feats.items()}, aabb=aabb.tolist(), obb=obb.tolist(),
+                   boxes=out), open(os.path.join(HERE, "ngp_boxes.json"), "w"), indent=1)
+    print("   wrote ngp_boxes.json")
+
+
 def raw_scene_wlh4(shape, seed):
     """On-disk layout (W,L,H,4) f32: rgb U[0,1), density U[-5,5) (SURVEY 8d synthetic input for --normalize_density)."""
     g = torch.Generator().manual_seed(seed)
@@ -658,6 +680,6 @@ def gen_fcos():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "detector", "eval", "fullsize", "train", "fcos"]
+    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "detector", "ngp", "eval", "fullsize", "train", "fcos"]
     for w in which:
         globals()["gen_" + w]()

@@ -132,3 +132,24 @@ def test_device_ingest_matches_host_loader(tmp_path, dev):
         (_, p1, _), _, s1 = m([raw.to_device(torch.float32)])
         (_, p2, _), _, s2 = m([_grid_from_npz(str(tmp_path / "f.npz"), True).to(dev)])
     assert p1[0].shape == p2[0].shape and torch.allclose(s1[0], s2[0], atol=1e-5) and torch.allclose(p1[0], p2[0], atol=1e-3)
+
+
+def test_voxel_score_heatmaps(tmp_path, dev):
+    """``objectness_output_paths`` (run_rpn.py --output_voxel_scores; reference rpn.py:538-549): one .npz per scene with keys '0'..'3', the
+    per-voxel maximum over the 13 anchors of each level's objectness logits, cropped to ceil(size / 2^(level+2))."""
+    from test_gpu_e2e import build, scene
+    m = build(True, 160, dev).eval()
+    x = scene((48, 40, 32), 9).to(dev)
+    path = str(tmp_path / "scores.npz")
+    with torch.no_grad():
+        m([x], objectness_output_paths=[path])
+        # the same maps straight from the head, for comparison
+        feats = m.backbone(x[None])
+        logits, _ = m.rpn.head(list(feats))
+    z = np.load(path)
+    assert sorted(z.files) == ["0", "1", "2", "3"]
+    for lvl in range(4):
+        w, l, h = np.ceil(np.array([48, 40, 32]) / 2 ** (lvl + 2)).astype(int)
+        assert z[str(lvl)].shape == (w, l, h)
+        ref = logits[lvl][0].float().max(dim=0)[0][:w, :l, :h].cpu().numpy()
+        assert np.allclose(z[str(lvl)], ref, atol=1e-5)

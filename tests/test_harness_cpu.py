@@ -83,3 +83,24 @@ def test_rotated_coder_and_level_mapper_match_reference(golden):
     assert torch.allclose(coder.decode_single(T(g["deltas"]), T(g["rois"])), T(g["decoded"]), atol=1e-4, rtol=1e-6)
     mapper = _setup_scales([1 / 4, 1 / 8, 1 / 16, 1 / 32], 200, 4)
     assert torch.equal(mapper(T(g["mapper_boxes"])), T(g["mapper_levels"]))
+
+
+def test_ngp_box_export_matches_reference(tmp_path):
+    """scripts/proposals2ngp.py against boxes produced by the reference's functions (tests/golden/ngp_boxes.json) + the file round trip."""
+    from nerf_rpn_amd.scripts import proposals2ngp as P
+    g = json.load(open(os.path.join(GOLDEN, "ngp_boxes.json")))
+    feats = {k: (np.array(v) if isinstance(v, list) else v) for k, v in g["features"].items()}
+    for mitsuba in (0, 1):
+        f = dict(feats, from_mitsuba=bool(mitsuba))
+        for kind, fn, boxes in (("aabb", P.proposals_to_ngp_boxes, np.array(g["aabb"])), ("obb", P.obb_to_ngp_boxes, np.array(g["obb"]))):
+            for mine, ref in zip(fn(boxes, f), g["boxes"][f"{kind}_{mitsuba}"]):
+                for key in ("orientation", "position", "extents"):
+                    assert np.allclose(mine[key], ref[key], atol=1e-12), (kind, mitsuba, key)
+    os.makedirs(tmp_path / "scenes" / "s" / "train"); os.makedirs(tmp_path / "p"); os.makedirs(tmp_path / "f")
+    json.dump({"frames": []}, open(tmp_path / "scenes" / "s" / "train" / "transforms.json", "w"))
+    np.savez(tmp_path / "p" / "s.npz", proposal=np.array(g["obb"], dtype=np.float32), score=np.linspace(0.4, 0.9, 5).astype(np.float32))
+    np.savez(tmp_path / "f" / "s.npz", from_mitsuba=False, **feats)
+    P.main(["--bbox_format", "obb", "--dataset", "hypersim", "--dataset_path", str(tmp_path / "scenes"), "--features_path", str(tmp_path / "f"),
+            "--proposals_path", str(tmp_path / "p"), "--output_dir", str(tmp_path / "o")])
+    out = json.load(open(tmp_path / "o" / "s.json"))
+    assert len(out["bounding_boxes"]) == 4 and out["bounding_boxes"][0]["score"] > out["bounding_boxes"][-1]["score"] > 0.5
