@@ -304,85 +304,113 @@ static inline int pool_out(int in, int k, int s, int p, int ceil_mode) {
 }
 extern "C" int nrpn_pool_out_size(int in, int k, int s, int p, int ceil_mode) { return pool_out(in, k, s, p, ceil_mode); }
 
-template <typename T>
+// V consecutive channels per thread: 4 (8 / 16-byte accesses) or, for bf16 with C % 8 == 0, 8 (16-byte accesses): half the
+// instructions per byte on kernels that are issue-bound (27 window positions per output of the 3/2/1 pool)
+template <typename T, int V> struct vecv;
+template <typename T> struct vecv<T, 4> {
+  static __device__ __forceinline__ void ld(const T *p, float *o) { const f4 v = vec4<T>::ld(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+  static __device__ __forceinline__ void st(T *p, const float *o) { vec4<T>::st(p, f4{o[0], o[1], o[2], o[3]}); }
+};
+template <> struct vecv<bf16s, 8> {
+  typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+  static __device__ __forceinline__ void ld(const bf16s *p, float *o) {
+    const us8 u = *reinterpret_cast<const us8 *>(p);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = bf16_bits_to_f32(u[q]);
+  }
+  static __device__ __forceinline__ void st(bf16s *p, const float *o) {
+    us8 u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = f32_to_bf16_bits(o[q]);
+    *reinterpret_cast<us8 *>(p) = u;
+  }
+};
+
+template <typename T, int V>
 __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int8_t *__restrict__ arg, int n, int gx, int gy, int gz, int ox,
                                    int oy, int oz, int c, int k, int s, int p) {
-  const int ct = c / 4;
+  const int ct = c / V;
   const long long total = (long long)n * ox * oy * oz * ct;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(g % ct) * 4;
+    const int cg = (int)(g % ct) * V;
     long long v = g / ct;
     const int z = (int)(v % oz); v /= oz;
     const int yy = (int)(v % oy); v /= oy;
     const int xx = (int)(v % ox);
     const long long b = v / ox;
-    f4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bi[4] = {0, 0, 0, 0};
-    bool first[4] = {true, true, true, true};
-    for (int a = 0; a < k; ++a) {
+    float best[V];
+    int bi[V];
+    bool first = true;
+    // window clipped to the grid once per axis (torch: -inf padding, first maximum wins => ascending scan order is kept)
+    const int a0 = max(0, p - xx * s), a1 = min(k, gx + p - xx * s);
+    const int b0 = max(0, p - yy * s), b1 = min(k, gy + p - yy * s);
+    const int d0 = max(0, p - z * s), d1 = min(k, gz + p - z * s);
+    for (int a = a0; a < a1; ++a) {
       const int ix = xx * s - p + a;
-      if ((unsigned)ix >= (unsigned)gx) continue;
-      for (int bq = 0; bq < k; ++bq) {
+      for (int bq = b0; bq < b1; ++bq) {
         const int iy = yy * s - p + bq;
-        if ((unsigned)iy >= (unsigned)gy) continue;
-        for (int d = 0; d < k; ++d) {
+        for (int d = d0; d < d1; ++d) {
           const int iz = z * s - p + d;
-          if ((unsigned)iz >= (unsigned)gz) continue;
-          const f4 xv = vec4<T>::ld(x + ((((b * gx + ix) * gy + iy) * gz + iz) * (long long)c + cg));
+          float xv[V];
+          vecv<T, V>::ld(x + ((((b * gx + ix) * gy + iy) * gz + iz) * (long long)c + cg), xv);
           const int code = (a * k + bq) * k + d;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (first[q] || xv[q] > best[q]) { best[q] = xv[q]; bi[q] = code; first[q] = false; }
+          for (int q = 0; q < V; ++q)
+            if (first || xv[q] > best[q]) { best[q] = xv[q]; bi[q] = code; }
+          first = false;
         }
       }
     }
+    if (first) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+    }
     const long long o = (g / ct) * (long long)c + cg;
-    vec4<T>::st(y + o, best);
+    vecv<T, V>::st(y + o, best);
     if (arg) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) arg[o + q] = (int8_t)bi[q];
+      for (int q = 0; q < V; ++q) arg[o + q] = (int8_t)bi[q];
     }
   }
 }
 
-// gather form: every input voxel sums the dy of the windows whose argmax points at it (no atomics, deterministic)
-template <typename T>
+// gather form: every input voxel sums the dy of the windows whose argmax points at it (no atomics, deterministic).  Per axis the
+// windows containing coordinate x are those with offset a = (x + p) mod s, + s, + 2s, ... < k: at most ceil(k / s) candidates,
+// enumerated directly (8 for the 3/2/1 pool instead of testing all 27 offsets).
+template <typename T, int V>
 __global__ void maxpool_bwd_kernel(const T *__restrict__ dy, const int8_t *__restrict__ arg, T *__restrict__ dx, int n, int gx, int gy, int gz,
                                    int ox, int oy, int oz, int c, int k, int s, int p) {
-  const int ct = c / 4;
+  const int ct = c / V;
   const long long total = (long long)n * gx * gy * gz * ct;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(g % ct) * 4;
+    const int cg = (int)(g % ct) * V;
     long long v = g / ct;
     const int z = (int)(v % gz); v /= gz;
     const int yy = (int)(v % gy); v /= gy;
     const int xx = (int)(v % gx);
     const long long b = v / gx;
-    f4 acc = {0, 0, 0, 0};
-    for (int a = 0; a < k; ++a) {
-      const int tx = xx + p - a;
-      if (tx < 0 || tx % s) continue;
-      const int wx = tx / s;
-      if (wx >= ox) continue;
-      for (int bq = 0; bq < k; ++bq) {
-        const int ty = yy + p - bq;
-        if (ty < 0 || ty % s) continue;
-        const int wy = ty / s;
-        if (wy >= oy) continue;
-        for (int d = 0; d < k; ++d) {
-          const int tz = z + p - d;
-          if (tz < 0 || tz % s) continue;
-          const int wz = tz / s;
-          if (wz >= oz) continue;
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    for (int a = (xx + p) % s; a < k; a += s) {
+      const int wx = (xx + p - a) / s;
+      if (xx + p - a < 0 || wx >= ox) continue;
+      for (int bq = (yy + p) % s; bq < k; bq += s) {
+        const int wy = (yy + p - bq) / s;
+        if (yy + p - bq < 0 || wy >= oy) continue;
+        for (int d = (z + p) % s; d < k; d += s) {
+          const int wz = (z + p - d) / s;
+          if (z + p - d < 0 || wz >= oz) continue;
           const long long o = ((((b * ox + wx) * oy + wy) * oz + wz) * (long long)c + cg);
           const int code = (a * k + bq) * k + d;
-          const f4 gv = vec4<T>::ld(dy + o);
+          float gv[V];
+          vecv<T, V>::ld(dy + o, gv);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] += (arg[o + q] == code) ? gv[q] : 0.f;
+          for (int q = 0; q < V; ++q) acc[q] += (arg[o + q] == code) ? gv[q] : 0.f;
         }
       }
     }
-    vec4<T>::st(dx + (g / ct) * (long long)c + cg, acc);
+    vecv<T, V>::st(dx + (g / ct) * (long long)c + cg, acc);
   }
 }
 
@@ -391,9 +419,15 @@ extern "C" int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n,
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_fwd: bad sizes");
   NRPN_REQUIRE(x && y, "maxpool_fwd: null pointer");
   const int ox = pool_out(gx, k, s, p, ceil_mode), oy = pool_out(gy, k, s, p, ceil_mode), oz = pool_out(gz, k, s, p, ceil_mode);
-  const long long total = (long long)n * ox * oy * oz * (c / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y,
-                                       argmax, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+  if (dtype == NRPN_BF16 && c % 8 == 0) {
+    const long long total = (long long)n * ox * oy * oz * (c / 8);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16s, 8>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const bf16s *)x, (bf16s *)y, argmax, n,
+                       gx, gy, gz, ox, oy, oz, c, k, s, p);
+  } else {
+    const long long total = (long long)n * ox * oy * oz * (c / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T, 4>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y,
+                                         argmax, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+  }
   NRPN_LAUNCH_CHECK("maxpool_fwd");
   return NRPN_OK;
 }
@@ -403,9 +437,15 @@ extern "C" int nrpn_maxpool3d_bwd(const void *dy, const int8_t *argmax, void *dx
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_bwd: bad sizes");
   NRPN_REQUIRE(dy && argmax && dx, "maxpool_bwd: null pointer");
   const int ox = pool_out(gx, k, s, p, ceil_mode), oy = pool_out(gy, k, s, p, ceil_mode), oz = pool_out(gz, k, s, p, ceil_mode);
-  const long long total = (long long)n * gx * gy * gz * (c / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)dy, argmax,
-                                       (T *)dx, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+  if (dtype == NRPN_BF16 && c % 8 == 0) {
+    const long long total = (long long)n * gx * gy * gz * (c / 8);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16s, 8>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const bf16s *)dy, argmax, (bf16s *)dx,
+                       n, gx, gy, gz, ox, oy, oz, c, k, s, p);
+  } else {
+    const long long total = (long long)n * gx * gy * gz * (c / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 4>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)dy, argmax,
+                                         (T *)dx, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+  }
   NRPN_LAUNCH_CHECK("maxpool_bwd");
   return NRPN_OK;
 }
