@@ -13,6 +13,8 @@
 // Replaces torch.nn.Conv3d (MIOpen/cuDNN) in reference feature_extractor.py:331-358, fpn.py:109-110, anchor.py:190-198.
 #include "common.h"
 
+#include <type_traits>
+
 typedef __attribute__((ext_vector_type(4))) float f4;
 typedef __attribute__((ext_vector_type(2))) float f2;
 typedef __attribute__((ext_vector_type(16))) float f16v;
@@ -790,21 +792,25 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   };
   // one K-step: the 8 LDS-DMA pieces of the NEXT step are issued one behind each MFMA of sub-step 0 (an LDS-DMA issue
   // costs ~60 cycles among bare MFMAs but >100 in a burst), the ds_reads of sub-step s+1 behind the MFMAs of sub-step s
-  auto compute = [&](int buf, bool next_live) {
+  // P = the sub-step whose MFMAs carry the 8 LDS-DMA issues of the next K-step (0, or 2 for the second wave of each SIMD when the
+  // stagger experiment is on: after the barrier both waves of a SIMD otherwise sit in their DMA-issue phase at the same time)
+  auto compute = [&](int buf, bool next_live, auto ptag) {
+    constexpr int P = decltype(ptag)::value;
     const char *A = lds + buf * (A_BYTES + B_BYTES);
     const char *B = A + A_BYTES;
     f4 af[2][TM], bfv[2][TN];
     load_frags(A, B, 0, af[0], bfv[0]);
     __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-    issue(buf ^ 1, next_live);
+    if (P == 0) issue(buf ^ 1, next_live);
 #pragma unroll
     for (int s = 0; s < KB / 32; ++s) {
       if (s + 1 < KB / 32) load_frags(A, B, s + 1, af[(s + 1) & 1], bfv[(s + 1) & 1]);
+      if (P == s && s > 0) issue(buf ^ 1, next_live);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[s & 1][i], bfv[s & 1][j]);
-      if (s == 0) {
+      if (s == P) {
 #pragma unroll
         for (int q = 0; q < TM * TN; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -823,12 +829,14 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
       }
     }
   };
+  const bool late_issue = (p.flags & NRPN_CONV_DEBUG_STAGGER) && wave_u >= 4;
 
   issue(0, ks_begin < nk);
   __syncthreads();
 #pragma unroll 1
   for (int ks = ks_begin; ks < nk; ++ks) {
-    compute((ks - ks_begin) & 1, ks + 1 < nk);
+    if (late_issue) compute((ks - ks_begin) & 1, ks + 1 < nk, std::integral_constant<int, 2>{});
+    else compute((ks - ks_begin) & 1, ks + 1 < nk, std::integral_constant<int, 0>{});
     if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
   }
 
@@ -1091,7 +1099,7 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // classic layout: the kernel splits v into (batch, x, y, z) with these
   if (segs) a.segs = *segs;
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1;
-  a.flags = flags & (3 | NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC);
+  a.flags = flags & (3 | NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER);
   NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && (long long)a.taps * wrows * cin * es < (1ll << 31),
                "conv3d_fwd: activation / weight tensors must stay below 2 GiB (32-bit buffer offsets)");
   a.x_bytes = (unsigned)(a.M * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);

@@ -33,11 +33,16 @@ for fill in ('randn', 'zeros'):
     y = torch.empty(1, grid, grid, grid, cout, device=dev, dtype=torch.bfloat16)
     for rnd in range(2):
         line = f'{fill} round {rnd}:'
-        for name, fl in (('base', 0), ('alias', 256), ('nosync', 512), ('alias+nosync', 768)):
+        for name, fl in (('base', 0), ('stagger', 1024), ('alias', 256), ('nosync', 512), ('alias+nosync', 768), ('stagger+nosync', 1536)):
             t = timeit(lambda: lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, fl, 0, 0,
                                         ops._s()))
             line += f'  {name}: {t*1e3:.1f} us {flops / t / 1e9:.0f} TF'
         print(line, flush=True)
+outs = []
+for fl in (0, 1024):
+    lib.call('conv3d_fwd', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, grid, grid, grid, cin, cout, cout, k, 1, fl, 0, 0, ops._s())
+    outs.append(y.clone())
+print('stagger == base:', torch.equal(outs[0], outs[1]), flush=True)
 x = torch.randn(1, grid, grid, grid, cin, device=dev).bfloat16()
 lib.call('set_conv_tile_m', 128)
 for kb in (64, 128):
