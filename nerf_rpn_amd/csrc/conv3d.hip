@@ -13,8 +13,6 @@
 // Replaces torch.nn.Conv3d (MIOpen/cuDNN) in reference feature_extractor.py:331-358, fpn.py:109-110, anchor.py:190-198.
 #include "common.h"
 
-#include <type_traits>
-
 typedef __attribute__((ext_vector_type(4))) float f4;
 typedef __attribute__((ext_vector_type(2))) float f2;
 typedef __attribute__((ext_vector_type(16))) float f16v;
@@ -676,7 +674,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_ws_kernel(const ConvArgs p)
 // 64 B/clk L1 path) and the number of LDS-DMA issues (8 pieces per 32 MFMAs per wave).  Two LDS buffers of 64 KB.
 // Used when Cout >= 256 and the 256x256 tiling still yields ~one workgroup per CU.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool OUTF32>
+template <bool OUTF32, bool STAG = false>
 __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p) {
   typedef bf16s T;
   constexpr int BM = 256, BN = 256, KB = 128, KE = 64, PPR = 8, RSTEP = 64, TM = 4, TN = 2;
@@ -792,25 +790,29 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   };
   // one K-step: the 8 LDS-DMA pieces of the NEXT step are issued one behind each MFMA of sub-step 0 (an LDS-DMA issue
   // costs ~60 cycles among bare MFMAs but >100 in a burst), the ds_reads of sub-step s+1 behind the MFMAs of sub-step s
-  // P = the sub-step whose MFMAs carry the 8 LDS-DMA issues of the next K-step (0, or 2 for the second wave of each SIMD when the
-  // stagger experiment is on: after the barrier both waves of a SIMD otherwise sit in their DMA-issue phase at the same time)
-  auto compute = [&](int buf, bool next_live, auto ptag) {
-    constexpr int P = decltype(ptag)::value;
+  // one K-step: the 8 LDS-DMA pieces of the NEXT step are issued one behind each MFMA of sub-step 0 (an LDS-DMA issue
+  // costs ~60 cycles among bare MFMAs but >100 in a burst), the ds_reads of sub-step s+1 behind the MFMAs of sub-step s.
+  // STAG (experiment): the two waves of a SIMD leave the barrier together and would both sit in their DMA-issue phase at once;
+  // waves 4-7 issue theirs as one burst before sub-step 2 instead (a wave-uniform branch cannot be interleaved by the scheduler).
+  const bool late_issue = STAG && wave_u >= 4;
+  auto compute = [&](int buf, bool next_live) {
     const char *A = lds + buf * (A_BYTES + B_BYTES);
     const char *B = A + A_BYTES;
     f4 af[2][TM], bfv[2][TN];
     load_frags(A, B, 0, af[0], bfv[0]);
     __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-    if (P == 0) issue(buf ^ 1, next_live);
+    if (!STAG) issue(buf ^ 1, next_live);
 #pragma unroll
     for (int s = 0; s < KB / 32; ++s) {
       if (s + 1 < KB / 32) load_frags(A, B, s + 1, af[(s + 1) & 1], bfv[(s + 1) & 1]);
-      if (P == s && s > 0) issue(buf ^ 1, next_live);
+      if (STAG && (s == 0 || s == 2)) {
+        if ((s == 2) == late_issue) issue(buf ^ 1, next_live);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[s & 1][i], bfv[s & 1][j]);
-      if (s == P) {
+      if (!STAG && s == 0) {
 #pragma unroll
         for (int q = 0; q < TM * TN; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -829,14 +831,12 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
       }
     }
   };
-  const bool late_issue = (p.flags & NRPN_CONV_DEBUG_STAGGER) && wave_u >= 4;
 
   issue(0, ks_begin < nk);
   __syncthreads();
 #pragma unroll 1
   for (int ks = ks_begin; ks < nk; ++ks) {
-    if (late_issue) compute((ks - ks_begin) & 1, ks + 1 < nk, std::integral_constant<int, 2>{});
-    else compute((ks - ks_begin) & 1, ks + 1 < nk, std::integral_constant<int, 0>{});
+    compute((ks - ks_begin) & 1, ks + 1 < nk);
     if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
   }
 
@@ -1033,7 +1033,10 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   if (huge) {
     if constexpr (MODE == 0 && sizeof(T) == 2) {
       const size_t lds_ = 2 * (size_t)(256 + 256) * 128;
-      if (out_f32) {
+      if (!out_f32 && (a.flags & NRPN_CONV_DEBUG_STAGGER)) {
+        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_big_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        hipLaunchKernelGGL((conv_igemm_big_kernel<false, true>), grid, dim3(512), lds_, st, a);
+      } else if (out_f32) {
         NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
         hipLaunchKernelGGL(conv_igemm_big_kernel<true>, grid, dim3(512), lds_, st, a);
       } else {
