@@ -237,6 +237,8 @@ int nrpn_set_conv_lds_dma(int on);
 /* tuning knob: tile of the bf16 k1/k3 LDS-DMA kernel -- 0 = per shape, 128 = 128x128 (two workgroups per CU), 256 = wave-specialised
  * 256x128 (4 MFMA + 4 LDS-DMA waves), 512 = 256x256 with 8 waves (default for Cout >= 256 when it yields >= 200 workgroups) */
 int nrpn_set_conv_tile_m(int bm);
+/* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
+int nrpn_set_conv_stagger(int on);
 /* tuning knob: 1 (default) = mid-size grids (16..199 tiles of 256x256) run the 256x256 kernel on K slices; 0 = 128-row kernel */
 int nrpn_set_conv_big_split(int on);
 /* tuning knob: 1 (default) = 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256; 0 = always the 128x128 kernel */

@@ -166,8 +166,8 @@ def test_maxpool(cfg, dtype, ch, dev):
     yh = ops.MaxPoolFn.apply(xh, k, s, p, ceil_mode)
     assert torch.equal(cf(yh.detach().float().cpu()), y.detach())
     yh.backward(cl(gy).to(dev).to(dtype))
-    # overlapping windows (3/2/1) add up to 8 gradients per voxel: exact in fp32, one bf16 rounding of the sum otherwise
-    assert torch.allclose(cf(xh.grad.float().cpu()), xr.grad, atol=1e-6 if dtype == torch.float32 else 3e-2, rtol=0 if dtype == torch.float32 else 1e-2)
+    # overlapping windows (3/2/1) add up to 8 gradients per voxel: fp32 summation order vs torch's, one bf16 rounding of the sum otherwise
+    assert torch.allclose(cf(xh.grad.float().cpu()), xr.grad, atol=1e-5 if dtype == torch.float32 else 3e-2, rtol=0 if dtype == torch.float32 else 1e-2)
 
 
 @pytest.mark.parametrize("sizes", [((10, 10, 10), (5, 5, 5)), ((9, 7, 5), (5, 4, 3)), ((33, 20, 7), (17, 10, 4))])
