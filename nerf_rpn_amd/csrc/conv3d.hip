@@ -1487,7 +1487,6 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 // bytes pulled through the CU's vector-memory path per MFMA (the 128x128 tile moves 32 KB per 16 MFMAs per wave and saturates
 // it).  One workgroup = (cout tile, cin tile, tap, voxel slice); fp32 atomics into the packed gradient.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool STAG>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs p) {
   typedef bf16s T;
   constexpr int KV = 64, RS = 256, SUB = KV * RS;            // 16 KB sub-tile
@@ -1580,12 +1579,10 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   issue_dma(0);
   __syncthreads();
   int buf = 0;
-  // STAG: waves 4-7 (the second wave of every SIMD) issue the next chunk's DMA after the second of the four sub-steps instead of at the
-  // top of the chunk, so the two waves of a SIMD are not in their DMA-issue burst at the same time (cf. conv_igemm_big_kernel)
-  const bool late_issue = STAG && wave_u >= 4;
+  // (issuing the DMA of waves 4-7 later in the chunk, as conv_igemm_big_kernel does, was measured 10 % SLOWER here: 208 -> 229 us)
 #pragma unroll 1
   for (long long ch = c_begin; ch < c_end; ++ch) {
-    if (ch + 1 < c_end && !late_issue) issue_dma(buf ^ 1);
+    if (ch + 1 < c_end) issue_dma(buf ^ 1);
     const char *base = lds + buf * 4 * SUB;
     const char *A = base + wm * SUB;
     const char *B = base + (2 + (wn >> 1)) * SUB;
@@ -1610,7 +1607,6 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
 #pragma unroll
     for (int q = 0; q < KV / KSUB; ++q) {
-      if (STAG && q == 2 && late_issue && ch + 1 < c_end) issue_dma(buf ^ 1);
       if (q + 1 < KV / KSUB) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfv[(q + 1) & 1][j] = wg_frag<T, true>(B, (wn & 1) * 64 + j * 32, (q + 1) * KSUB, lane);
@@ -2025,13 +2021,12 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
     a.ntiles_n = (cin + 255) / 256;
     const int tiles = ((wrows + 255) / 256) * a.ntiles_n * a.taps;
     const size_t lds = 2 * 4 * (size_t)64 * 256;
-    if (g_conv_stagger) {
-      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(conv_wgrad_big_kernel<true>, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
-    } else {
-      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(conv_wgrad_big_kernel<false>, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
+    static bool done = false;
+    if (!done) {
+      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      done = true;
     }
+    hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
     NRPN_LAUNCH_CHECK("conv_wgrad_big");
   }
   if (rc || !gbias || defer_bias) return rc;
