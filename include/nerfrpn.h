@@ -61,6 +61,11 @@ int nrpn_iou3d_obb_pair_f32(const float *b1, const float *b2, float *iou, int64_
  * vertex sort / arg-min selections on the values, which is what autograd differentiates in the reference's 40-kernel chain. */
 int nrpn_rotated_iou_loss_f32(const float *pred, const float *target, int64_t n, int mode, float *loss, float *grad, float *iou,
                               nrpn_stream_t stream);
+/* 2-D projection smooth-L1 of the RPN, VALUE only (model/rpn.py:37-102 get_w2cs / project / obb2points_3d, 421-453): pred, target [n,box_dim]
+ *   (6: AABB corners, 7: OBB), views [4][4][4] world->camera, intrinsics [3][3] -> out[0] = sum smooth_l1(uv_pred - uv_target; beta) / n /
+ *   max_mesh_dim over 2 extreme points x 4 views x (u,v).  One workgroup, fixed summation order. */
+int nrpn_projection_loss_f32(const float *pred, const float *target, int64_t n, int box_dim, const float *views, const float *intrinsics,
+                             float beta, float max_mesh_dim, float *out, nrpn_stream_t stream);
 /* all pairs: a [n,w], b [m,w] -> iou [n,m]; w = 6 (AABB x1..z2) or 7 (OBB)   (box_iou_3d, model/utils.py:387-458) */
 int nrpn_iou3d_matrix_f32(const float *a, const float *b, float *iou, int64_t n, int64_t m, int box_dim,
                           nrpn_stream_t stream);
@@ -156,6 +161,14 @@ int nrpn_match_anchors_f32(const int32_t *table, int64_t total_anchors, const fl
 /* obb2hbb_3d: [n,7] -> [n,6] */
 int nrpn_obb_to_aabb_f32(const float *obb, float *aabb, int64_t n, nrpn_stream_t stream);
 
+/* Balanced positive / negative sampler (BalancedPositiveNegativeSampler, model/utils.py:35-98): labels [total] f32 (>= 1 positive, 0 negative,
+ *   < 0 ignored) -> out_pos [max_pos], out_neg [batch] int64 ascending + counts int32[3] = {num_pos, num_neg, error}, with
+ *   num_pos = min(#pos, max_pos), num_neg = min(#neg, batch - num_pos) and each subset uniformly random: the k smallest
+ *   (splitmix64(seed, index) >> 32, index) of the class.  No host read-back inside (the reference needs two torch.where sizes and
+ *   two randperm sorts per scene); the result depends on (labels, seed) only.  workspace: nrpn_sample_workspace_bytes(), 8-byte aligned. */
+size_t nrpn_sample_workspace_bytes(void);
+int nrpn_sample_pos_neg(const float *labels, int64_t total, int max_pos, int batch, int64_t seed, void *workspace, int64_t *out_pos,
+                        int64_t *out_neg, int32_t *counts, nrpn_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Sampled RPN losses with fused backward.  [a20]  (compute_loss, rpn.py:372-419)
  *   logits [T], deltas [T,dw], targets [npos,dw] (already encoded for the sampled positives), pos/neg int64 index

@@ -280,7 +280,83 @@ __global__ void rotated_iou_loss_kernel(const float *__restrict__ pred, const fl
   for (int k = 0; k < 7; ++k) grad[i * 7 + k] = l.g[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 2-D projection smooth-L1 of the RPN (reference model/rpn.py:37-102 get_w2cs / project / obb2points_3d, 421-453): the two extreme
+// points of every predicted and matched ground-truth box are projected into the four fixed views (camera = M @ [x y z 1]^T,
+// picture = K @ camera[:3], (u, v) = picture[:2] / picture[2]) and compared with smooth-L1, summed, / n / max_mesh_dim.  VALUE
+// only (the reported loss_rpn_box_reg_2d when its weight is 0, the reference default): one workgroup, fixed summation order.
+// The torch formulation -- ~45 launches for <= 128 boxes -- remains the path when the term is trained through.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void box_point(const float *b, int box_dim, int e, float &x, float &y, float &z) {
+  if (box_dim == 6) {   // AABB: min corner, max corner
+    x = b[3 * e]; y = b[3 * e + 1]; z = b[3 * e + 2];
+    return;
+  }
+  const float c = cosf(b[6]), s = sinf(b[6]);
+  const float vx = b[3] / 2 * c - b[4] / 2 * s, vy = b[3] / 2 * s + b[4] / 2 * c, vz = b[5] / 2;
+  const float sg = e ? 1.f : -1.f;
+  x = b[0] + sg * vx; y = b[1] + sg * vy; z = b[2] + sg * vz;
+}
+
+__device__ __forceinline__ void view_uv(const float *M, const float *K, float x, float y, float z, float &u, float &v) {
+  float cam[3], pic[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) cam[r] = M[r * 4] * x + M[r * 4 + 1] * y + M[r * 4 + 2] * z + M[r * 4 + 3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) pic[r] = K[r * 3] * cam[0] + K[r * 3 + 1] * cam[1] + K[r * 3 + 2] * cam[2];
+  u = pic[0] / pic[2];
+  v = pic[1] / pic[2];
+}
+
+__device__ __forceinline__ float smooth_l1(float d, float beta) {
+  const float a = fabsf(d);
+  return a < beta ? 0.5f * d * d / beta : a - 0.5f * beta;
+}
+
+__global__ void __launch_bounds__(256) projection_loss_kernel(const float *__restrict__ pred, const float *__restrict__ target, long long n, int box_dim,
+                                                              const float *__restrict__ views, const float *__restrict__ intr, float beta,
+                                                              float max_mesh_dim, float *__restrict__ out) {
+  __shared__ float red[256];
+  __shared__ float Ms[64], Ks[9];
+  if (threadIdx.x < 64) Ms[threadIdx.x] = views[threadIdx.x];
+  if (threadIdx.x < 9) Ks[threadIdx.x] = intr[threadIdx.x];
+  __syncthreads();
+  float acc = 0.f;
+  for (long long item = threadIdx.x; item < 2 * n; item += 256) {
+    const long long b = item >> 1;
+    const int e = (int)(item & 1);
+    float px, py, pz, tx, ty, tz;
+    box_point(pred + b * box_dim, box_dim, e, px, py, pz);
+    box_point(target + b * box_dim, box_dim, e, tx, ty, tz);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float pu, pv, tu, tv;
+      view_uv(Ms + v * 16, Ks, px, py, pz, pu, pv);
+      view_uv(Ms + v * 16, Ks, tx, ty, tz, tu, tv);
+      acc += smooth_l1(pu - tu, beta) + smooth_l1(pv - tv, beta);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)n / max_mesh_dim;
+}
+
 }  // namespace
+
+extern "C" int nrpn_projection_loss_f32(const float *pred, const float *target, int64_t n, int box_dim, const float *views, const float *intrinsics,
+                                        float beta, float max_mesh_dim, float *out, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n >= 0 && (box_dim == 6 || box_dim == 7) && beta > 0.f && max_mesh_dim > 0.f, "projection_loss: bad arguments (n=%lld box_dim=%d)",
+               (long long)n, box_dim);
+  NRPN_REQUIRE(views && intrinsics && out && (n == 0 || (pred && target)), "projection_loss: null pointer");
+  hipLaunchKernelGGL(projection_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), pred, target, (long long)n, box_dim, views, intrinsics, beta,
+                     max_mesh_dim, out);
+  NRPN_LAUNCH_CHECK("projection_loss");
+  return NRPN_OK;
+}
 
 extern "C" int nrpn_rotated_iou_loss_f32(const float *pred, const float *target, int64_t n, int mode, float *loss, float *grad, float *iou,
                                          nrpn_stream_t stream) {

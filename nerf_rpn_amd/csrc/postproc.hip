@@ -885,6 +885,171 @@ extern "C" int nrpn_match_anchors_f32(const int32_t *table, int64_t total_anchor
 }
 
 // =====================================================================================================================
+// Balanced positive / negative sampler (reference BalancedPositiveNegativeSampler, model/utils.py:35-98: positives = labels >= 1,
+// negatives = labels == 0, num_pos = min(#pos, batch * fraction), num_neg = min(#neg, batch - num_pos), a uniformly random subset of
+// each via torch.randperm).  The reference's formulation costs two host read-backs (torch.where sizes) and a device sort of ~10^6
+// random keys per scene; here every anchor gets a 32-bit key = splitmix64(seed, index) and the k smallest (key, index) of a class ARE
+// a uniformly random k-subset: a 4096-bin histogram of the keys' top 12 bits finds the bin the k-th smallest falls into, everything
+// below that bin is taken, the bin itself (~count / 4096 candidates) is sorted in LDS for the remainder, and the selected indices are
+// sorted ascending (what torch.where order gives the reference's masks).  Integer atomics only: the result is a function of
+// (labels, seed), independent of scheduling.  Outputs: pos [max_pos], neg [batch] int64 ascending, counts = {num_pos, num_neg, error}.
+// =====================================================================================================================
+constexpr int kSampBins = 4096, kSampCap = 8192;
+// workspace int32: hist[2][kSampBins] | cursor[2] bcursor[2] thr[2] need[2] k[2] below[2] err pad[3] | (8-byte aligned) boundary u64 [2][kSampCap]
+constexpr int kSampParams = 2 * kSampBins, kSampInts = 2 * kSampBins + 16;
+
+__host__ __device__ __forceinline__ uint32_t sample_key(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+constexpr uint64_t kSampNegSeed = 0xD1B54A32D192ED03ull;
+
+__device__ __forceinline__ int sample_class(float lab) { return lab >= 1.f ? 0 : (lab == 0.f ? 1 : -1); }
+
+__global__ void __launch_bounds__(256) sample_hist_kernel(const float *__restrict__ labels, int64_t total, uint64_t seed, int *__restrict__ ws) {
+  __shared__ int h[2 * kSampBins];
+  for (int b = threadIdx.x; b < 2 * kSampBins; b += 256) h[b] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = sample_class(labels[i]);
+    if (c < 0) continue;
+    const uint32_t key = sample_key(c ? seed ^ kSampNegSeed : seed, (uint64_t)i);
+    atomicAdd(&h[c * kSampBins + (key >> 20)], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < 2 * kSampBins; b += 256)
+    if (h[b]) atomicAdd(&ws[b], h[b]);
+}
+
+__global__ void __launch_bounds__(1024) sample_threshold_kernel(int *__restrict__ ws, int max_pos, int batch) {
+  __shared__ int scan[1024];
+  __shared__ int kk[2];
+  int *par = ws + kSampParams;
+  for (int c = 0; c < 2; ++c) {
+    const int *h = ws + c * kSampBins;
+    const int b0 = threadIdx.x * 4;
+    const int v0 = h[b0], v1 = h[b0 + 1], v2 = h[b0 + 2], v3 = h[b0 + 3];
+    scan[threadIdx.x] = v0 + v1 + v2 + v3;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele scan over the 1024 four-bin groups
+      const int add = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      scan[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int total = scan[1023];
+    if (threadIdx.x == 0) {
+      kk[c] = c == 0 ? min(total, max_pos) : min(total, batch - kk[0]);
+      par[8 + c] = kk[c];
+      if (kk[c] == 0) { par[4 + c] = -1; par[6 + c] = 0; par[10 + c] = 0; }
+      if (kk[c] == total && total > 0) { par[4 + c] = kSampBins; par[6 + c] = 0; par[10 + c] = total; }
+    }
+    __syncthreads();
+    const int k = kk[c];
+    if (k > 0 && k < total) {
+      int cum = scan[threadIdx.x] - (v0 + v1 + v2 + v3);       // exclusive prefix of this thread's first bin
+      const int vs[4] = {v0, v1, v2, v3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cum < k && cum + vs[j] >= k) { par[4 + c] = b0 + j; par[6 + c] = k - cum; par[10 + c] = cum; }
+        cum += vs[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) sample_collect_kernel(const float *__restrict__ labels, int64_t total, uint64_t seed, int *__restrict__ ws,
+                                                             unsigned long long *__restrict__ boundary, int64_t *__restrict__ out_pos,
+                                                             int64_t *__restrict__ out_neg) {
+  int *par = ws + kSampParams;
+  const int thr0 = par[4], thr1 = par[5];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = sample_class(labels[i]);
+    if (c < 0) continue;
+    const uint32_t key = sample_key(c ? seed ^ kSampNegSeed : seed, (uint64_t)i);
+    const int bin = (int)(key >> 20), thr = c ? thr1 : thr0;
+    if (bin < thr) {
+      const int slot = atomicAdd(&par[c], 1);
+      (c ? out_neg : out_pos)[slot] = i;
+    } else if (bin == thr) {
+      const int slot = atomicAdd(&par[2 + c], 1);
+      if (slot < kSampCap) boundary[(size_t)c * kSampCap + slot] = ((unsigned long long)key << 32) | (unsigned long long)i;
+    }
+  }
+}
+
+__device__ void bitonic_sort_u64(unsigned long long *a, int n2) {       // n2 = power of two, all threads of the workgroup participate
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < n2; t += blockDim.x) {
+        const int x = t ^ j;
+        if (x > t) {
+          const unsigned long long u = a[t], v = a[x];
+          if (((t & k) == 0) ? (u > v) : (u < v)) { a[t] = v; a[x] = u; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(1024) sample_finish_kernel(int *__restrict__ ws, const unsigned long long *__restrict__ boundary,
+                                                             int64_t *__restrict__ out_pos, int64_t *__restrict__ out_neg, int32_t *__restrict__ counts) {
+  __shared__ unsigned long long a[kSampCap];
+  const int c = blockIdx.x;
+  int *par = ws + kSampParams;
+  int64_t *out = c ? out_neg : out_pos;
+  const int k = par[8 + c], need = par[6 + c], below = par[10 + c];
+  const int nb = par[2 + c];
+  if (nb > kSampCap || (need > 0 && nb < need) || par[c] != below) {      // more candidates in one bin than the LDS sort holds / inconsistent counts
+    if (threadIdx.x == 0) counts[2] = 1;
+    return;
+  }
+  if (need > 0) {
+    int n2 = 1;
+    while (n2 < nb) n2 <<= 1;
+    for (int t = threadIdx.x; t < n2; t += blockDim.x) a[t] = t < nb ? boundary[(size_t)c * kSampCap + t] : ~0ull;
+    __syncthreads();
+    bitonic_sort_u64(a, n2);
+    for (int t = threadIdx.x; t < need; t += blockDim.x) out[below + t] = (int64_t)(a[t] & 0xffffffffull);
+    __syncthreads();
+  }
+  __threadfence_block();
+  int n2 = 1;
+  while (n2 < k) n2 <<= 1;
+  for (int t = threadIdx.x; t < n2; t += blockDim.x) a[t] = t < k ? (unsigned long long)out[t] : ~0ull;
+  __syncthreads();
+  bitonic_sort_u64(a, n2);
+  for (int t = threadIdx.x; t < k; t += blockDim.x) out[t] = (int64_t)a[t];
+  if (threadIdx.x == 0) counts[c] = k;
+}
+
+extern "C" size_t nrpn_sample_workspace_bytes(void) { return (size_t)kSampInts * 4 + (size_t)2 * kSampCap * 8; }
+
+extern "C" int nrpn_sample_pos_neg(const float *labels, int64_t total, int max_pos, int batch, int64_t seed, void *workspace, int64_t *out_pos,
+                                   int64_t *out_neg, int32_t *counts, nrpn_stream_t stream) {
+  NRPN_REQUIRE(total > 0 && total < (1ll << 31), "sample: total=%lld outside (0, 2^31)", (long long)total);
+  NRPN_REQUIRE(max_pos >= 0 && batch >= max_pos && batch <= kSampCap, "sample: need 0 <= max_pos <= batch <= %d (got %d, %d)", kSampCap, max_pos, batch);
+  NRPN_REQUIRE(labels && workspace && out_pos && out_neg && counts, "sample: null pointer");
+  hipStream_t st = as_stream(stream);
+  int *ws = reinterpret_cast<int *>(workspace);
+  unsigned long long *boundary = reinterpret_cast<unsigned long long *>(ws + kSampInts);
+  NRPN_HIP(hipMemsetAsync(ws, 0, (size_t)kSampInts * 4, st));
+  NRPN_HIP(hipMemsetAsync(counts, 0, 3 * 4, st));
+  const unsigned blocks = (unsigned)std::min<int64_t>(cdiv64(total, 256 * 8), 2048);
+  const uint64_t useed = (uint64_t)seed;
+  hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, labels, total, useed, ws);
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3(1), dim3(1024), 0, st, ws, max_pos, batch);
+  hipLaunchKernelGGL(sample_collect_kernel, dim3(blocks), dim3(256), 0, st, labels, total, useed, ws, boundary, out_pos, out_neg);
+  hipLaunchKernelGGL(sample_finish_kernel, dim3(2), dim3(1024), 0, st, ws, boundary, out_pos, out_neg, counts);
+  NRPN_LAUNCH_CHECK("sample_pos_neg");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
 // Sampled losses (<= a few hundred rows): one workgroup, wave shuffles + LDS for the two reductions, gradients
 // written straight into the (caller-zeroed) dense gradient buffers of the head outputs.
 // =====================================================================================================================

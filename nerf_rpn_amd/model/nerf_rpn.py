@@ -60,11 +60,15 @@ class NeRFRegionProposalNetwork(nn.Module):
                             mode="constant", value=0) for m in meshes]
         return meshes, targets
 
+    @staticmethod
+    def _degenerate(boxes):
+        return boxes[:, 3:] <= boxes[:, :3] if boxes.shape[1] == 6 else boxes[:, 3:6] <= 0
+
     def check_bbox_degeneration(self, targets):
         if targets is None:
             return
         for target_idx, boxes in enumerate(targets):
-            bad = boxes[:, 3:] <= boxes[:, :3] if boxes.shape[1] == 6 else boxes[:, 3:6] <= 0
+            bad = self._degenerate(boxes)
             if bad.any():
                 bb = boxes[torch.where(bad.any(dim=1))[0][0]].tolist()
                 torch._assert(False, "All bounding boxes should have positive height, width and depth."
@@ -86,15 +90,21 @@ class NeRFRegionProposalNetwork(nn.Module):
             torch._assert(len(val) == 3, f"expecting the last three dimensions of the Tensor to be W, H and D instead got {mesh.shape[-3:]}")
             original_mesh_sizes.append((int(val[0]), int(val[1]), int(val[2])))
         meshes, targets = self.transform(list(meshes), targets)
-        self.check_bbox_degeneration(targets)
+        early = self.training and hasattr(self.backbone, "feature_grids")
+        if not early:
+            self.check_bbox_degeneration(targets)
         mesh_tensors = ops.stack_scenes(meshes)
         prepared = None
-        if self.training and hasattr(self.backbone, "feature_grids"):
-            # target assignment + sampling (the only host read-backs of a training step) are issued before the backbone: the rest
-            # of the step is then enqueued without a synchronisation (see RegionProposalNetwork.prepare_targets)
+        if early:
+            # target assignment + sampling are issued before the backbone and hold the ONE host read-back of a training step (the sampled
+            # counts); the degenerate-box check rides on that copy as device flags instead of synchronising on its own.  The rest of
+            # the step is then enqueued without a synchronisation (see RegionProposalNetwork.prepare_targets)
             size = tuple(int(v) for v in mesh_tensors.shape[-3:])
+            flags = [self._degenerate(b).any() for b in targets if b.is_cuda and b.numel()]
             prepared = self.rpn.prepare_targets(size, [tuple(g) for g in self.backbone.feature_grids(size)], targets,
-                                                original_mesh_sizes, mesh_tensors.device)
+                                                original_mesh_sizes, mesh_tensors.device, flags)
+            if prepared["flags"] is None or any(prepared["flags"]) or len(prepared["flags"]) != len(targets):
+                self.check_bbox_degeneration(targets)         # raises with the offending box (or covers what the flags did not)
         features = list(self.backbone(mesh_tensors))
         proposals, level_index, proposal_losses, scores = self.rpn(mesh_tensors, features, original_mesh_sizes, targets,
                                                                    objectness_output_paths, prepared)

@@ -182,7 +182,7 @@ class RegionProposalNetwork(nn.Module):
             matched.append(m)
         return labels, matched
 
-    def prepare_targets(self, mesh_size, grids, targets: List[Tensor], original_mesh_sizes, device):
+    def prepare_targets(self, mesh_size, grids, targets: List[Tensor], original_mesh_sizes, device, pending_flags=None):
         """Everything of the training loss that does not depend on the network output: anchor table, IoU + matcher labels, the
         sampled positives / negatives, their matched ground truth, regression targets and anchors.  The model calls this BEFORE the
         backbone is enqueued: the sampler's host read-backs (torch.where / randperm sizes) then happen while the GPU has nothing
@@ -193,15 +193,15 @@ class RegionProposalNetwork(nn.Module):
         pad = self.anchor_generator.padding_mask(mesh_size, grids, original_mesh_sizes, device) if n > 1 else None
         labels, matched = self.assign_targets_to_anchors(table, targets, original_mesh_sizes if n > 1 else None, pad)
         T = table.total
+        flags = None
         if self.sampler_hook is not None:
             pos, neg = self.sampler_hook(labels)
         else:
-            ps, ns = [], []
-            for i, lab in enumerate(labels):
-                p, q = self.fg_bg_sampler.sample_indices(lab)
-                ps.append(p + i * T)
-                ns.append(q + i * T)
-            pos, neg = torch.cat(ps), torch.cat(ns)
+            pairs, flags = self.fg_bg_sampler.sample_batch(labels, pending_flags)     # the one host read-back of a training step
+            if n == 1:
+                pos, neg = pairs[0]
+            else:
+                pos, neg = torch.cat([p + i * T for i, (p, _) in enumerate(pairs)]), torch.cat([q + i * T for i, (_, q) in enumerate(pairs)])
         pos, neg = pos.to(device), neg.to(device)
         if self.sampler_hook is not None or n > 1:      # sample_indices already returns ascending indices per scene
             pos, neg = pos.sort()[0], neg.sort()[0]
@@ -225,7 +225,7 @@ class RegionProposalNetwork(nn.Module):
         reg_targets = ops.encode_boxes(table, matched_gt, local, int(self.rotate))
         anchors_pos = ops.anchors(table, local)
         return dict(mesh_size=tuple(mesh_size), grids=[tuple(g) for g in grids], table=table, pad=pad, labels=labels, matched=matched,
-                    pos=pos, neg=neg, matched_gt=matched_gt, reg_targets=reg_targets, anchors_pos=anchors_pos)
+                    flags=flags, pos=pos, neg=neg, matched_gt=matched_gt, reg_targets=reg_targets, anchors_pos=anchors_pos)
 
     def compute_loss(self, prep, logits, deltas, max_mesh_dim):
         """reference rpn.py:372-456 on the sampled rows only."""
@@ -251,6 +251,8 @@ class RegionProposalNetwork(nn.Module):
         M @ [x y z 1]^T, picture = K @ camera[:3], u,v = picture[:2] / picture[2] -- batched over the 4 cameras and over
         prediction + target points (2 batched matmuls + 1 divide instead of 16 matmuls, 8 divides and 10 concatenations)."""
         M, K = _view_stack(max_mesh_dim, pred.device)
+        if pred.is_cuda and not (pred.requires_grad and torch.is_grad_enabled()):
+            return ops.projection_loss(pred, target, M, K, 1.0 / 9, float(max_mesh_dim))    # one launch instead of ~45
         if target.size(1) == 6:
             p = torch.cat([pred[:, :3], pred[:, 3:]], dim=0)
             t = torch.cat([target[:, :3], target[:, 3:]], dim=0)

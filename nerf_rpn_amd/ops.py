@@ -105,6 +105,58 @@ def rotated_iou_loss(pred, target, mode):
     return RotatedIoULossFn.apply(pred, target, mode)
 
 
+_SAMPLE_WS = {}
+
+
+def sample_pos_neg(labels, batch, max_pos, seed, extra_flags=None):
+    """Balanced sampler of every scene in ONE host read-back (reference BalancedPositiveNegativeSampler, model/utils.py:35-98).
+    labels: list of [T] float32 device tensors; seed: python int (one draw per call; scene i uses seed + i).
+    -> ([(pos_i, neg_i)], host list of ``extra_flags``): int64 ascending index tensors; ``extra_flags`` (a list of 0-dim device tensors)
+    ride on the same device->host copy so that callers with their own pending checks do not synchronise a second time."""
+    n = len(labels)
+    dev = labels[0].device
+    for lab in labels:
+        if lab.dtype != torch.float32 or lab.dim() != 1:
+            raise TypeError("sample_pos_neg: labels must be 1-D float32")
+        _chk(lab.contiguous())
+    wsb = int(lib.query("sample_workspace_bytes"))
+    key = (str(dev), n, batch, max_pos)
+    if key not in _SAMPLE_WS:          # per-scene scratch, reused every step (stream-ordered)
+        _SAMPLE_WS[key] = torch.empty((n, (wsb + 7) // 8), dtype=torch.int64, device=dev)
+    ws = _SAMPLE_WS[key]
+    out_pos = torch.empty((n, max(max_pos, 1)), dtype=torch.int64, device=dev)
+    out_neg = torch.empty((n, max(batch, 1)), dtype=torch.int64, device=dev)
+    nx = len(extra_flags) if extra_flags else 0
+    counts = torch.empty(n * 3 + nx, dtype=torch.int32, device=dev)
+    for i, lab in enumerate(labels):
+        call("sample_pos_neg", _p(lab.contiguous()), lab.numel(), int(max_pos), int(batch), (int(seed) + i) & 0x7FFFFFFFFFFFFFFF, _p(ws[i]),
+             _p(out_pos[i]), _p(out_neg[i]), _p(counts[3 * i:]), _s())
+    if nx:
+        counts[3 * n:] = torch.stack([f.reshape(()) for f in extra_flags]).to(torch.int32)
+    host = counts.cpu().tolist()                      # the one synchronisation
+    res = []
+    for i in range(n):
+        kp, kn, err = host[3 * i:3 * i + 3]
+        if err:
+            raise RuntimeError("sample_pos_neg: a key bin holds more candidates than the kernel's LDS sort (see nrpn_sample_pos_neg)")
+        res.append((out_pos[i, :kp], out_neg[i, :kn]))
+    return res, host[3 * n:]
+
+
+def projection_loss(pred, target, views, intrinsics, beta, max_mesh_dim):
+    """2-D projection smooth-L1 of the RPN (value only, no gradient): pred / target [n,6|7], views [4,4,4], intrinsics [3,3] -> scalar
+    (reference rpn.py:37-102, 421-453)."""
+    if pred.shape != target.shape or pred.shape[1] not in (6, 7):
+        raise ValueError(f"projection_loss: pred {tuple(pred.shape)} and target {tuple(target.shape)} must both be [n,6] or [n,7]")
+    pred, target = _f32(pred.detach()).contiguous(), _f32(target.detach()).contiguous()
+    views, intrinsics = views.contiguous(), intrinsics.contiguous()
+    _chk(pred, target, views, intrinsics)
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    call("projection_loss_f32", _p(pred), _p(target), pred.shape[0], pred.shape[1], _p(views), _p(intrinsics), float(beta), float(max_mesh_dim),
+         _p(out), _s())
+    return out[0]
+
+
 def iou3d_matrix(a, b):
     """All-pairs IoU [n,w] x [m,w] -> [n,m], w = 6 (AABB) or 7 (OBB) (reference box_iou_3d)."""
     if a.shape[1] != b.shape[1] or a.shape[1] not in (6, 7):

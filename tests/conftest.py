@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 # Kernel-level oracle / torch parity first, composed paths after: with `-x` one red end-to-end test must not hide the kernel tests.
 _ORDER = ["test_oracle_golden", "test_abi_and_host", "test_harness_cpu", "test_dist_gloo", "test_gpu_postproc", "test_gpu_conv",
-          "test_gpu_geomloss", "test_gpu_swin", "test_gpu_fcos", "test_gpu_aug", "test_gpu_roialign", "test_gpu_detector", "test_gpu_e2e", "test_gpu_trainer",
+          "test_gpu_geomloss", "test_gpu_sampler", "test_gpu_swin", "test_gpu_fcos", "test_gpu_aug", "test_gpu_roialign", "test_gpu_detector", "test_gpu_e2e", "test_gpu_trainer",
           "test_gpu_fullsize", "test_gpu_harness", "test_gpu_rccl"]
 
 

@@ -99,3 +99,23 @@ def test_loss_classes_use_the_fused_kernel(dev, monkeypatch):
         calls.clear()
         RotatedIOULoss(mode)(p, b2.to(dev)).backward()
         assert calls == ["rotated_iou_loss_f32"], calls
+
+
+@pytest.mark.parametrize("box_dim", [7, 6])
+def test_projection_loss_kernel_matches_torch_chain(box_dim, dev):
+    """nrpn_projection_loss_f32 (one launch) against the torch formulation of reference rpn.py:37-102, 421-453 (batched matmuls) that
+    stays the path when the term carries a gradient; both on the device, plus the empty case (0/0 like the torch chain)."""
+    from nerf_rpn_amd.model.rpn import RegionProposalNetwork, _view_stack
+    b1, b2 = rand_pairs(117, 11)
+    if box_dim == 6:
+        b1 = torch.cat([b1[:, :3] - b1[:, 3:6] / 2, b1[:, :3] + b1[:, 3:6] / 2], dim=1)
+        b2 = torch.cat([b2[:, :3] - b2[:, 3:6] / 2, b2[:, :3] + b2[:, 3:6] / 2], dim=1)
+    p, t = b1.to(dev), b2.to(dev)
+    fused = RegionProposalNetwork._projection_loss(None, p, t, 160)
+    chain = RegionProposalNetwork._projection_loss(None, p.clone().requires_grad_(True), t, 160)
+    assert chain.requires_grad and not fused.requires_grad
+    assert torch.allclose(fused, chain.detach(), rtol=2e-5, atol=1e-6), (float(fused), float(chain))
+    assert torch.equal(fused, RegionProposalNetwork._projection_loss(None, p, t, 160))          # fixed summation order
+    M, K = _view_stack(160, dev)
+    from nerf_rpn_amd import ops
+    assert torch.isnan(ops.projection_loss(p[:0], t[:0], M, K, 1.0 / 9, 160.0))
