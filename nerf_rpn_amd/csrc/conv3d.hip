@@ -834,10 +834,48 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
 
   issue(0, ks_begin < nk);
   __syncthreads();
+  if constexpr (STAG) {
+    // Rotated pipeline: the barrier that hands over the next buffer sits BEFORE the MFMAs of the last sub-step instead of after them.
+    // The fragments of sub-step 3 are in registers by then, so its 8 MFMAs run while the ds_reads of the next K-step's sub-step 0 are in
+    // flight -- in the plain loop every wave of the workgroup left the barrier with nothing to multiply until those reads returned.
+    // Same MFMA order per accumulator as the plain loop: bit-identical results.  DMA issue: waves 0-3 in sub-step 0, waves 4-7 in
+    // sub-step 1 (the two waves of a SIMD are then not both in their DMA-issue phase); both land before the barrier after sub-step 2.
+    f4 af[2][TM], bfv[2][TN];
+    load_frags(lds, lds + A_BYTES, 0, af[0], bfv[0]);
 #pragma unroll 1
-  for (int ks = ks_begin; ks < nk; ++ks) {
-    compute((ks - ks_begin) & 1, ks + 1 < nk);
-    if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
+    for (int ks = ks_begin; ks < nk; ++ks) {
+      const int buf = (ks - ks_begin) & 1;
+      const char *A = lds + buf * (A_BYTES + B_BYTES);
+      const char *B = A + A_BYTES;
+      const char *An = lds + (buf ^ 1) * (A_BYTES + B_BYTES);
+      const bool next_live = ks + 1 < nk;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        if (sub < 3) {
+          load_frags(A, B, sub + 1, af[(sub + 1) & 1], bfv[(sub + 1) & 1]);
+        } else {
+          if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
+          load_frags(An, An + A_BYTES, 0, af[0], bfv[0]);
+        }
+        if (sub < 2 && (sub == 1) == late_issue) issue(buf ^ 1, next_live);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[sub & 1][i], bfv[sub & 1][j]);
+#pragma unroll
+        for (int q = 0; q < TM + TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int ks = ks_begin; ks < nk; ++ks) {
+      compute((ks - ks_begin) & 1, ks + 1 < nk);
+      if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
+    }
   }
 
   const bool has_bias = (p.flags & NRPN_CONV_BIAS) && p.bias;

@@ -24,6 +24,7 @@ def timeit(fn, iters=30, warm=5):
 
 
 dev = torch.device('cuda:0')
+lib.call('set_conv_stagger', 0)      # 'base' = the plain loop; the 'stagger' columns select the rotated + staggered loop by flag
 grid, cin, cout, k = 40, 256, 256, 3
 flops = 2.0 * grid ** 3 * cin * cout * k ** 3
 for fill in ('randn', 'zeros'):
@@ -51,3 +52,4 @@ for kb in (64, 128):
     print(f'128x128 tile, K-step {kb} B: {t*1e3:.1f} us {flops / t / 1e9:.0f} TF', flush=True)
 lib.call('set_conv_kstep_bytes', 128)
 lib.call('set_conv_tile_m', 0)
+lib.call('set_conv_stagger', 1)
