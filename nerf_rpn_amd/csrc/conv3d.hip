@@ -1617,13 +1617,27 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   issue_dma(0);
   __syncthreads();
   int buf = 0;
-  // (issuing the DMA of waves 4-7 later in the chunk, as conv_igemm_big_kernel does, was measured 10 % SLOWER here: 208 -> 229 us)
+  // Rotated pipeline (cf. conv_igemm_big_kernel): the barrier that hands over the next chunk sits before the MFMAs of the LAST sub-step,
+  // whose fragments are already in registers; those MFMAs then cover the transpose reads of the next chunk's sub-step 0.  Same MFMA
+  // order per accumulator as the plain loop.  (Issuing the DMA of waves 4-7 later in the chunk, as the forward kernel does, was
+  // measured 10 % SLOWER here: 208 -> 229 us.)
+  constexpr int NSUB = KV / KSUB;
+  static_assert(NSUB % 2 == 0, "fragment double-buffer parity across chunks");
+  f4 af[2][TM], bfv[2][TN];
+  {
+    const char *A0 = lds + wm * SUB, *B0 = lds + (2 + (wn >> 1)) * SUB;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfv[0][j] = wg_frag<T, true>(B0, (wn & 1) * 64 + j * 32, 0, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = wg_frag<T, true>(A0, i * 32, 0, lane);
+  }
 #pragma unroll 1
   for (long long ch = c_begin; ch < c_end; ++ch) {
     if (ch + 1 < c_end) issue_dma(buf ^ 1);
     const char *base = lds + buf * 4 * SUB;
     const char *A = base + wm * SUB;
     const char *B = base + (2 + (wn >> 1)) * SUB;
+    const char *nbase = lds + (buf ^ 1) * 4 * SUB;
     if (do_bias) {
       typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
 #pragma unroll
@@ -1636,39 +1650,35 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
           for (int e = 0; e < 8; ++e) bias_acc[t][e] += bf16_bits_to_f32(h[e]);
         }
     }
-    // register double-buffered fragments: the 12 transpose reads of sub-step kb+1 ride behind the first six MFMAs of sub-step kb
-    f4 af[2][TM], bfv[2][TN];
+    // register double-buffered fragments: the 12 transpose reads of sub-step q+1 ride behind the first six MFMAs of sub-step q
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bfv[0][j] = wg_frag<T, true>(B, (wn & 1) * 64 + j * 32, 0, lane);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[0][i] = wg_frag<T, true>(A, i * 32, 0, lane);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
-#pragma unroll
-    for (int q = 0; q < KV / KSUB; ++q) {
-      if (q + 1 < KV / KSUB) {
+    for (int q = 0; q < NSUB; ++q) {
+      if (q + 1 < NSUB) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfv[(q + 1) & 1][j] = wg_frag<T, true>(B, (wn & 1) * 64 + j * 32, (q + 1) * KSUB, lane);
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[(q + 1) & 1][i] = wg_frag<T, true>(A, i * 32, (q + 1) * KSUB, lane);
+      } else {
+        __syncthreads();          // every wave has read its last fragments of this chunk; the next chunk has landed
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfv[0][j] = wg_frag<T, true>(nbase + (2 + (wn >> 1)) * SUB, (wn & 1) * 64 + j * 32, 0, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = wg_frag<T, true>(nbase + wm * SUB, i * 32, 0, lane);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[q & 1][i], bfv[q & 1][j]);
-      if (q + 1 < KV / KSUB) {
 #pragma unroll
-        for (int g = 0; g < TM + TN; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      for (int g = 0; g < TM + TN; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
     }
-    __syncthreads();
     buf ^= 1;
   }
+  __syncthreads();      // the bias reduction below reuses the LDS
 
   if (do_bias) {   // reduce the 32 row groups through LDS: one partial per column per workgroup
     float *red = reinterpret_cast<float *>(lds);
