@@ -94,7 +94,9 @@ class ConvProbe:
             n_, gx_, gy_, gz_, cin_, _, wrows_, k_ = args[4:12]
             if 2.0 * n_ * gx_ * gy_ * gz_ * cin_ * wrows_ * (k_ ** 3) < 1e10:     # only the heavy launches (>= 10 GFLOP) are timed
                 return orig(name, *args)
-            if self.only is not None and (name, (n_ * gx_ * gy_ * gz_, cin_, wrows_, k_)) != self.only:
+            if self.only is not None and ((name, (n_ * gx_ * gy_ * gz_, cin_, wrows_, k_)) != self.only or not torch.is_grad_enabled()):
+                # timed region: forward-pass launches of the dominant kernel only (autograd runs the backward with grad mode off); its
+                # dgrad launches share the GPU with the weight-gradient side stream, so their wall time is not a kernel duration
                 return orig(name, *args)
             a = torch.cuda.Event(enable_timing=True)
             b = torch.cuda.Event(enable_timing=True)
@@ -358,6 +360,7 @@ def main():
     torch.cuda.synchronize()
     probe.enabled = not args.no_probe
     from nerf_rpn_amd import ops as _ops0
+    side_stream = _ops0._WGRAD_SIDE["enabled"]
     packs0 = _ops0.PACK_COUNT["conv"] + _ops0.PACK_COUNT["stem"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -376,9 +379,11 @@ def main():
     final_loss = loss.item()
     if probe.only is not None:
         timed_records, probe.records, probe.only, probe.enabled = probe.records, [], None, True
+        _ops0.set_wgrad_stream(False)       # per-class durations: one kernel at a time (no overlap with the weight-gradient stream)
         for _ in range(BREAKDOWN_STEPS):
             step()
         torch.cuda.synchronize()
+        _ops0.set_wgrad_stream(side_stream)
         probe.enabled = False
         probe.breakdown, probe.records = probe.records, timed_records
 
@@ -402,7 +407,7 @@ def main():
                                    "boxes), fwd+bwd+clip+AdamW (weights repacked every step), random-init weights", "scenes_per_gpu": 1,
                        "parallelism": f"dp{world}", "world_size_seen": world,
                        "backend": (dist.get_backend() if world > 1 else "single process")},
-            "weight_packs_per_step": packs_per_step, **({"tuning_knobs": knobs} if knobs else {}),
+            "weight_packs_per_step": packs_per_step, "wgrad_side_stream": side_stream, **({"tuning_knobs": knobs} if knobs else {}),
             "final_loss": round(final_loss, 5),
             "roofline": roof,
         }

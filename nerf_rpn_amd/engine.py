@@ -159,6 +159,7 @@ class FlatTrainer:
         return hook
 
     def _launch(self, b):
+        ops.wgrad_stream_join()      # weight gradients enqueued on the side stream must be in the arena before the bucket leaves
         s, e = self.buckets[b]
         self.launched[b] = True
         self.handles.append(dist.all_reduce(self.g_arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -179,6 +180,7 @@ class FlatTrainer:
         self.seen = [0] * len(self.params)
 
     def step(self):
+        ops.wgrad_stream_join()
         self.sync_gradients()
         lr, beta1 = self.lr, self.betas[0]
         if self.total_steps:

@@ -9,7 +9,8 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libnerfrpn_hip.so")
+# NRPN_LIBRARY: load another build of the same ABI (A/B timing of two kernel versions on one GPU box); default = the in-tree library
+SO_PATH = os.environ.get("NRPN_LIBRARY") or os.path.join(_HERE, "libnerfrpn_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "nerfrpn.h")
 
 F32, BF16 = 0, 1

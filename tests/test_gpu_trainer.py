@@ -126,3 +126,30 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
         a, b = (tr.flat_params() - init)[sig].double(), (after_ref - init)[sig].double()
         cos = (a @ b / (a.norm() * b.norm())).item()
         assert cos > 0.9 and 0.9 < (a.norm() / b.norm()).item() < 1.1, (cos, (a.norm() / b.norm()).item())
+
+
+def test_wgrad_side_stream_gives_the_same_arena(golden, dev):
+    """ConvFn.backward enqueues the weight-gradient kernels of arena training on a second HIP stream (ops.set_wgrad_stream): the gradient
+    arena and three optimiser steps must be bit-identical to the single-stream run."""
+    from nerf_rpn_amd import ops
+    from nerf_rpn_amd.engine import FlatTrainer
+    xs, gts, pos, neg = _batch(golden, dev)
+    out = {}
+    try:
+        for side in (False, True):
+            ops.set_wgrad_stream(side)
+            torch.manual_seed(0)
+            m = build(True, 160, dev).train()
+            tr = FlatTrainer(m, lr=3e-4, weight_decay=0.01, clip_grad_norm=0.1)
+            _loss(m, xs, gts, pos, neg).backward()
+            assert ops._WGRAD_SIDE["dirty"] is False            # the end-of-backward callback joined the side stream
+            g = tr.g_arena.clone()
+            for _ in range(3):
+                tr.step()
+                _loss(m, xs, gts, pos, neg).backward()
+            out[side] = (g, tr.p_arena.clone(), bool(ops._WGRAD_SIDE["streams"]))
+    finally:
+        ops.set_wgrad_stream(True)
+    assert out[True][2], "the side stream was never created"
+    assert torch.equal(out[False][0], out[True][0]), (out[False][0] - out[True][0]).abs().max().item()
+    assert torch.equal(out[False][1], out[True][1]), (out[False][1] - out[True][1]).abs().max().item()

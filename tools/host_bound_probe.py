@@ -40,6 +40,12 @@ def run(name, n=30, warm=6):
 
 
 run('a) as is')
+from nerf_rpn_amd import ops  # noqa: E402
+ops.set_wgrad_stream(True)
+run('a2) wgrad on a side stream')
+g1 = trainer.g_arena.clone() if hasattr(trainer, 'g_arena') else None
+ops.set_wgrad_stream(False)
+run('a) as is, again')
 rpn = model.rpn
 orig_prepare = rpn.prepare_targets
 cache = {}
