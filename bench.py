@@ -94,8 +94,8 @@ class ConvProbe:
             n_, gx_, gy_, gz_, cin_, _, wrows_, k_ = args[4:12]
             if 2.0 * n_ * gx_ * gy_ * gz_ * cin_ * wrows_ * (k_ ** 3) < 1e10:     # only the heavy launches (>= 10 GFLOP) are timed
                 return orig(name, *args)
-            if self.only is not None and ((name, (n_ * gx_ * gy_ * gz_, cin_, wrows_, k_)) != self.only or not torch.is_grad_enabled()):
-                # timed region: forward-pass launches of the dominant kernel only (autograd runs the backward with grad mode off); its
+            if self.only is not None and ((name, (n_ * gx_ * gy_ * gz_, cin_, wrows_, k_)) != self.only or self.ops.IN_BACKWARD[0]):
+                # timed region: forward-pass launches of the dominant kernel only; its
                 # dgrad launches share the GPU with the weight-gradient side stream, so their wall time is not a kernel duration
                 return orig(name, *args)
             a = torch.cuda.Event(enable_timing=True)
@@ -113,6 +113,7 @@ class ConvProbe:
         self.lib.call = call
         import nerf_rpn_amd.ops as ops
         ops.call = call
+        self.ops = ops
 
     def summary(self, dtype_name):
         def group(records):

@@ -642,6 +642,9 @@ def _wgrad_workspace(device, key, nbytes):
 CHAIN_MASK_INPUT_GRAD, CHAIN_GRAD_PREMASKED = 1, 2
 
 
+IN_BACKWARD = [0]       # > 0 while ConvFn.backward is enqueuing (bench.py tells forward launches from dgrad launches of the same entry point)
+
+
 class ConvFn(torch.autograd.Function):
     """Conv3d k in {1,3}, stride 1, 'same' padding, channels-last, optional fused bias + ReLU.
     ``weights``: one or more reference-layout parameters that share the GEMM (their rows are concatenated, then padded to
@@ -674,6 +677,14 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        IN_BACKWARD[0] += 1
+        try:
+            return ConvFn._backward(ctx, dy)
+        finally:
+            IN_BACKWARD[0] -= 1
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, y, wpd, *weights = ctx.saved_tensors
         rows_total, relu, nw, ksize, has_bias, segs, chain = ctx.meta
         n, gx, gy, gz, cin = x.shape
