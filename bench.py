@@ -344,8 +344,12 @@ def main():
             # heavy launches comes from BREAKDOWN_STEPS extra, untimed steps afterwards
             probe.only = ("conv3d_fwd", (64000, 256, 256, 3))
 
+    # the scene grid is resident in HBM; the ground-truth boxes (NUM_GT x 7 floats) are handed over as a host tensor, as the reference's
+    # loader does -- the RPN uploads them on its target-preparation stream (nerf_rpn.py forward)
+    gt_in = gt if fcos else gt.cpu()
+
     def step():
-        _, losses, _ = model([x], [gt])
+        _, losses, _ = model([x], [gt_in])
         if fcos:
             loss = losses["loss_cls"] + losses["loss_reg"] + losses["loss_centerness"]
         else:

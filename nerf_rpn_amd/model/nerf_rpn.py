@@ -43,6 +43,7 @@ class NeRFRegionProposalNetwork(nn.Module):
             dict(training=rpn_pre_nms_top_n_train, testing=rpn_pre_nms_top_n_test),
             dict(training=rpn_post_nms_top_n_train, testing=rpn_post_nms_top_n_test), rpn_nms_thresh,
             score_thresh=rpn_score_thresh, iou_batch_size=iou_batch_size, rotated_bbox=rotated_bbox, reg_loss_type=reg_loss_type)
+        self._prep_stream = None          # side stream of the target preparation when the ground truth arrives as host tensors (forward)
         self.set_compute_dtype(kwargs.get("compute_dtype", torch.float32))
 
     def set_compute_dtype(self, dtype):
@@ -100,11 +101,29 @@ class NeRFRegionProposalNetwork(nn.Module):
             # counts); the degenerate-box check rides on that copy as device flags instead of synchronising on its own.  The rest of
             # the step is then enqueued without a synchronisation (see RegionProposalNetwork.prepare_targets)
             size = tuple(int(v) for v in mesh_tensors.shape[-3:])
-            flags = [self._degenerate(b).any() for b in targets if b.is_cuda and b.numel()]
-            prepared = self.rpn.prepare_targets(size, [tuple(g) for g in self.backbone.feature_grids(size)], targets,
-                                                original_mesh_sizes, mesh_tensors.device, flags)
-            if prepared["flags"] is None or any(prepared["flags"]) or len(prepared["flags"]) != len(targets):
-                self.check_bbox_degeneration(targets)         # raises with the offending box (or covers what the flags did not)
+            grids = [tuple(g) for g in self.backbone.feature_grids(size)]
+            dev = mesh_tensors.device
+            if dev.type == "cuda" and all(not b.is_cuda for b in targets):
+                # Ground truth handed over as HOST tensors (what the reference's loader yields): nothing of the target preparation
+                # depends on earlier GPU work, so it runs on its own stream -- upload, matcher, sampler and the read-back of the sampled
+                # counts -- and the host never waits for the previous step's backward still executing on the main stream.
+                self.check_bbox_degeneration(targets)         # on the host copies: no device round trip
+                main = torch.cuda.current_stream(dev)
+                if self._prep_stream is None:
+                    self._prep_stream = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(self._prep_stream):
+                    targets = [b.to(dev, non_blocking=True) for b in targets]
+                    prepared = self.rpn.prepare_targets(size, grids, targets, original_mesh_sizes, dev)
+                main.wait_stream(self._prep_stream)
+                for v in list(prepared.values()) + [targets]:       # produced on the side stream, consumed (and later freed) on the main one
+                    for t in (v if isinstance(v, (list, tuple)) else [v]):
+                        if isinstance(t, torch.Tensor) and t.is_cuda:
+                            t.record_stream(main)
+            else:
+                flags = [self._degenerate(b).any() for b in targets if b.is_cuda and b.numel()]
+                prepared = self.rpn.prepare_targets(size, grids, targets, original_mesh_sizes, dev, flags)
+                if prepared["flags"] is None or any(prepared["flags"]) or len(prepared["flags"]) != len(targets):
+                    self.check_bbox_degeneration(targets)         # raises with the offending box (or covers what the flags did not)
         features = list(self.backbone(mesh_tensors))
         proposals, level_index, proposal_losses, scores = self.rpn(mesh_tensors, features, original_mesh_sizes, targets,
                                                                    objectness_output_paths, prepared)

@@ -247,7 +247,7 @@ class Trainer:
         for i, (rgbsigma, boxes, scene_name) in enumerate(self.train_loader):
             self.model.train()
             rgbsigma = self.scenes_to_device(rgbsigma)
-            boxes = [t.cuda(non_blocking=True) for t in boxes]
+            # the ground truth stays on the host: the model uploads it on its target-preparation stream (NeRFRegionProposalNetwork.forward)
             _, losses, _ = self.model(rgbsigma, boxes)
             lo = losses['loss_objectness']
             lr_ = losses['loss_rpn_box_reg'] * a.reg_loss_weight

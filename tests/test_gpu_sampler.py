@@ -120,3 +120,32 @@ def test_training_step_samples_once_and_keeps_the_box_check(dev, monkeypatch):
     bad[1, 4] = 0.0
     with pytest.raises(AssertionError, match="positive height, width and depth"):
         model([x], [bad])
+
+
+def test_host_ground_truth_takes_the_prep_stream_and_gives_the_same_step(dev):
+    """Ground truth handed over as host tensors: upload + matcher + sampler run on the model's own stream (no wait for the main stream's
+    backlog); sampled anchors, losses and gradients must equal the device-resident path under the same seed, and the degenerate-box
+    assertion still fires."""
+    import bench
+    model = bench.build_model(torch.bfloat16, dev, "vgg")
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4, 64, 48, 64, generator=g).to(dev)
+    gt = torch.tensor([[20., 22., 18., 16., 12., 10., 0.3], [40., 30., 24., 12., 18., 14., -0.7], [30., 12., 40., 9., 9., 20., 1.1]])
+    res = []
+    for host in (False, True):
+        torch.manual_seed(21)
+        model.zero_grad(set_to_none=True)
+        _, losses, _ = model([x], [gt if host else gt.to(dev)])
+        (losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"]).backward()
+        torch.cuda.synchronize()
+        res.append((model.rpn.last_aux["pos"].clone(), model.rpn.last_aux["neg"].clone(), {k: v.detach().clone() for k, v in losses.items()},
+                    torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])))
+    assert model._prep_stream is not None
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    assert torch.equal(res[0][3], res[1][3])
+    bad = gt.clone()
+    bad[2, 3] = -1.0
+    with pytest.raises(AssertionError, match="positive height, width and depth"):
+        model([x], [bad])

@@ -18,8 +18,11 @@ trainer = FlatTrainer(model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, tot
 x, gt = bench.synthetic_scene(0, dev)
 
 
+gt_in = [gt]
+
+
 def step():
-    _, losses, _ = model([x], [gt])
+    _, losses, _ = model([x], gt_in)
     loss = losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"] + 0.0 * losses["loss_rpn_box_reg_2d"]
     loss.backward()
     trainer.step()
@@ -39,7 +42,9 @@ def run(name, n=30, warm=6):
     print(f'{name}: {tot / n * 1e3:.2f} ms/step, host enqueue {host / n * 1e3:.2f} ms/step', flush=True)
 
 
-run('a) as is')
+run('a) as is (device-resident ground truth)')
+gt_in[0] = gt.cpu()
+run('a1) host ground truth: target preparation on its own stream')
 from nerf_rpn_amd import ops  # noqa: E402
 ops.set_wgrad_stream(True)
 run('a2) wgrad on a side stream')
