@@ -198,6 +198,7 @@ class FlatTrainer:
                                "CPU use is limited to the gloo gradient-exchange tests via sync_gradients()")
         ops.weights_changed()       # the raw-pointer update is invisible to tensor._version: invalidate every GEMM-layout weight copy
         self.g_arena.zero_()
+        self.weights.prefetch_dgrad()
         return lr
 
     def flat_params(self):

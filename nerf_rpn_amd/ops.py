@@ -534,18 +534,47 @@ class ArenaWeights:
             ent = [torch.empty(self.master.numel(), dtype=dtype, device=self.master.device), -1]
             self.trans[dtype] = ent
         if ent[1] != self.epoch:
-            if self.table is None:
-                rows, prefix = [], [0]
-                for (o, t, co, ci, _) in self.entries:
-                    rows.append([o, t, co, ci])
-                    prefix.append(prefix[-1] + t * ((co + 63) // 64) * ((ci + 63) // 64))
-                dev = self.master.device
-                self.table = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int32, device=dev), prefix[-1])
-            tab, prefix, total = self.table
-            call("transpose_weights", _p(self.master), _p(ent[0]), _p(tab), _p(prefix), len(self.entries), total, F32 if dtype == torch.float32 else BF16, _s())
-            self.launches["transpose"] += 1
-            ent[1] = self.epoch
+            self._transpose(dtype)
         return ent[0][off:off + taps * cout * cin].view(taps, cin, cout)
+
+    def _transpose(self, dtype):
+        ent = self.trans[dtype]
+        if self.table is None:
+            rows, prefix = [], [0]
+            for (o, t, co, ci, _) in self.entries:
+                rows.append([o, t, co, ci])
+                prefix.append(prefix[-1] + t * ((co + 63) // 64) * ((ci + 63) // 64))
+            dev = self.master.device
+            self.table = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int32, device=dev), prefix[-1])
+        tab, prefix, total = self.table
+        call("transpose_weights", _p(self.master), _p(ent[0]), _p(tab), _p(prefix), len(self.entries), total, F32 if dtype == torch.float32 else BF16, _s())
+        self.launches["transpose"] += 1
+        ent[1] = self.epoch
+
+    def prefetch_dgrad(self):
+        """Called by the trainer right after an optimiser step: refresh the dgrad operands on the weight-gradient side stream, off the
+        next forward's critical path (they are first read by the next BACKWARD, which waits for the event recorded here)."""
+        side = _wgrad_side_stream(self.master.device)
+        if side is None or not self.trans or self.table is None:
+            return
+        side.wait_stream(torch.cuda.current_stream(self.master.device))      # behind the AdamW kernel that rewrote the master arena
+        with torch.cuda.stream(side):
+            for dtype in list(self.trans):
+                if self.trans[dtype][1] != self.epoch:
+                    self._transpose(dtype)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        _DGRAD_READY["event"] = ev
+
+
+_DGRAD_READY = {"event": None}
+
+
+def _wait_dgrad_operands():
+    ev = _DGRAD_READY["event"]
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        _DGRAD_READY["event"] = None
 
 
 def _sink(t):
@@ -704,6 +733,7 @@ class ConvFn(torch.autograd.Function):
             dy = dyr
         dx = None
         if ctx.needs_input_grad[0]:
+            _wait_dgrad_operands()
             # CHAIN_MASK_INPUT_GRAD: x is the ReLU output of the layer that receives dx and this conv is its only consumer, so that
             # layer's ReLU backward is applied in this dgrad's epilogue (dx = 0 where x <= 0) instead of a separate pass
             mask = x if (chain & CHAIN_MASK_INPUT_GRAD) and segs is None else None
