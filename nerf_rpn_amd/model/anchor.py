@@ -101,41 +101,18 @@ class RPNHead(nn.Module):
             h = ops.ConvFn.apply(x, self._pack, self.head_rows, False, True, 2, self.cls_logits.weight, self.bbox_pred.weight,
                                  self.cls_logits.bias, self.bbox_pred.bias)
             return [out0] + hip_nn.ragged_split(h, feats_cl[1:])
+        outs = []
         convs = [m for m in self.conv if isinstance(m, nn.Conv3d)]
-
-        def level(f):
+        for f in feats_cl:
             # conv+ReLU chain private to the head: every intermediate has exactly one consumer, so each layer's ReLU backward rides
             # in the epilogue of the next layer's dgrad (ops.CHAIN_*) -- no separate relu_backward launches
             t = f
             for i, cv in enumerate(convs):
                 chain = ops.CHAIN_GRAD_PREMASKED | (ops.CHAIN_MASK_INPUT_GRAD if i > 0 else 0)
                 t = hip_nn.conv3d(cv, t, relu=True, chain=chain)
-            return ops.ConvFn.apply(t, self._pack, self.head_rows, (False, ops.CHAIN_MASK_INPUT_GRAD), True, 2, self.cls_logits.weight,
-                                    self.bbox_pred.weight, self.cls_logits.bias, self.bbox_pred.bias)
-        side = ops.level_stream(feats_cl[0].device) if len(feats_cl) > 1 else None
-        if side is None:
-            return [level(f) for f in feats_cl]
-        # the coarser levels (short, latency-bound launches) run on the pyramid-level stream beside the finest level's chip-filling ones.
-        # Weight operands shared by the levels are refreshed on the main stream first (whoever asks first launches the pack / cast).
-        f0 = feats_cl[0]
-        main = torch.cuda.current_stream(f0.device)
-        grad = torch.is_grad_enabled()
-        need0 = grad and f0.requires_grad                                                    # = x.requires_grad of the first conv
-        need = grad and (f0.requires_grad or any(p.requires_grad for p in self.conv.parameters()))     # ... of every later one
-        for i, cv in enumerate(convs):
-            hip_nn._pack_of(cv).get((cv.weight,), f0.dtype, cv.out_channels, need if i else need0, cv.in_channels)
-        self._pack.get((self.cls_logits.weight, self.bbox_pred.weight), f0.dtype, self.head_rows, need if convs else need0, self.cls_logits.in_channels)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            coarse = []
-            for f in feats_cl[1:]:
-                f.record_stream(side)
-                coarse.append(level(f))
-        out0 = level(f0)
-        main.wait_stream(side)
-        for o in coarse:
-            o.record_stream(main)
-        return [out0] + coarse
+            outs.append(ops.ConvFn.apply(t, self._pack, self.head_rows, (False, ops.CHAIN_MASK_INPUT_GRAD), True, 2, self.cls_logits.weight,
+                                         self.bbox_pred.weight, self.cls_logits.bias, self.bbox_pred.bias))
+        return outs
 
     def forward(self, x: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
         dt = x[0].dtype

@@ -565,40 +565,16 @@ class ArenaWeights:
             ev = torch.cuda.Event()
             ev.record(side)
         _DGRAD_READY["event"] = ev
-        _DGRAD_READY["waited"] = set()
 
 
-_DGRAD_READY = {"event": None, "waited": set()}
+_DGRAD_READY = {"event": None}
 
 
 def _wait_dgrad_operands():
-    """First dgrad of a stream after an optimiser step: wait for the operand refresh enqueued on the side stream."""
     ev = _DGRAD_READY["event"]
     if ev is not None:
-        sid = _s()
-        if sid not in _DGRAD_READY["waited"]:
-            torch.cuda.current_stream().wait_event(ev)
-            _DGRAD_READY["waited"].add(sid)
-
-
-# Pyramid-level stream: the RPN head shares its weights across the FPN levels and its per-level chains are independent.  The finest
-# level fills the chip on its own; the coarser ones are chains of short, latency-bound launches, so they run on a second stream beside it
-# (forward, and -- because autograd replays a node on the stream of its forward -- backward).  NRPN_LEVEL_STREAM=0 disables.
-_LEVEL_SIDE = {"enabled": _os.environ.get("NRPN_LEVEL_STREAM", "1") != "0", "streams": {}}
-
-
-def set_level_stream(enabled):
-    _LEVEL_SIDE["enabled"] = bool(enabled)
-
-
-def level_stream(device):
-    if not _LEVEL_SIDE["enabled"] or device.type != "cuda":
-        return None
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _LEVEL_SIDE["streams"].get(key)
-    if st is None:
-        st = _LEVEL_SIDE["streams"][key] = torch.cuda.Stream(device=device)
-    return st
+        torch.cuda.current_stream().wait_event(ev)
+        _DGRAD_READY["event"] = None
 
 
 def _sink(t):

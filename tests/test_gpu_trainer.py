@@ -154,35 +154,3 @@ def test_wgrad_side_stream_gives_the_same_arena(golden, dev):
     assert out[True][2], "the side stream was never created"
     assert torch.equal(out[False][0], out[True][0]), (out[False][0] - out[True][0]).abs().max().item()
     assert torch.equal(out[False][1], out[True][1]), (out[False][1] - out[True][1]).abs().max().item()
-
-
-def test_pyramid_level_stream_gives_the_same_step(golden, dev):
-    """RPNHead runs the coarser pyramid levels on a second stream (ops.set_level_stream); forward outputs, the gradient arena and two
-    optimiser steps must be bit-identical to the single-stream run, in eval mode too."""
-    from nerf_rpn_amd import ops
-    from nerf_rpn_amd.engine import FlatTrainer
-    xs, gts, pos, neg = _batch(golden, dev)
-    out = {}
-    try:
-        for side in (False, True):
-            ops.set_level_stream(side)
-            torch.manual_seed(0)
-            m = build(True, 160, dev).train()
-            m.set_compute_dtype(torch.bfloat16)
-            tr = FlatTrainer(m, lr=3e-4, weight_decay=0.01, clip_grad_norm=0.1)
-            losses = []
-            for _ in range(3):
-                loss = _loss(m, xs, gts, pos, neg)
-                loss.backward()
-                g = tr.g_arena.clone()
-                tr.step()
-                losses.append(loss.detach().clone())
-            m.eval()
-            with torch.no_grad():
-                ev = m(xs)[0][1]
-            out[side] = (torch.stack(losses), g, tr.p_arena.clone(), torch.cat([b.reshape(-1) for b in ev]))
-    finally:
-        ops.set_level_stream(True)
-    assert ops._LEVEL_SIDE["streams"], "the level stream was never created"
-    for a, b in zip(out[False], out[True]):
-        assert torch.equal(a, b), (a - b).abs().max().item()
