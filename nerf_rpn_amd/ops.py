@@ -565,16 +565,20 @@ class ArenaWeights:
             ev = torch.cuda.Event()
             ev.record(side)
         _DGRAD_READY["event"] = ev
+        _DGRAD_READY["waited"] = set()
 
 
-_DGRAD_READY = {"event": None}
+_DGRAD_READY = {"event": None, "waited": set()}
 
 
 def _wait_dgrad_operands():
+    """First dgrad of a stream after an optimiser step: wait for the operand refresh enqueued on the side stream."""
     ev = _DGRAD_READY["event"]
     if ev is not None:
-        torch.cuda.current_stream().wait_event(ev)
-        _DGRAD_READY["event"] = None
+        sid = _s()
+        if sid not in _DGRAD_READY["waited"]:
+            torch.cuda.current_stream().wait_event(ev)
+            _DGRAD_READY["waited"].add(sid)
 
 
 def _sink(t):
