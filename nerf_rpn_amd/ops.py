@@ -57,9 +57,15 @@ def _wgrad_side_stream(device):
 def wgrad_stream_join():
     """Make the current stream wait for every weight-gradient kernel enqueued on the side stream so far."""
     if _WGRAD_SIDE["dirty"]:
+        joined = True
         for st in _WGRAD_SIDE["streams"].values():
-            torch.cuda.current_stream(st.device).wait_stream(st)
-        _WGRAD_SIDE["dirty"] = False
+            cur = torch.cuda.current_stream(st.device)
+            if cur == st:            # called from inside the side-stream context (a bucket completed by a wgrad): already ordered, but
+                joined = False       # the main stream has not waited yet -- keep the flag for the next join
+            else:
+                cur.wait_stream(st)
+        if joined:
+            _WGRAD_SIDE["dirty"] = False
 
 
 def _chk(*ts):
