@@ -149,3 +149,31 @@ def test_host_ground_truth_takes_the_prep_stream_and_gives_the_same_step(dev):
     bad[2, 3] = -1.0
     with pytest.raises(AssertionError, match="positive height, width and depth"):
         model([x], [bad])
+
+
+def test_batch_of_two_scenes_samples_every_scene(dev):
+    """Two scenes of different sizes (zero-padded to a common grid) through the training forward with the kernel sampler: per-scene
+    counts follow the reference's rules, sampled anchors carry the right labels, padded anchors are never drawn, and the backward runs."""
+    import bench
+    model = bench.build_model(torch.bfloat16, dev, "vgg")
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.rand(4, 64, 64, 48, generator=g).to(dev), torch.rand(4, 48, 56, 64, generator=g).to(dev)]
+    gts = [torch.tensor([[20., 22., 18., 16., 12., 10., 0.3], [40., 30., 24., 12., 18., 14., -0.7]]),
+           torch.tensor([[24., 20., 30., 14., 14., 12., 0.9]])]
+    torch.manual_seed(4)
+    _, losses, _ = model(xs, gts)
+    loss = losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"]
+    loss.backward()
+    assert torch.isfinite(loss)
+    aux = model.rpn.last_aux
+    labels = torch.cat(aux["labels"])
+    T = aux["labels"][0].numel()
+    pos, neg = aux["pos"], aux["neg"]
+    assert (labels[pos] >= 1).all() and (labels[neg] == 0).all()
+    assert (pos[1:] > pos[:-1]).all() and (neg[1:] > neg[:-1]).all()
+    for i in range(2):
+        lab = aux["labels"][i]
+        n_pos = int(((pos >= i * T) & (pos < (i + 1) * T)).sum())
+        n_neg = int(((neg >= i * T) & (neg < (i + 1) * T)).sum())
+        assert n_pos == min(int((lab >= 1).sum()), 128) and n_neg == min(int((lab == 0).sum()), 256 - n_pos), (i, n_pos, n_neg)
+    assert int((aux["labels"][1] < 0).sum()) > 0          # the smaller scene has ignored (padding) anchors
