@@ -163,8 +163,8 @@ def sample_pos_neg(labels, batch, max_pos, seed, extra_flags=None):
             raise TypeError("sample_pos_neg: labels must be 1-D float32")
         _chk(lab.contiguous())
     wsb = int(lib.query("sample_workspace_bytes"))
-    key = (str(dev), n, batch, max_pos)
-    if key not in _SAMPLE_WS:          # per-scene scratch, reused every step (stream-ordered)
+    key = (str(dev), n, batch, max_pos, _s())
+    if key not in _SAMPLE_WS:          # per-scene scratch of this stream, reused every step (stream-ordered)
         _SAMPLE_WS[key] = torch.empty((n, (wsb + 7) // 8), dtype=torch.int64, device=dev)
     ws = _SAMPLE_WS[key]
     out_pos = torch.empty((n, max(max_pos, 1)), dtype=torch.int64, device=dev)
