@@ -243,6 +243,10 @@ int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, fl
  * K slices, 4 = wave-specialised 256x128;  of a wgrad launch: 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */
 int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
 int nrpn_conv3d_wgrad_plan(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
+/* State: the library keeps NO per-call or per-stream state -- every buffer, workspace and stream comes from the caller.  What is process-wide:
+ * (a) the nrpn_set_* switches below, developer knobs for A/B measurements whose defaults are the product configuration (set them before
+ * launching, not concurrently with launches); (b) a (kernel, device) cache of granted dynamic-LDS limits (mutex-protected, idempotent);
+ * (c) the thread-local message behind nrpn_last_error(). */
 /* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
 int nrpn_set_conv_kstep_bytes(int kb);
 /* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */

@@ -28,6 +28,14 @@ int nrpn_fail(int code, const char *fmt, ...);
     if (e_ != hipSuccess) return nrpn_fail(NRPN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute belongs to the device the call is made on, so the cache
+// is keyed on both (a process-wide "done" flag would leave a second device of the same process at the 64 KB default).  Thread-safe.
+int nrpn_ensure_dynamic_lds(const void *kernel, int bytes);
+#define NRPN_LDS(kernel, bytes)                                                                         \
+  do {                                                                                                  \
+    if (int rc_ = nrpn_ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), (int)(bytes))) return rc_; \
+  } while (0)
+
 static inline hipStream_t as_stream(nrpn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1043,7 +1043,7 @@ extern "C" int nrpn_set_conv_tile_m(int bm) {
 
 template <typename K>
 static int launch_igemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const ConvArgs &a) {
-  if (lds > 64 * 1024) NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024) NRPN_LDS(kernel, (int)lds);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
   return NRPN_OK;
 }
@@ -1074,13 +1074,13 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
     if constexpr (MODE == 0 && sizeof(T) == 2) {
       const size_t lds_ = 2 * (size_t)(256 + 256) * 128;
       if (!out_f32 && (g_conv_stagger || (a.flags & NRPN_CONV_DEBUG_STAGGER))) {
-        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_big_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        NRPN_LDS((conv_igemm_big_kernel<false, true>), (int)lds_);
         hipLaunchKernelGGL((conv_igemm_big_kernel<false, true>), grid, dim3(512), lds_, st, a);
       } else if (out_f32) {
-        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        NRPN_LDS((conv_igemm_big_kernel<true>), (int)lds_);
         hipLaunchKernelGGL(conv_igemm_big_kernel<true>, grid, dim3(512), lds_, st, a);
       } else {
-        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        NRPN_LDS((conv_igemm_big_kernel<false>), (int)lds_);
         hipLaunchKernelGGL(conv_igemm_big_kernel<false>, grid, dim3(512), lds_, st, a);
       }
     }
@@ -1088,10 +1088,10 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
     if constexpr (MODE == 0 && sizeof(T) == 2) {
       const size_t lds_ = 3 * (size_t)(256 + 128) * 128;
       if (out_f32) {
-        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        NRPN_LDS((conv_igemm_ws_kernel<true>), (int)lds_);
         hipLaunchKernelGGL(conv_igemm_ws_kernel<true>, grid, dim3(512), lds_, st, a);
       } else {
-        NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        NRPN_LDS((conv_igemm_ws_kernel<false>), (int)lds_);
         hipLaunchKernelGGL(conv_igemm_ws_kernel<false>, grid, dim3(512), lds_, st, a);
       }
     }
@@ -2007,15 +2007,8 @@ static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
   a.ntiles_n = ntiles_n;
   const size_t lds = 4 * (size_t)WgCfg<T>::KV * WgCfg<T>::RS;
   const bool tr = g_wgrad_tr_mode != 0;
-  static bool attr_done[2][2][2] = {};
-  bool &done = attr_done[sizeof(T) == 2][MODE][tr];
-  if (!done) {
-    if (tr) NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_kernel<T, MODE, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_kernel<T, MODE, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
+  if (tr) NRPN_LDS((conv_wgrad_kernel<T, MODE, true>), (int)lds);
+  else NRPN_LDS((conv_wgrad_kernel<T, MODE, false>), (int)lds);
   dim3 grid((unsigned)(((a.wrows + 127) / 128) * ntiles_n * (MODE == 0 ? a.taps : 1) * a.ksplit));
   if (tr) hipLaunchKernelGGL((conv_wgrad_kernel<T, MODE, true>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<T, MODE, false>), grid, dim3(256), lds, st, a);
@@ -2069,11 +2062,7 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
     a.ntiles_n = (cin + 255) / 256;
     const int tiles = ((wrows + 255) / 256) * a.ntiles_n * a.taps;
     const size_t lds = 2 * 4 * (size_t)64 * 256;
-    static bool done = false;
-    if (!done) {
-      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      done = true;
-    }
+    NRPN_LDS(conv_wgrad_big_kernel, (int)lds);
     hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
     NRPN_LAUNCH_CHECK("conv_wgrad_big");
   }
@@ -2159,11 +2148,11 @@ extern "C" int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_p
     const dim3 grid((unsigned)(7 * z.slices));
     if (dtype == NRPN_F32) {
       constexpr size_t lds_ = 2 * (size_t)(ZrCfg<float>::KV * ZrCfg<float>::RSA + 7 * ZrCfg<float>::KV * ZrCfg<float>::RSB);
-      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_zrow_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+      NRPN_LDS((stem_wgrad_zrow_kernel<float>), (int)lds_);
       hipLaunchKernelGGL(stem_wgrad_zrow_kernel<float>, grid, dim3(256), lds_, st, z);
     } else {
       constexpr size_t lds_ = 2 * (size_t)(ZrCfg<bf16s>::KV * ZrCfg<bf16s>::RSA + 7 * ZrCfg<bf16s>::KV * ZrCfg<bf16s>::RSB);
-      NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_zrow_kernel<bf16s>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+      NRPN_LDS((stem_wgrad_zrow_kernel<bf16s>), (int)lds_);
       hipLaunchKernelGGL(stem_wgrad_zrow_kernel<bf16s>, grid, dim3(256), lds_, st, z);
     }
     NRPN_LAUNCH_CHECK("stem_wgrad_zrow");

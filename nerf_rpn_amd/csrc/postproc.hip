@@ -6,6 +6,9 @@
 
 #include <cfloat>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 thread_local char g_nrpn_err[512] = "";
 
@@ -18,6 +21,19 @@ int nrpn_fail(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *nrpn_last_error(void) { return g_nrpn_err; }
+
+int nrpn_ensure_dynamic_lds(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, int> granted;      // (kernel, device) -> bytes already granted
+  int dev = 0;
+  NRPN_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int &have = granted[{kernel, dev}];
+  if (have >= bytes) return NRPN_OK;
+  NRPN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  have = bytes;
+  return NRPN_OK;
+}
 extern "C" int nrpn_abi_version(void) { return 2; }
 
 extern "C" int nrpn_check_device(int ordinal) {
@@ -259,12 +275,7 @@ extern "C" int nrpn_nms3d(const float *boxes, const int32_t *levels, const int32
     hipLaunchKernelGGL(nms_mask_kernel<7>, grid, dim3(64), 0, st, boxes, levels, d_count, (int)n_max, thr, mask, words);
   NRPN_LAUNCH_CHECK("nms_mask");
   const size_t lds = (size_t)words * 65 * 8;  // worst case: one level spans every word
-  static bool attr_done = false;
-  if (!attr_done) {
-    NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)((kMaxNms / 64) * 65 * 8)));
-    attr_done = true;
-  }
+  NRPN_LDS(nms_scan_kernel, (int)((kMaxNms / 64) * 65 * 8));
   hipLaunchKernelGGL(nms_scan_kernel, dim3(levels ? kNmsLevels : 1), dim3(256), lds, st, levels, d_count, (int)n_max, mask, words,
                      keep);
   NRPN_LAUNCH_CHECK("nms_scan");
@@ -418,12 +429,7 @@ extern "C" int nrpn_segmented_topk_f32(const float *scores, const int64_t *h_off
   NRPN_REQUIRE(scores && h_offsets && out_idx && out_val, "topk: null pointer");
   const int P = next_pow2(k);
   const size_t lds = (size_t)P * 8 + 2048 * 4 + 1024 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 16384 * 8 + 2048 * 4 + 1024 * 4));
-    attr_done = true;
-  }
+  NRPN_LDS(topk_kernel, 16384 * 8 + 2048 * 4 + 1024 * 4);
   for (int s = 0; s < nseg; ++s) {
     NRPN_REQUIRE(h_offsets[s + 1] >= h_offsets[s] && h_offsets[s + 1] < (1ll << 31), "topk: bad segment %d", s);
     hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), lds, as_stream(stream), scores, (long long)h_offsets[s],
@@ -790,12 +796,7 @@ extern "C" int nrpn_select_kept_f32(const float *boxes, const float *scores, con
   NRPN_REQUIRE(n >= 1 && n <= 16384 && post_top_n >= 1, "select: bad n=%lld post=%d", (long long)n, post_top_n);
   NRPN_REQUIRE(boxes && scores && levels && keep && out_boxes && out_scores && out_levels && d_out_count, "select: null pointer");
   const int P = next_pow2((int)n);
-  static bool attr_done = false;
-  if (!attr_done) {
-    NRPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(select_kept_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 16384 * 8));
-    attr_done = true;
-  }
+  NRPN_LDS(select_kept_kernel, 16384 * 8);
   hipLaunchKernelGGL(select_kept_kernel, dim3(1), dim3(kTopkThreads), (size_t)P * 8, as_stream(stream), boxes, scores, levels, keep,
                      d_count, (int)n, box_dim, P, post_top_n, out_boxes, out_scores, out_levels, d_out_count);
   NRPN_LAUNCH_CHECK("select_kept");
