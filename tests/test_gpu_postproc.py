@@ -38,6 +38,19 @@ def test_rotated_iou_pairs(golden, dev):
     assert torch.allclose(a, T(g["aabb_iou"]), atol=1e-7)
 
 
+def test_rotated_iou_analytic_cases_on_the_device(dev):
+    """The closed-form pairs of tests/test_oracle_golden.py::analytic_iou_cases through the three HIP IoU paths (paired kernel, all-pairs
+    kernel, the fused differentiable loss kernel's IoU output), both argument orders."""
+    from nerf_rpn_amd import ops
+    from test_oracle_golden import analytic_iou_cases
+    b1, b2, want = analytic_iou_cases()
+    a, b = b1.to(dev), b2.to(dev)
+    assert torch.allclose(ops.iou3d_pair(a[None], b[None])[0].cpu(), want, atol=3e-6)
+    assert torch.allclose(ops.iou3d_pair(b[None], a[None])[0].cpu(), want, atol=3e-6)
+    assert torch.allclose(ops.iou3d_matrix(a, b).diagonal().cpu(), want, atol=3e-6)
+    assert torch.allclose(ops.rotated_iou_loss(a, b, "giou")[1].cpu(), want, atol=3e-6)
+
+
 def test_differentiable_iou_matches_oracle(golden, dev):
     from nerf_rpn_amd.model.rotated_iou import oriented_iou_loss as L
     from oracle import geometry as OG
