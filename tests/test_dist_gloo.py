@@ -19,6 +19,34 @@ def _free_port():
     return p
 
 
+def _run_ranks(target, extra_args, world=2, attempts=3):
+    """Spawn ``world`` ranks of ``target(rank, world, port, *extra_args, queue)`` and return their results sorted by rank.  The rendezvous
+    port is picked by binding port 0 and released before the ranks bind it, so another process can grab it in between (seen as a rare
+    gloo connection error): a failed RENDEZVOUS is retried on a fresh port; results themselves are never retried into agreement --
+    every assertion is made by the caller on the one set of results returned."""
+    import queue as _queue
+    ctx = mp.get_context("spawn")
+    last = None
+    for _ in range(attempts):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port, *extra_args, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+        except _queue.Empty as e:
+            res, last = None, e
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if res is not None and all(p.exitcode == 0 for p in procs):
+            return res
+        last = last or RuntimeError(f"rank exit codes {[p.exitcode for p in procs]}")
+    raise AssertionError(f"the {world}-rank run failed {attempts} times: {last}")
+
+
 class Tiny(nn.Module):
     def __init__(self):
         super().__init__()
@@ -33,6 +61,8 @@ class Tiny(nn.Module):
 
 def _worker(rank, world, port, bucket_bytes, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if os.path.exists("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the container hostname may not resolve: keep gloo's transport on loopback
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nerf_rpn_amd.engine import FlatTrainer
     torch.manual_seed(100 + rank)            # different init per rank: the trainer must broadcast rank 0's weights
@@ -53,16 +83,7 @@ def _worker(rank, world, port, bucket_bytes, q):
 
 @pytest.mark.parametrize("bucket_bytes", [64, 1 << 20])
 def test_flat_trainer_gradient_exchange(bucket_bytes):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_worker, (bucket_bytes,))
     (_, w_a, g_a, nb), (_, w_b, g_b, _) = res
     assert torch.equal(w_a, w_b)                             # rank 0's weights everywhere
     assert torch.allclose(g_a, g_b)                          # identical reduced gradients
@@ -113,6 +134,8 @@ class Shared(nn.Module):
 
 def _sink_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if os.path.exists("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nerf_rpn_amd.engine import FlatTrainer
     torch.manual_seed(5)
@@ -133,16 +156,7 @@ def _sink_worker(rank, world, port, q):
 
 
 def test_direct_sink_accumulation_with_shared_weights():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_sink_worker, ())
     (_, g_a, expected, early), (_, g_b, _, _) = res
     assert torch.allclose(g_a, g_b)
     names = [n for n, _ in Shared().named_parameters()]
