@@ -242,6 +242,16 @@ int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, fl
 /* kernel selection of a forward / dgrad launch: 0 = 128-row tile, 1 = 256x256 tile, 2 = 256x256 tile on K slices, 3 = 128-row tile on
  * K slices, 4 = wave-specialised 256x128;  of a wgrad launch: 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */
 int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
+/* BatchNorm statistics out of the conv epilogue (the conv -> BatchNorm3d pairs of feature_extractor.py:288-377 in training mode):
+ * nrpn_conv3d_fwd_stats = nrpn_conv3d_fwd that also writes per-row-group partial (sum, sum of squares) of the STORED bf16 outputs into
+ * stats f32 [P][2][Cout], P = nrpn_conv3d_fwd_stats_rows(...) (0 = this shape's kernel has no fused statistics: K-sliced / fp32 / narrow
+ * K-step -- run nrpn_bn_stats on the output instead); nrpn_bn_stats_finalize turns the partials into mean / biased variance and updates
+ * the running statistics exactly as nrpn_bn_stats does for its own slab partials (fp64 accumulation, fixed order). */
+int nrpn_conv3d_fwd_stats_rows(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
+int nrpn_conv3d_fwd_stats(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
+                          int cout, int wrows, int ksize, int dtype, int flags, float *stats, nrpn_stream_t stream);
+int nrpn_bn_stats_finalize(const float *partials, int nparts, int64_t rows, int c, float *mean, float *var, float *running_mean,
+                           float *running_var, float momentum, nrpn_stream_t stream);
 int nrpn_conv3d_wgrad_plan(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 /* State: the library keeps NO per-call or per-stream state -- every buffer, workspace and stream comes from the caller.  What is process-wide:
  * (a) the nrpn_set_* switches below, developer knobs for A/B measurements whose defaults are the product configuration (set them before

@@ -136,7 +136,20 @@ struct ConvArgs {
   float *ws;          // [ksplit][M][Cout] fp32 partials (plain stores, summed in slice order by splitk_epilogue_kernel: deterministic)
   int slices;         // 1: the K slices run on the 256x256 kernel (mid-size grids, conv_big_split); 0: on the 128-row kernel
   Segs segs;          // MODE 0 only: ragged voxel list (n > 0) instead of N copies of X*Y*Z
+  float *stats;       // optional (bf16 staged epilogues only): per row-group partial BatchNorm statistics [P][2][Cout] = (sum, sum of squares)
+                      // of the STORED (bf16-rounded) outputs; row group = the rows one wave row covers (see nrpn_conv3d_fwd_stats_rows)
 };
+
+// per-column (sum, sum of squares) of the values a lane holds in its C fragments -> partial statistics row `pidx` (lanes l and l^32 hold
+// the two row halves of the same 32 columns)
+__device__ __forceinline__ void store_col_stats(float *stats, long long pidx, int cout, int col, float s, float q, int lane) {
+  s += __shfl_xor(s, 32, 64);
+  q += __shfl_xor(q, 32, 64);
+  if (lane < 32 && col < cout) {
+    stats[(pidx * 2) * cout + col] = s;
+    stats[(pidx * 2 + 1) * cout + col] = q;
+  }
+}
 
 template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128>
 __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(const ConvArgs p) {
@@ -426,18 +439,27 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     char *stage = lds + wave * (TM * 32 * PITCH);
     const T *maskp = reinterpret_cast<const T *>(p.mask);
     T *yp = reinterpret_cast<T *>(p.y);
+    const bool full_tile = m0 + BM <= p.M;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + fr;
       const float bv = (has_bias && col < p.Cout) ? p.bias[col] : 0.f;
+      float ssum = 0.f, qsum = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float o = acc[i][j][r] + bv;
           if (relu) o = fmaxf(o, 0.f);
-          *reinterpret_cast<bf16s *>(stage + (i * 32 + frag_row(r, lane)) * PITCH + (j * 32 + fr) * 2) = f32_to_bf16_bits(o);
+          const bf16s ob = f32_to_bf16_bits(o);
+          *reinterpret_cast<bf16s *>(stage + (i * 32 + frag_row(r, lane)) * PITCH + (j * 32 + fr) * 2) = ob;
+          if (p.stats && (full_tile || m0 + (wm * TM + i) * 32 + frag_row(r, lane) < p.M)) {
+            const float of = bf16_bits_to_f32(ob);
+            ssum += of;
+            qsum += of * of;
+          }
         }
+      if (p.stats) store_col_stats(p.stats, (m0 / BM) * (BM / (TM * 32)) + wm, p.Cout, col, ssum, qsum, lane);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -908,6 +930,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     char *stage = lds + wave * (64 * PITCH);
     const T *maskp = reinterpret_cast<const T *>(p.mask);
     T *yp = reinterpret_cast<T *>(p.y);
+    const bool full_tile = m0 + BM <= p.M;
+    float ssum[TN] = {0.f, 0.f}, qsum[TN] = {0.f, 0.f};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -921,7 +945,13 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
           for (int r = 0; r < 16; ++r) {
             float o = acc[i][j][r] + bv;
             if (relu) o = fmaxf(o, 0.f);
-            *reinterpret_cast<bf16s *>(stage + (ii * 32 + frag_row(r, elane)) * PITCH + (j * 32 + efr) * 2) = f32_to_bf16_bits(o);
+            const bf16s ob = f32_to_bf16_bits(o);
+            *reinterpret_cast<bf16s *>(stage + (ii * 32 + frag_row(r, elane)) * PITCH + (j * 32 + efr) * 2) = ob;
+            if (p.stats && (full_tile || m0 + (wm * TM + i) * 32 + frag_row(r, elane) < p.M)) {
+              const float of = bf16_bits_to_f32(ob);
+              ssum[j] += of;
+              qsum[j] += of * of;
+            }
           }
         }
       }
@@ -947,6 +977,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this half before the next half overwrites the stage
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        store_col_stats(p.stats, (m0 / BM) * 2 + wm, p.Cout, n0 + (wn * TN + j) * 32 + efr, ssum[j], qsum[j], elane);
     }
     return;
   }
@@ -1061,6 +1096,10 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const bool huge = can && a.Cout >= 256 && (a.slices || g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
   const bool big = can && !huge && g_conv_bm == 256 && a.segs.n == 0;      // wave-specialised 256x128: on par with 128x128 (measured), opt-in only
   const int bm = (big || huge) ? 256 : 128;
+  if (a.stats) {      // fused BatchNorm statistics exist in the staged bf16 epilogues of the 128-row and 256x256 kernels only
+    const bool staged = MODE == 0 && sizeof(T) == 2 && !out_f32 && (a.Cout & 7) == 0 && a.ksplit <= 1 && !big && (huge || wide);
+    if (!staged) return nrpn_fail(NRPN_ERR_ARG, "conv3d_fwd_stats: this shape does not run a kernel with fused statistics (ask nrpn_conv3d_fwd_stats_rows first)");
+  }
   dim3 grid((unsigned)(cdiv64(a.M, bm) * ((a.Cout + (huge ? 256 : bn) - 1) / (huge ? 256 : bn)) * (a.ksplit > 1 ? a.ksplit : 1)));
   int rc = 0;
 #define NRPN_LC(BN_, OF_, KB_)                                                                                                    \
@@ -1129,7 +1168,8 @@ extern "C" int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int 
 }
 
 static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, const void *mask, void *y, long long M, int gx, int gy, int gz, const Segs *segs,
-                           int cin, int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
+                           int cin, int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream,
+                           float *stats = nullptr) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_fwd: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_fwd: bad dtype %d", dtype);
   NRPN_REQUIRE(M > 0 && gx > 0 && gy > 0 && gz > 0 && cin > 0 && cout > 0 && wrows >= cout, "conv3d_fwd: bad sizes");
@@ -1137,7 +1177,7 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
   NRPN_REQUIRE((cin * es) % 64 == 0, "conv3d_fwd: Cin*elemsize must be a multiple of 64 bytes (Cin=%d)", cin);
   NRPN_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
   ConvArgs a{};
-  a.x = x; a.w = wp; a.bias = bias; a.mask = mask; a.y = y;
+  a.x = x; a.w = wp; a.bias = bias; a.mask = mask; a.y = y; a.stats = stats;
   a.M = M;
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // classic layout: the kernel splits v into (batch, x, y, z) with these
   if (segs) a.segs = *segs;
@@ -1179,6 +1219,27 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
   NRPN_REQUIRE(!relu_mask || !(flags & NRPN_CONV_OUT_F32) || dtype == NRPN_F32, "conv3d_fwd: relu_mask needs outputs in the input dtype");
   return conv3d_fwd_impl(x, wp, bias, relu_mask, y, (long long)n * gx * gy * gz, gx, gy, gz, nullptr, cin, cout, wrows, ksize, dtype, flags,
                          workspace, stream);
+}
+
+// Rows P of the partial-statistics buffer [P][2][Cout] a forward launch of this shape fills when asked to (0 = the shape runs a kernel
+// without fused statistics: K-sliced, fp32, narrow K-step or the opt-in variants -- use nrpn_bn_stats on the output instead).
+extern "C" int nrpn_conv3d_fwd_stats_rows(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
+  if (dtype != NRPN_BF16 || (cout & 7) != 0 || !g_conv_glds || g_conv_bm == 256) return 0;
+  const long long M = (long long)n * gx * gy * gz;
+  const int plan = nrpn_conv3d_fwd_plan(n, gx, gy, gz, cin, cout, ksize, dtype);
+  if (plan == 1) return (int)(cdiv64(M, 256) * 2);
+  if (plan != 0 || g_conv_kb != 128 || (cin * 2) % 128 != 0) return 0;
+  return (int)(cdiv64(M, 128) * (cout <= 64 ? 4 : 2));
+}
+
+// nrpn_conv3d_fwd + partial BatchNorm statistics of the stored outputs from the same launch (finish them with nrpn_bn_stats_finalize).
+extern "C" int nrpn_conv3d_fwd_stats(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
+                                     int cout, int wrows, int ksize, int dtype, int flags, float *stats, nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && stats, "conv3d_fwd_stats: bad sizes / null statistics buffer");
+  NRPN_REQUIRE(nrpn_conv3d_fwd_stats_rows(n, gx, gy, gz, cin, cout, ksize, dtype) > 0 && !(flags & NRPN_CONV_OUT_F32) && wrows == cout,
+               "conv3d_fwd_stats: this shape does not run a kernel with fused statistics");
+  return conv3d_fwd_impl(x, wp, bias, nullptr, y, (long long)n * gx * gy * gz, gx, gy, gz, nullptr, cin, cout, wrows, ksize, dtype, flags,
+                         nullptr, stream, stats);
 }
 
 extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, void *y, int nseg, const int32_t *dims, int cin,

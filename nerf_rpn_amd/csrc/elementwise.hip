@@ -185,6 +185,17 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
   return NRPN_OK;
 }
 
+// Finish partial statistics produced elsewhere ([nparts][2][C] = per-part (sum, sum of squares) over disjoint row sets, e.g. by the conv
+// epilogue: nrpn_conv3d_fwd_stats) into mean / biased variance (+ running statistics), exactly as nrpn_bn_stats finishes its own slabs.
+extern "C" int nrpn_bn_stats_finalize(const float *partials, int nparts, int64_t rows, int c, float *mean, float *var, float *running_mean,
+                                      float *running_var, float momentum, nrpn_stream_t stream) {
+  NRPN_REQUIRE(partials && mean && var && nparts > 0 && rows > 0 && c > 0, "bn_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, as_stream(stream), partials, nparts, (long long)rows, c,
+                     mean, var, running_mean, running_var, momentum);
+  NRPN_LAUNCH_CHECK("bn_stats_finalize");
+  return NRPN_OK;
+}
+
 // y = relu?((x - mean) * rsqrt(var + eps) * gamma + beta)   -- grid-stride over 4-channel groups
 template <typename T>
 __global__ void bn_apply_kernel(const T *__restrict__ x, T *__restrict__ y, long long groups, int c, const float *__restrict__ mean,

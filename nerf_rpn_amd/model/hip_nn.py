@@ -16,7 +16,7 @@ def _pack_of(mod):
     return pk
 
 
-def conv3d(mod, x, relu=False, out_f32=False, segs=None, chain=0):
+def conv3d(mod, x, relu=False, out_f32=False, segs=None, chain=0, stats=None):
     """nn.Conv3d (k 1|3, stride 1, same padding; or the 4-channel k7 stem) on a channels-last tensor.
     ``segs``: x is a ragged list [1, sum voxels, 1, 1, C] of grids with these (X, Y, Z) dims (see ``ragged_cat``)."""
     k = mod.kernel_size[0]
@@ -34,8 +34,8 @@ def conv3d(mod, x, relu=False, out_f32=False, segs=None, chain=0):
         raise NotImplementedError(f"Conv3d k={k} stride={mod.stride} padding={mod.padding} has no HIP kernel yet")
     if segs is not None and (k == 7 or mod.stride[0] != 1):
         raise NotImplementedError("ragged voxel lists are supported by the stride-1 k1 / k3 convolutions only")
-    return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, (relu, chain) if chain else relu, out_f32, 1 if segs is None else (1, tuple(segs)),
-                            mod.weight, mod.bias)
+    mode = (relu, chain, stats) if stats is not None else ((relu, chain) if chain else relu)
+    return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, mode, out_f32, 1 if segs is None else (1, tuple(segs)), mod.weight, mod.bias)
 
 
 def ragged_cat(feats):
@@ -93,13 +93,16 @@ def bn_counters(root):
     return c
 
 
-def batch_norm(mod, x, relu, counted=False):
-    """``counted``: the caller already bumped this module's num_batches_tracked through a BNCounters.step() of this forward."""
+def batch_norm(mod, x, relu, counted=False, stats=None):
+    """``counted``: the caller already bumped this module's num_batches_tracked through a BNCounters.step() of this forward.
+    ``stats``: the holder handed to the conv that produced ``x`` (conv3d(..., stats=holder)); if that launch left partial statistics in it,
+    only their finish runs here instead of a statistics pass over ``x``."""
     training = mod.training or mod.running_mean is None
     if mod.training and mod.track_running_stats and mod.num_batches_tracked is not None and not counted:
         mod.num_batches_tracked.add_(1)
     return ops.BatchNormFn.apply(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, training,
-                                 mod.momentum if mod.momentum is not None else 0.1, mod.eps, relu)
+                                 mod.momentum if mod.momentum is not None else 0.1, mod.eps, relu,
+                                 stats.get("partials") if (stats and training) else None)
 
 
 def max_pool(mod, x):
@@ -120,9 +123,11 @@ def run_modules(mods, x, counted=False):
         nxt2 = mods[i + 2] if i + 2 < len(mods) else None
         if isinstance(m, nn.Conv3d):
             if isinstance(nxt, nn.BatchNorm3d):
-                x = conv3d(m, x)
+                # training-mode statistics come out of the conv's epilogue where its kernel has them (nrpn_conv3d_fwd_stats)
+                holder = {} if (nxt.training or nxt.running_mean is None) else None
+                x = conv3d(m, x, stats=holder)
                 fuse = isinstance(nxt2, nn.ReLU)
-                x = batch_norm(nxt, x, fuse, counted)
+                x = batch_norm(nxt, x, fuse, counted, holder)
                 i += 3 if fuse else 2
             elif isinstance(nxt, nn.ReLU):
                 x = conv3d(m, x, relu=True)

@@ -644,8 +644,10 @@ def _seg_dims(segs):
     return (ctypes.c_int32 * len(flat))(*flat)
 
 
-def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask=None):
-    """segs: None, or the (X, Y, Z) dims of the grids laid end to end in x = [1, sum(X*Y*Z), 1, 1, C] (ragged list)."""
+def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask=None, stats=None):
+    """segs: None, or the (X, Y, Z) dims of the grids laid end to end in x = [1, sum(X*Y*Z), 1, 1, C] (ragged list).
+    stats: None, or a dict that asks for BatchNorm statistics out of the conv epilogue: when the shape's kernel has them, the launch
+    fills stats['partials'] = f32 [P, 2, cout] (see nrpn_conv3d_fwd_stats); otherwise the dict stays empty."""
     import ctypes
     n, gx, gy, gz, cin = x.shape
     y = torch.empty((n, gx, gy, gz, cout), dtype=out_dtype, device=x.device)
@@ -653,6 +655,13 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask
         flags |= CONV_OUT_F32
     if bias is not None:
         flags |= CONV_BIAS
+    if stats is not None and segs is None and mask is None and out_dtype == x.dtype and wrows == cout:
+        rows = query("conv3d_fwd_stats_rows", n, gx, gy, gz, cin, cout, ksize, _dt(x))
+        if rows > 0:
+            part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+            call("conv3d_fwd_stats", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(part), _s())
+            stats["partials"] = part
+            return y
     wsb = query("conv3d_fwd_workspace_bytes", n, gx, gy, gz, cin, cout, ksize, _dt(x))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     if segs is None or ksize == 1:
@@ -699,8 +708,10 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, pack, rows_total, relu, out_f32, nw, *wb):
         segs = None
         chain = 0
-        if isinstance(relu, tuple):        # (relu, chain): see CHAIN_* below
-            relu, chain = relu
+        stats = None
+        if isinstance(relu, tuple):        # (relu, chain[, stats holder]): see CHAIN_* below and _conv_fwd
+            relu, chain, *rest = relu
+            stats = rest[0] if rest else None
         if isinstance(nw, tuple):          # (nw, segs): ragged voxel list, x = [1, sum voxels, 1, 1, C]
             nw, segs = nw
         weights, biases = wb[:nw], wb[nw:]
@@ -714,7 +725,7 @@ class ConvFn(torch.autograd.Function):
             if bias.numel() < rows_total:
                 bias = torch.cat([bias, bias.new_zeros(rows_total - bias.numel())])
         out_dtype = torch.float32 if out_f32 else x.dtype
-        y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs)
+        y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, stats)
         ctx.save_for_backward(x, y if relu else None, wpd, *weights)
         ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None, segs, chain)
         ctx.sinks = ([_sink(w) for w in weights], [_sink(b) for b in biases])
@@ -880,7 +891,7 @@ class BatchNormFn(torch.autograd.Function):
     """BatchNorm3d (+ fused ReLU) on channels-last rows; training uses per-rank batch statistics (no SyncBN, as the reference)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu, partials=None):
         _chk(x)
         c = x.shape[-1]
         rows = x.numel() // c
@@ -889,8 +900,11 @@ class BatchNormFn(torch.autograd.Function):
         if training:
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             var = torch.empty(c, dtype=torch.float32, device=dev)
-            ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=dev)
-            call("bn_stats", _p(x), rows, c, _dt(x), _p(mean), _p(var), _p(rmean), _p(rvar), float(momentum), _p(ws), _s())
+            if partials is not None:      # the producing conv left (sum, sum of squares) partials of x in its epilogue: only finish them
+                call("bn_stats_finalize", _p(partials), partials.shape[0], rows, c, _p(mean), _p(var), _p(rmean), _p(rvar), float(momentum), _s())
+            else:
+                ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=dev)
+                call("bn_stats", _p(x), rows, c, _dt(x), _p(mean), _p(var), _p(rmean), _p(rvar), float(momentum), _p(ws), _s())
         else:
             mean, var = rmean.float().contiguous(), rvar.float().contiguous()
         y = torch.empty_like(x)
@@ -923,7 +937,7 @@ class BatchNormFn(torch.autograd.Function):
         if bsink is not None:
             bsink.notify()
             dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class MaxPoolFn(torch.autograd.Function):

@@ -331,3 +331,51 @@ def test_ragged_conv_equals_per_grid_convs(grids, cin, cout, dtype, dev):
         assert relerr(x.grad.float().cpu(), b.cpu()) < tol
     assert relerr(conv.weight.grad.cpu(), ref[2].cpu()) < (1e-5 if dtype == torch.float32 else 1e-4)
     assert relerr(conv.bias.grad.cpu(), ref[3].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,grid,rows_expected", [
+    (64, 64, (1, 24, 20, 22), True),       # 128-row kernel, 64-column tiles (four row groups per tile), ragged last tile
+    (128, 128, (2, 16, 18, 20), True),     # 128-row kernel, 128-column tiles, two scenes
+    (256, 256, (1, 40, 40, 33), True),     # 256x256 kernel (>= 200 tiles), ragged last tile
+    (512, 512, (1, 20, 20, 20), False),    # K-sliced: no fused statistics, the holder stays empty
+])
+def test_batchnorm_statistics_from_the_conv_epilogue(cin, cout, grid, rows_expected, dev):
+    """conv -> BatchNorm3d (training): the conv launch leaves per-row-group (sum, sum of squares) of its STORED bf16 outputs
+    (nrpn_conv3d_fwd_stats) and BatchNorm only finishes them.  Output, batch statistics, running statistics and the gradients must
+    match the two-kernel statistics pass (nrpn_bn_stats) on the same conv output."""
+    from nerf_rpn_amd import lib, ops
+    from nerf_rpn_amd.model import hip_nn
+    n, gx, gy, gz = grid
+    rows = lib.query("conv3d_fwd_stats_rows", n, gx, gy, gz, cin, cout, 3, lib.BF16)
+    assert (rows > 0) == rows_expected, rows
+    torch.manual_seed(cin + gx)
+    conv = nn.Conv3d(cin, cout, 3, padding=1).to(dev)
+    bn = nn.BatchNorm3d(cout).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+        conv.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(n, gx, gy, gz, cin, device=dev).bfloat16()
+    out = {}
+    for fused in (True, False):
+        bn.running_mean.zero_()
+        bn.running_var.fill_(1.0)
+        xi = x.clone().requires_grad_(True)
+        holder = {} if fused else None
+        y = hip_nn.conv3d(conv, xi, stats=holder)
+        assert (fused and rows_expected) == bool(holder)                 # the fused path really ran (or really did not)
+        if holder:
+            assert tuple(holder["partials"].shape) == (rows, 2, cout)
+        z = hip_nn.batch_norm(bn, y, True, stats=holder)
+        (z.float() * torch.linspace(0.5, 1.5, cout, device=dev)).sum().backward()
+        out[fused] = (y.detach().clone(), z.detach().clone(), bn.running_mean.clone(), bn.running_var.clone(), xi.grad.clone(),
+                      conv.weight.grad.clone(), bn.weight.grad.clone())
+        conv.zero_grad(); bn.zero_grad()
+    assert torch.equal(out[True][0], out[False][0])                       # the conv output itself is unchanged
+    for a, b, tol in zip(out[True][2:4], out[False][2:4], (1e-6, 1e-6)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=tol), (a - b).abs().max()
+    zerr = (out[True][1].float() - out[False][1].float()).abs().max().item()
+    assert zerr <= 2 ** -6, zerr                                          # at most one bf16 ulp of an O(1) value where the statistics differ in the last bit
+    for a, b in zip(out[True][4:], out[False][4:]):
+        scale = b.float().abs().max().item() + 1e-12
+        assert (a.float() - b.float()).abs().max().item() <= 2e-2 * scale
