@@ -334,8 +334,8 @@ def test_ragged_conv_equals_per_grid_convs(grids, cin, cout, dtype, dev):
 
 
 @pytest.mark.parametrize("cin,cout,grid,rows_expected", [
-    (64, 64, (1, 24, 20, 22), True),       # 128-row kernel, 64-column tiles (four row groups per tile), ragged last tile
-    (128, 128, (2, 16, 18, 20), True),     # 128-row kernel, 128-column tiles, two scenes
+    (64, 64, (1, 40, 40, 21), True),       # 128-row kernel, 64-column tiles (four row groups per tile), ragged last tile
+    (128, 128, (2, 30, 30, 21), True),     # 128-row kernel, 128-column tiles, two scenes, ragged last tile
     (256, 256, (1, 40, 40, 33), True),     # 256x256 kernel (>= 200 tiles), ragged last tile
     (512, 512, (1, 20, 20, 20), False),    # K-sliced: no fused statistics, the holder stays empty
 ])
