@@ -93,6 +93,11 @@ def bn_counters(root):
     return c
 
 
+import os as _os
+
+FUSED_BN_STATS = _os.environ.get("NRPN_BN_FUSED_STATS", "1") != "0"      # A/B switch; default on
+
+
 def batch_norm(mod, x, relu, counted=False, stats=None):
     """``counted``: the caller already bumped this module's num_batches_tracked through a BNCounters.step() of this forward.
     ``stats``: the holder handed to the conv that produced ``x`` (conv3d(..., stats=holder)); if that launch left partial statistics in it,
@@ -124,7 +129,7 @@ def run_modules(mods, x, counted=False):
         if isinstance(m, nn.Conv3d):
             if isinstance(nxt, nn.BatchNorm3d):
                 # training-mode statistics come out of the conv's epilogue where its kernel has them (nrpn_conv3d_fwd_stats)
-                holder = {} if (nxt.training or nxt.running_mean is None) else None
+                holder = {} if (FUSED_BN_STATS and (nxt.training or nxt.running_mean is None)) else None
                 x = conv3d(m, x, stats=holder)
                 fuse = isinstance(nxt2, nn.ReLU)
                 x = batch_norm(nxt, x, fuse, counted, holder)
