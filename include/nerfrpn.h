@@ -402,7 +402,10 @@ int nrpn_groupnorm_bwd(const void *x, const void *y, const void *dy, void *dx, c
 /* Head epilogue for one level (fcos.py:104-128).  cls_out / box_out: f32 [rows, wrows] outputs of the fused 3x3x3 GEMMs
  * (cls_out col 0 = cls_logits, col 1 = centerness when !ctr_on_reg; box_out cols 0..reg_dim-1 = bbox_pred, col reg_dim =
  * centerness when ctr_on_reg).  reg = norm_reg ? [relu(scale*raw[:6]) * stride_mul, scale*raw[6:]] : exp(scale*raw).
- * The backward overwrites d_cls_out / d_box_out and ACCUMULATES d_scale (f32 scalar). */
+ * The backward overwrites d_cls_out / d_box_out and writes d_scale[0]; d_scale points to nrpn_fcos_reduce_floats() floats whose
+ * first two are ZERO on entry ([0] result, [1] ticket -- left zero --, then one partial per workgroup, summed in workgroup order: no
+ * floating-point atomics, the result does not depend on scheduling). */
+int nrpn_fcos_reduce_floats(void);
 int nrpn_fcos_head_out_f32(const float *cls_out, const float *box_out, int wrows, const float *scale, float stride_mul,
                            int norm_reg, int reg_dim, int ctr_on_reg, int64_t rows, float *logits, float *reg, float *ctr,
                            nrpn_stream_t stream);
@@ -419,8 +422,9 @@ int nrpn_fcos_gt_summary_f32(const float *gt, int count, int width, float *summa
 int nrpn_fcos_targets_f32(const float *summary, const int32_t *gt_offsets, int n, int levels, const int32_t *dims,
                           const int32_t *strides, const float *ori_sizes, float radius, int norm_reg, int reg_dim, int8_t *labels,
                           float *reg_targets, int32_t *num_pos, nrpn_stream_t stream);
-/* torchvision sigmoid_focal_loss(alpha, gamma=2, reduction='sum') over labels >= 0 (loss.py:541-545): loss_sum f32 scalar
- * (overwritten) and, when dlogits != NULL, d loss_sum / d logit per element. */
+/* torchvision sigmoid_focal_loss(alpha, gamma=2, reduction='sum') over labels >= 0 (loss.py:541-545): loss_sum[0] (overwritten;
+ * loss_sum points to nrpn_fcos_reduce_floats() floats of scratch, ordered workgroup partials as above) and, when dlogits != NULL,
+ * d loss_sum / d logit per element. */
 int nrpn_fcos_focal_f32(const float *logits, const int8_t *labels, int64_t count, float alpha, float *loss_sum, float *dlogits,
                         nrpn_stream_t stream);
 /* FCOSPostProcessor.forward_for_single_feature_map, all levels at once (inference.py:56-88): score = sigmoid(cls) *

@@ -274,6 +274,29 @@ __global__ void fcos_head_out_kernel(const float *__restrict__ cls_out, const fl
   }
 }
 
+// Deterministic grid-wide sum of one value per workgroup: buf = [0] result, [1] ticket (zero before the launch; left zero), [2 + block]
+// partials.  Every workgroup stores its partial, the one drawing the last ticket adds them in block order (cf. sumsq_kernel): the result
+// does not depend on the order the workgroups finish in.  All threads of the workgroup must call it; `mine` is taken from thread 0.
+constexpr int kOrderedSumFloats = 2 + 1024;
+__device__ __forceinline__ void ordered_block_sum(float *buf, float mine) {
+  __shared__ bool last;
+  __shared__ float part[256];
+  if (threadIdx.x == 0) {
+    buf[2 + blockIdx.x] = mine;
+    __threadfence();
+    last = atomicAdd(reinterpret_cast<unsigned *>(buf + 1), 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int k = threadIdx.x; k < (int)gridDim.x; k += blockDim.x) t += buf[2 + k];      // fixed assignment of partials to threads ...
+  part[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }      // ... fixed tree
+  if (threadIdx.x == 0) { buf[0] = part[0]; reinterpret_cast<unsigned *>(buf)[1] = 0u; }
+}
+
 __global__ void __launch_bounds__(256) fcos_head_out_bwd_kernel(const float *__restrict__ box_out, int wrows, const float *__restrict__ scale,
                                                                 float stride_mul, int norm_reg, int D, int ctr_on_reg, long long rows,
                                                                 const float *__restrict__ d_logits, const float *__restrict__ d_reg,
@@ -302,7 +325,7 @@ __global__ void __launch_bounds__(256) fcos_head_out_bwd_kernel(const float *__r
   red[threadIdx.x] = ds;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0 && red[0] != 0.f) atomicAdd(d_scale, red[0]);
+  ordered_block_sum(d_scale, red[0]);
 }
 
 extern "C" int nrpn_fcos_head_out_f32(const float *cls_out, const float *box_out, int wrows, const float *scale, float stride_mul,
@@ -315,6 +338,8 @@ extern "C" int nrpn_fcos_head_out_f32(const float *cls_out, const float *box_out
   NRPN_LAUNCH_CHECK("fcos_head_out");
   return NRPN_OK;
 }
+
+extern "C" int nrpn_fcos_reduce_floats(void) { return kOrderedSumFloats; }
 
 extern "C" int nrpn_fcos_head_out_bwd_f32(const float *box_out, int wrows, const float *scale, float stride_mul, int norm_reg, int reg_dim,
                                           int ctr_on_reg, int64_t rows, const float *d_logits, const float *d_reg, const float *d_ctr,
@@ -517,14 +542,14 @@ __global__ void __launch_bounds__(256) fcos_focal_kernel(const float *__restrict
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) atomicAdd(loss_sum, red[0]);
+  ordered_block_sum(loss_sum, red[0]);
 }
 
 extern "C" int nrpn_fcos_focal_f32(const float *logits, const int8_t *labels, int64_t count, float alpha, float *loss_sum, float *dlogits,
                                    nrpn_stream_t stream) {
   NRPN_REQUIRE(logits && labels && loss_sum && count > 0, "fcos_focal: bad args");
   hipStream_t st = as_stream(stream);
-  NRPN_HIP(hipMemsetAsync(loss_sum, 0, 4, st));
+  NRPN_HIP(hipMemsetAsync(loss_sum, 0, 8, st));      // result + ticket
   hipLaunchKernelGGL(fcos_focal_kernel, dim3(ew_blocks(count, 1024)), dim3(256), 0, st, logits, reinterpret_cast<const signed char *>(labels),
                      (long long)count, alpha, loss_sum, dlogits);
   NRPN_LAUNCH_CHECK("fcos_focal");

@@ -317,6 +317,7 @@ extern "C" int nrpn_patch_merge(const void *src, void *dst, int n, int gx, int g
 // shifted-window attention, window 4x4x4 (64 tokens), head_dim 32
 // =====================================================================================================================
 constexpr int WS = 4, WT = 64, HD = 32;
+constexpr int kUnitWs = 408;      // backward workspace floats per (window, head) unit: [0,343) table partial, [344,408) padded-token (k | v) bias partial
 
 struct AttnGeom {
   int n, gx, gy, gz;      // token grid
@@ -515,9 +516,9 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T *__restrict
     }
   }
   __syncthreads();
-  if (dbias_pad && padacc[i] != 0.f) atomicAdd(dbias_pad + (i < HD ? C + off + i : 2 * C + off + i - HD), padacc[i]);
-  float *tw = tabws + ((long long)w * g.heads + head) * 343;       // this unit's partial table (summed by attn_table_reduce_kernel)
+  float *tw = tabws + ((long long)w * g.heads + head) * kUnitWs;   // this unit's partials (summed by attn_table_reduce_kernel / attn_pad_reduce_kernel)
   for (int k = i; k < 343; k += 64) tw[k] = tab[k];
+  if (dbias_pad) tw[344 + i] = padacc[i];      // (k | v) bias gradient reaching this unit's padded tokens: plain store, ordered sum later
 }
 
 // =====================================================================================================================
@@ -814,9 +815,9 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16s *_
     }
   }
   __syncthreads();
-  if (dbias_pad && padacc[lane] != 0.f) atomicAdd(dbias_pad + (lane < 32 ? C + off + lane : 2 * C + off + lane - 32), padacc[lane]);
-  float *tw = tabws + ((long long)w * g.heads + head) * 343;       // this unit's partial table (summed by attn_table_reduce_kernel)
+  float *tw = tabws + ((long long)w * g.heads + head) * kUnitWs;   // this unit's partials (summed by attn_table_reduce_kernel / attn_pad_reduce_kernel)
   for (int k = lane; k < 343; k += 64) tw[k] = tabg[k];
+  if (dbias_pad) tw[344 + lane] = padacc[lane];
 }
 
 // dtable[k][head] = sum over the windows' partial tables; block = (64 table entries, 16 window lanes), grid = (6, heads)
@@ -828,8 +829,8 @@ __global__ void attn_table_reduce_kernel(const float *__restrict__ tabws, float 
     int w = threadIdx.y;
     for (; w + 48 < windows; w += 64)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] += tabws[((long long)(w + 16 * u) * heads + head) * 343 + k];
-    for (; w < windows; w += 16) a[0] += tabws[((long long)w * heads + head) * 343 + k];
+      for (int u = 0; u < 4; ++u) a[u] += tabws[((long long)(w + 16 * u) * heads + head) * kUnitWs + k];
+    for (; w < windows; w += 16) a[0] += tabws[((long long)w * heads + head) * kUnitWs + k];
   }
   red[threadIdx.y][threadIdx.x] = (a[0] + a[1]) + (a[2] + a[3]);
   __syncthreads();
@@ -837,6 +838,22 @@ __global__ void attn_table_reduce_kernel(const float *__restrict__ tabws, float 
     float sum = 0.f;
     for (int q = 0; q < 16; ++q) sum += red[q][threadIdx.x];
     dtable[k * heads + head] = sum;
+  }
+}
+
+// dbias_pad[C + head*32 + d] (k half) / [2C + head*32 + d] (v half) = sum over the windows' pad partials, in window order (no atomics);
+// block = (64 values, 16 window lanes), grid = heads
+__global__ void attn_pad_reduce_kernel(const float *__restrict__ tabws, float *__restrict__ dbias_pad, int windows, int heads, int C) {
+  __shared__ float red[16][64];
+  const int head = blockIdx.x, i = threadIdx.x;
+  float a = 0.f;
+  for (int w = threadIdx.y; w < windows; w += 16) a += tabws[((long long)w * heads + head) * kUnitWs + 344 + i];
+  red[threadIdx.y][i] = a;
+  __syncthreads();
+  if (threadIdx.y == 0) {
+    float sum = 0.f;
+    for (int q = 0; q < 16; ++q) sum += red[q][i];
+    dbias_pad[(i < HD ? C : 2 * C) + head * HD + (i & (HD - 1))] = sum;
   }
 }
 
@@ -873,7 +890,7 @@ extern "C" int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, cons
 
 extern "C" size_t nrpn_window_attn_bwd_workspace_bytes(int n, int gx, int gy, int gz, int heads) {
   const long long windows = (long long)n * ((gx + WS - 1) / WS) * ((gy + WS - 1) / WS) * ((gz + WS - 1) / WS);
-  return (size_t)(windows * heads * 343 * 4);
+  return (size_t)(windows * heads * kUnitWs * 4);
 }
 
 extern "C" int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, const void *dout,
@@ -895,6 +912,7 @@ extern "C" int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, cons
                                          (const T *)dout, (T *)dqkv, tabws, dbias_pad, g));
   }
   hipLaunchKernelGGL(attn_table_reduce_kernel, dim3(6, heads), dim3(64, 16), 0, st, (const float *)tabws, dtable, windows, heads);
+  if (dbias_pad) hipLaunchKernelGGL(attn_pad_reduce_kernel, dim3(heads), dim3(64, 16), 0, st, (const float *)tabws, dbias_pad, windows, heads, c);
   NRPN_LAUNCH_CHECK("window_attn_bwd");
   return NRPN_OK;
 }

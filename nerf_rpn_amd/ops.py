@@ -1262,13 +1262,13 @@ class FcosHeadOutFn(torch.autograd.Function):
         wrows, rows, stride_mul, norm_reg, reg_dim, ctr_on_reg, shape = ctx.meta
         d_cls = torch.empty(shape, dtype=torch.float32, device=box_out.device)
         d_box = torch.empty(shape, dtype=torch.float32, device=box_out.device)
-        d_scale = torch.zeros(1, dtype=torch.float32, device=box_out.device)
+        d_scale = torch.zeros(query("fcos_reduce_floats"), dtype=torch.float32, device=box_out.device)     # [0] result, [1] ticket, partials
         dl = d_logits.contiguous() if d_logits is not None else None
         dr = d_reg.contiguous() if d_reg is not None else None
         dc = d_ctr.contiguous() if d_ctr is not None else None
         call("fcos_head_out_bwd_f32", _p(box_out), wrows, _p(sc), stride_mul, norm_reg, reg_dim, ctr_on_reg, rows, _p(dl), _p(dr), _p(dc),
              _p(d_cls), _p(d_box), _p(d_scale), _s())
-        return d_cls, d_box, d_scale, None, None, None, None
+        return d_cls, d_box, d_scale[:1], None, None, None, None
 
 
 class FcosGeometry:
@@ -1336,7 +1336,7 @@ class FocalLossFn(torch.autograd.Function):
     def forward(ctx, logits, labels, alpha):
         logits = logits.contiguous()
         _chk(logits, labels)
-        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        out = torch.empty(query("fcos_reduce_floats"), dtype=torch.float32, device=logits.device)      # [0] result, [1] ticket, partials
         grad = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
         call("fcos_focal_f32", _p(logits), _p(labels), logits.numel(), float(alpha), _p(out), _p(grad), _s())
         ctx.save_for_backward(grad)

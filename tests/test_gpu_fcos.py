@@ -204,3 +204,24 @@ def test_empty_targets_and_bf16(dev):
     _, l32, _ = m([x], [gt])
     for k in l32:
         assert torch.isfinite(l16[k]) and abs(l16[k].item() - l32[k].item()) < 0.1 * max(1.0, abs(l32[k].item())), (k, l16[k], l32[k])
+
+
+@pytest.mark.parametrize("backbone,dtype", [("vgg", torch.float32), ("swin", torch.bfloat16)])
+def test_two_runs_give_bit_identical_gradients(backbone, dtype, dev):
+    """No floating-point atomics on the FCOS / Swin training path either: the focal-loss sum and the Scale gradient are ordered workgroup
+    partials, the padded-token bias gradient of window attention is per-unit partials summed in window order.  Two forward/backward
+    runs on the same batch (a grid that needs window padding) agree bit for bit."""
+    m = build(True, backbone, dev).train()
+    m.set_compute_dtype(dtype)
+    x = scene((40, 36, 44), 3).to(dev)
+    gt = torch.tensor([[20., 18., 16., 14., 12., 10., 0.3], [12., 24., 30., 10., 9., 12., -0.8]], device=dev)
+    grads, losses = [], []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        _, ls, _ = m([x], [gt])
+        loss = ls["loss_cls"] + ls["loss_reg"] + ls["loss_centerness"]
+        loss.backward()
+        losses.append(torch.stack([ls[k].detach() for k in sorted(ls)]))
+        grads.append(torch.cat([p.grad.reshape(-1).float() for p in m.parameters() if p.grad is not None]))
+    assert torch.equal(losses[0], losses[1]), (losses[0] - losses[1]).abs().max().item()
+    assert torch.equal(grads[0], grads[1]), (grads[0] - grads[1]).abs().max().item()

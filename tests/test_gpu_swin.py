@@ -173,3 +173,22 @@ def test_bf16_mfma_attention_matches_valu_kernels(shape, heads, shift, dev):
     names = ["y", "x"] + [n for n, _ in att.named_parameters()]
     for n, a, r in zip(names, res[1], res[0]):
         assert rel(a, r) < 3e-2, (n, rel(a, r))
+
+
+def test_swin_rpn_two_runs_give_bit_identical_gradients(dev):
+    """Swin-S + RPN (OBB) on a grid whose coarser stages need window padding: bit-identical gradients run to run (ordered per-unit
+    partials for the relative-position table AND the padded-token bias gradient; no floating-point atomics across workgroups)."""
+    from test_gpu_e2e import build, scene
+    m = build(True, 160, dev, backbone="swin", sd=0.0).train()
+    m.set_compute_dtype(torch.bfloat16)
+    x = scene((40, 36, 44), 5).to(dev)
+    gt = torch.tensor([[20., 18., 16., 14., 12., 10., 0.3], [12., 24., 30., 10., 9., 12., -0.8]], device=dev)
+    labels = None
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(1)                      # same anchor sample in both runs
+        _, ls, _ = m([x], [gt])
+        (ls["loss_objectness"] + 5.0 * ls["loss_rpn_box_reg"]).backward()
+        grads.append(torch.cat([p.grad.reshape(-1).float() for p in m.parameters() if p.grad is not None]))
+    assert torch.equal(grads[0], grads[1]), (grads[0] - grads[1]).abs().max().item()
