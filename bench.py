@@ -89,19 +89,20 @@ class ConvProbe:
         orig = self._orig
 
         def call(name, *args):
-            if not self.enabled or name not in ("conv3d_fwd", "conv3d_wgrad"):
+            if not self.enabled or name not in ("conv3d_fwd", "conv3d_fwd_stats", "conv3d_wgrad"):
                 return orig(name, *args)
+            called, name = name, ("conv3d_fwd" if name == "conv3d_fwd_stats" else name)     # same kernel + the BatchNorm column sums; same leading arguments
             n_, gx_, gy_, gz_, cin_, _, wrows_, k_ = args[4:12]
             if 2.0 * n_ * gx_ * gy_ * gz_ * cin_ * wrows_ * (k_ ** 3) < 1e10:     # only the heavy launches (>= 10 GFLOP) are timed
-                return orig(name, *args)
+                return orig(called, *args)
             if self.only is not None and ((name, (n_ * gx_ * gy_ * gz_, cin_, wrows_, k_)) != self.only or self.ops.IN_BACKWARD[0]):
                 # timed region: forward-pass launches of the dominant kernel only; its
                 # dgrad launches share the GPU with the weight-gradient side stream, so their wall time is not a kernel duration
-                return orig(name, *args)
+                return orig(called, *args)
             a = torch.cuda.Event(enable_timing=True)
             b = torch.cuda.Event(enable_timing=True)
             a.record()
-            rc = orig(name, *args)
+            rc = orig(called, *args)
             b.record()
             if name == "conv3d_fwd":
                 n, gx, gy, gz, cin, cout, wrows, k = args[4:12]
