@@ -266,8 +266,6 @@ int nrpn_set_conv_lds_dma(int on);
 int nrpn_set_conv_tile_m(int bm);
 /* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
 int nrpn_set_conv_stagger(int on);
-/* tuning knob: 1 (default) = bf16 layers (Cout > 64) whose 128-row tiling yields < 128 workgroups use 64-row tiles (fewer or no K slices) */
-int nrpn_set_conv_bm64(int on);
 /* tuning knob: 1 (default) = mid-size grids (16..199 tiles of 256x256) run the 256x256 kernel on K slices; 0 = 128-row kernel */
 int nrpn_set_conv_big_split(int on);
 /* tuning knob: 1 (default) = 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256; 0 = always the 128x128 kernel */

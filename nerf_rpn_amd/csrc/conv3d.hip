@@ -1021,21 +1021,10 @@ __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float
   }
 }
 
-// 64-row M tiles (same kernel template, BM = 64: each wave 32x64) for bf16 layers whose 128-row tiling would leave more than half of
-// the 256 CUs idle and force a K split: twice the workgroups, half (or none) of the fp32 partial traffic and epilogue passes.
-static int g_conv_bm64 = 1;        // tuning knob (nrpn_set_conv_bm64)
-static int g_conv_bm_knob();       // = g_conv_bm, defined below
-static int g_conv_glds_knob();
-static int conv_tile_rows(long long M, int cout, int cin, int elem_bytes) {
-  if (!g_conv_bm64 || elem_bytes != 2 || cout <= 64 || !g_conv_glds_knob() || g_conv_bm_knob() != 0 || g_conv_kb_value() != 128 || (cin * 2) % 128 != 0)
-    return 128;
-  return cdiv64(M, 128) * ((cout + 127) / 128) < 128 ? 64 : 128;
-}
-
 // split the K loop when the (M, N) tiling alone cannot fill 256 CUs (the 10^3 / 5^3 pyramid levels)
 static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes) {
   const int bn = cout <= 64 ? 64 : 128;
-  const long long tiles = cdiv64(M, conv_tile_rows(M, cout, cin, elem_bytes)) * ((cout + bn - 1) / bn);
+  const long long tiles = cdiv64(M, 128) * ((cout + bn - 1) / bn);
   const int kb = (g_conv_kb_value() == 128 && (cin * elem_bytes) % 128 == 0) ? 128 : 64;
   const int nk = taps * (cin * elem_bytes / kb);
   if (tiles >= 128 || nk < 16) return 1;
@@ -1051,9 +1040,6 @@ static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes)
 static int g_conv_glds = 1;   // 1: LDS-DMA loads (buffer_load ... lds), 0: register-staged loads
 extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
 static int g_conv_bm = 0;     // 0: choose per shape; 128 / 256 / 512: force the tile (tuning knob, tools/bench_tile.py)
-static int g_conv_bm_knob() { return g_conv_bm; }
-static int g_conv_glds_knob() { return g_conv_glds; }
-extern "C" int nrpn_set_conv_bm64(int on) { g_conv_bm64 = on ? 1 : 0; return NRPN_OK; }
 
 // Mid-size grids (20^3: M = 8000) give only 32-64 tiles of 256x256: run the big kernel on K slices whose fp32 partials are
 // written with plain stores to ws[z][M][Cout] and summed by the epilogue (no atomics).  Returns the slice count, 0 = not used.
@@ -1109,8 +1095,7 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   const long long tiles_big = cdiv64(a.M, 256) * ((a.Cout + 255) / 256);
   const bool huge = can && a.Cout >= 256 && (a.slices || g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
   const bool big = can && !huge && g_conv_bm == 256 && a.segs.n == 0;      // wave-specialised 256x128: on par with 128x128 (measured), opt-in only
-  const bool small = MODE == 0 && !big && !huge && !a.slices && conv_tile_rows(a.M, a.Cout, a.Cin, (int)sizeof(T)) == 64;
-  const int bm = (big || huge) ? 256 : (small ? 64 : 128);
+  const int bm = (big || huge) ? 256 : 128;
   if (a.stats) {      // fused BatchNorm statistics exist in the staged bf16 epilogues of the 128-row and 256x256 kernels only
     const bool staged = MODE == 0 && sizeof(T) == 2 && !out_f32 && (a.Cout & 7) == 0 && a.ksplit <= 1 && !big && (huge || wide);
     if (!staged) return nrpn_fail(NRPN_ERR_ARG, "conv3d_fwd_stats: this shape does not run a kernel with fused statistics (ask nrpn_conv3d_fwd_stats_rows first)");
@@ -1148,12 +1133,6 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
         NRPN_LDS((conv_igemm_ws_kernel<false>), (int)lds_);
         hipLaunchKernelGGL(conv_igemm_ws_kernel<false>, grid, dim3(512), lds_, st, a);
       }
-    }
-  } else if (small) {
-    if constexpr (MODE == 0 && sizeof(T) == 2) {
-      const size_t lds_ = 2 * (size_t)(64 + 128) * 128;
-      if (out_f32) rc = launch_igemm(conv_igemm_kernel<T, 128, 0, true, 128, true, 64>, grid, lds_, st, a);
-      else rc = launch_igemm(conv_igemm_kernel<T, 128, 0, false, 128, true, 64>, grid, lds_, st, a);
     }
   } else if (bn == 64) { if (out_f32) NRPN_LC2(64, true); else NRPN_LC2(64, false); }
   else { if (out_f32) NRPN_LC2(128, true); else NRPN_LC2(128, false); }
@@ -1250,7 +1229,6 @@ extern "C" int nrpn_conv3d_fwd_stats_rows(int n, int gx, int gy, int gz, int cin
   const int plan = nrpn_conv3d_fwd_plan(n, gx, gy, gz, cin, cout, ksize, dtype);
   if (plan == 1) return (int)(cdiv64(M, 256) * 2);
   if (plan != 0 || g_conv_kb != 128 || (cin * 2) % 128 != 0) return 0;
-  if (conv_tile_rows(M, cout, cin, 2) == 64) return (int)(cdiv64(M, 64) * 2);
   return (int)(cdiv64(M, 128) * (cout <= 64 ? 4 : 2));
 }
 
