@@ -7,7 +7,7 @@
 // Design for the part: the reference runs one thread per (roi, channel, bin) on an NCWLH tensor, so every thread recomputes the
 // sample positions and the eight taps of a sample are eight scattered scalars.  Here one thread owns 4 consecutive channels of one
 // (roi, bin): the 64 lanes of a wave cover 256 channels of the same bin, every tap is one coalesced 8/16-byte load per lane, and the
-// sample geometry is wave-uniform.  The backward scatters through 64-bit FIXED-POINT integer atomics (2^-32 resolution) into a
+// sample geometry is wave-uniform.  The backward scatters through 64-bit FIXED-POINT integer atomics (2^-44 resolution) into a
 // workspace and converts once: integer addition is associative, so the gradient is bit-identical from run to run, unlike the
 // reference's fp32 atomicAdd (:329-336) -- and needs no RoI sorting.
 // Address of feature element (x, y, z) is ((x*Y + y)*Z + z)*C + c for every shape (the reference's index expression is only that
@@ -94,19 +94,31 @@ __device__ __forceinline__ void sample_xyz(const Roi &o, int pw, int pl, int ph,
   z = zz + o.ch;
 }
 
-constexpr double kFix = 4294967296.0;        // 2^32
+// 2^44 fixed point in a signed 64-bit accumulator: contributions of 1e-9 (a mean loss over ~1000 RoIs spread over 8..64 samples) keep
+// 4+ significant digits, values down to 6e-14 survive, and the sum may reach +-2^19 before it would wrap; a single contribution is
+// clamped to +-2^18 so that one outlier cannot wrap the accumulator on its own.
+constexpr double kFix = 17592186044416.0;     // 2^44
+constexpr float kFixClamp = 262144.f;         // 2^18
 
 // MODE 0: forward  out[bin][c] = mean of samples;  MODE 1: backward scatter of grad_out[bin][c] * w / count (fixed point)
 template <typename T, int MODE>
 __global__ void __launch_bounds__(64) roi_align_kernel(const T *__restrict__ feat, const float *__restrict__ rois, int width, int length, int height,
                                                        int channels, float scale, int pw_n, int pl_n, int ph_n, int sampling_ratio,
-                                                       T *__restrict__ out, const T *__restrict__ grad_out, long long *__restrict__ ws) {
+                                                       T *__restrict__ out, const T *__restrict__ grad_out, long long *__restrict__ ws,
+                                                       int nbatch) {
   const int bins = pw_n * pl_n * ph_n;
   const int bin = blockIdx.x % bins;
   const long long n = blockIdx.x / bins;
   const int ph = bin % ph_n, pl = (bin / ph_n) % pl_n, pw = bin / (ph_n * pl_n);
   const Roi o = roi_setup(rois + n * 8, scale, pw_n, pl_n, ph_n, sampling_ratio);
   const long long base = (long long)o.batch * width * length * height;
+  if (o.batch < 0 || o.batch >= nbatch) {      // a bad batch index would read / atomically write out of bounds: the RoI pools to zeros
+    if (MODE == 0) {
+      const f4 z = {0.f, 0.f, 0.f, 0.f};
+      for (int cg = threadIdx.x * 4; cg < channels; cg += 256) v4<T>::st(out + ((long long)n * bins + bin) * channels + cg, z);
+    }
+    return;
+  }
   for (int cg = threadIdx.x * 4; cg < channels; cg += 256) {
     f4 acc = {0.f, 0.f, 0.f, 0.f};
     f4 top = {0.f, 0.f, 0.f, 0.f};
@@ -134,7 +146,7 @@ __global__ void __launch_bounds__(64) roi_align_kernel(const T *__restrict__ fea
               long long *dst = ws + (base + tap_voxel(t, k, length, height)) * channels + cg;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float g = top[q] * t.w[k] / o.count;
+                const float g = fminf(fmaxf(top[q] * t.w[k] / o.count, -kFixClamp), kFixClamp);
                 if (g != 0.f) atomicAdd(reinterpret_cast<unsigned long long *>(dst + q), (unsigned long long)__double2ll_rn((double)g * kFix));
               }
             }
@@ -172,10 +184,10 @@ extern "C" int nrpn_roi_align_rotated_3d_fwd(const void *feat, const float *rois
   const dim3 grid((unsigned)(num_rois * pw * pl * ph));
   if (dtype == NRPN_F32)
     hipLaunchKernelGGL((roi_align_kernel<float, 0>), grid, dim3(64), 0, as_stream(stream), (const float *)feat, rois, x, y, z, c, spatial_scale, pw,
-                       pl, ph, sampling_ratio, (float *)out, (const float *)nullptr, (long long *)nullptr);
+                       pl, ph, sampling_ratio, (float *)out, (const float *)nullptr, (long long *)nullptr, n);
   else
     hipLaunchKernelGGL((roi_align_kernel<bf16s, 0>), grid, dim3(64), 0, as_stream(stream), (const bf16s *)feat, rois, x, y, z, c, spatial_scale,
-                       pw, pl, ph, sampling_ratio, (bf16s *)out, (const bf16s *)nullptr, (long long *)nullptr);
+                       pw, pl, ph, sampling_ratio, (bf16s *)out, (const bf16s *)nullptr, (long long *)nullptr, n);
   NRPN_LAUNCH_CHECK("roi_align_rotated_3d_fwd");
   return NRPN_OK;
 }
@@ -194,10 +206,10 @@ extern "C" int nrpn_roi_align_rotated_3d_bwd(const void *grad_out, const float *
     const dim3 grid((unsigned)(num_rois * pw * pl * ph));
     if (dtype == NRPN_F32)
       hipLaunchKernelGGL((roi_align_kernel<float, 1>), grid, dim3(64), 0, st, (const float *)nullptr, rois, x, y, z, c, spatial_scale, pw, pl, ph,
-                         sampling_ratio, (float *)nullptr, (const float *)grad_out, (long long *)workspace);
+                         sampling_ratio, (float *)nullptr, (const float *)grad_out, (long long *)workspace, n);
     else
       hipLaunchKernelGGL((roi_align_kernel<bf16s, 1>), grid, dim3(64), 0, st, (const bf16s *)nullptr, rois, x, y, z, c, spatial_scale, pw, pl, ph,
-                         sampling_ratio, (bf16s *)nullptr, (const bf16s *)grad_out, (long long *)workspace);
+                         sampling_ratio, (bf16s *)nullptr, (const bf16s *)grad_out, (long long *)workspace, n);
   }
   const int blocks = (int)min((long long)8192, (count + 255) / 256);
   if (dtype == NRPN_F32) hipLaunchKernelGGL(fixed_to_float_kernel<float>, dim3(blocks), dim3(256), 0, st, (const long long *)workspace, (float *)grad_in, count);

@@ -110,7 +110,10 @@ class RPNHead(nn.Module):
             for i, cv in enumerate(convs):
                 chain = ops.CHAIN_GRAD_PREMASKED | (ops.CHAIN_MASK_INPUT_GRAD if i > 0 else 0)
                 t = hip_nn.conv3d(cv, t, relu=True, chain=chain)
-            outs.append(ops.ConvFn.apply(t, self._pack, self.head_rows, (False, ops.CHAIN_MASK_INPUT_GRAD), True, 2, self.cls_logits.weight,
+            # the output GEMM may mask its input gradient only when its input IS the ReLU output of a private head conv: with
+            # conv_depth == 0 it reads the raw FPN feature (other consumers, no ReLU) and must hand back the full gradient
+            out_chain = ops.CHAIN_MASK_INPUT_GRAD if convs else 0
+            outs.append(ops.ConvFn.apply(t, self._pack, self.head_rows, (False, out_chain), True, 2, self.cls_logits.weight,
                                          self.bbox_pred.weight, self.cls_logits.bias, self.bbox_pred.bias))
         return outs
 

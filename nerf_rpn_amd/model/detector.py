@@ -112,6 +112,14 @@ class ROIPool(nn.Module):
         self.feature_extracting_type = feature_extracting_type
         self.canonical_scale, self.canonical_level = max_res, len(spatial_scale)
         self.remap = remap
+        if not use_cuda:
+            # The reference's default (use_cuda=False) max-pools integer crops (AABB) or an 8-corner "interpolation" grid followed by
+            # max-pool / trilinear resize (OBB, ``feature_extracting_type``), detector.py:264-438.  Only the RoIAlign op path
+            # (``--use_cuda``) exists here: say so instead of silently producing different features for a reference-trained RCNN.
+            import warnings
+            warnings.warn("ROIPool: use_cuda=False / feature_extracting_type=%r are not implemented on the HIP path; the rotated RoIAlign "
+                          "kernel (the reference's --use_cuda path) is used instead -- RCNN checkpoints trained with the reference's "
+                          "default pooling will not reproduce their scores" % (feature_extracting_type,), stacklevel=2)
         self.use_cuda = True
         self.align = ROIAlignRotated3D(self.output_size, sampling_ratio=0)
 

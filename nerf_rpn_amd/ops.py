@@ -572,6 +572,7 @@ class ArenaWeights:
             ev.record(side)
         _DGRAD_READY["event"] = ev
         _DGRAD_READY["waited"] = set()
+        _WGRAD_SIDE["dirty"] = True      # a step() with no backward in between still joins the side stream before it rewrites the arena
 
 
 _DGRAD_READY = {"event": None, "waited": set()}
@@ -674,13 +675,16 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask
 
 
 # wgrad workspace = [27-bit tap mask per voxel (k3) | per-slice bias partials]; the masks depend only on the grid, so one workspace per
-# grid shape is kept and the masks are built once (NRPN_WGRAD_MASK_READY afterwards).  All launches of a process go to one stream
-# per device here; the bias partials are consumed by the same C call that writes them.
+# (grid shape, stream) is kept and the masks are built once (NRPN_WGRAD_MASK_READY afterwards); the bias partials are consumed by the
+# same C call that writes them, or by the reduce_slices launch that follows it on the same stream.
 _WGRAD_WS = {}
 
 
 def _wgrad_workspace(device, key, nbytes):
-    key = (device.index,) + key
+    # keyed by the stream the wgrad is enqueued on as well: a layer with a frozen parameter keeps its wgrad on the main stream while
+    # arena layers of the same grid shape run on the side stream -- their bias partials (and the one-time mask build) must not share
+    # a buffer across streams
+    key = (device.index, _s()) + key
     ent = _WGRAD_WS.get(key)
     if ent is None or ent[0].numel() < nbytes:
         ent = [torch.empty(nbytes, dtype=torch.uint8, device=device), False]

@@ -96,6 +96,41 @@ def parse_args(argv=None):
     return build_parser().parse_args(argv)
 
 
+def sync_module_from_rank0(module, group=None):
+    """Broadcast rank 0's parameters and buffers to every rank (one flat buffer per dtype: a few large transfers instead of one
+    collective per tensor)."""
+    by_dtype = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, ts in by_dtype.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=0, group=group)
+        off = 0
+        with torch.no_grad():
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
+def allreduce_mean_gradients(params, world_size, group=None):
+    """Mean of the gradients over the ranks with ONE all-reduce of a flattened bucket (parameters without a gradient on this rank
+    contribute zeros, so every rank reduces the same layout)."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    dist.all_reduce(flat, group=group)
+    flat /= world_size
+    off = 0
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+
+
 class Trainer:
     def __init__(self, args, rank=0, world_size=1, device_id=None, logger=None):
         self.args, self.rank, self.world_size, self.device_id = args, rank, world_size, device_id
@@ -109,7 +144,8 @@ class Trainer:
         self.sample_model = ProposalTargetLayer(args.n_classes, batch_size=args.cls_batch_size, fg_fraction=args.fg_fraction,
                                                 fg_threshold=args.fg_threshold, bg_threshold=args.bg_threshold, is_rotated_bbox=args.rotated_bbox)
         self.pooling_model = ROIPool(args.output_size, args.spatial_scale, args.enlarge_scale, is_rotated_bbox=args.rotated_bbox,
-                                     feature_extracting_type=args.feature_extracting_type, max_res=args.resolution, remap=args.remap)
+                                     feature_extracting_type=args.feature_extracting_type, max_res=args.resolution, remap=args.remap,
+                                     use_cuda=args.use_cuda)
         self.RCNN_model = RCNN(args.feature_input_dim, Bottleneck, args.n_classes, args.output_size, is_add_layer=args.is_add_layer,
                                is_rotated_bbox=args.rotated_bbox, is_flatten=args.is_flatten)
         self.min_size = 1e-3
@@ -126,6 +162,11 @@ class Trainer:
                 self.backbone.load_state_dict(ck['backbone_state_dict'])
         self.model = Classification_Model(self.backbone, self.sample_model, self.pooling_model, self.RCNN_model, n_classes=args.n_classes,
                                           is_training=args.mode == 'train', batch_size=args.batch_size, is_rotated_bbox=args.rotated_bbox).cuda()
+        if self.world_size > 1:
+            # DDP construction semantics (the reference wraps the model, run_rpn_detect.py): every rank starts from rank 0's parameters
+            # and buffers -- without this each rank would keep its own random RCNN initialisation and the averaged gradients would be
+            # applied to diverged replicas
+            sync_module_from_rank0(self.model)
         self.init_datasets()
 
     def init_datasets(self):
@@ -224,10 +265,7 @@ class Trainer:
             loss = losses['loss_objectness'] if a.obj_only else losses['loss_objectness'] + losses['loss_rpn_box_reg']
             loss.backward()
             if self.world_size > 1:       # one process per GPU over RCCL: mean of the gradients (the reference wraps the model in DDP)
-                for p in self.model.parameters():
-                    if p.grad is not None:
-                        dist.all_reduce(p.grad)
-                        p.grad /= self.world_size
+                allreduce_mean_gradients(self.model.parameters(), self.world_size)
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), a.clip_grad_norm)
             self.optimizer.step()
             self.scheduler.step()

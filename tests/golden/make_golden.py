@@ -503,6 +503,128 @@ def gen_fullsize():
         save(name, **arrs)
 
 
+def gen_stages():
+    """Integer stages of the eval path on the reference's REAL candidate distribution at BASELINE configs[1] size (160^3, VGG19-EF, OBB,
+    --normalize_density; the scene of eval_obb_160_cfg1).  Hooks the reference (rpn.py:292-370, utils.py:215-265) and records: raw logits
+    of all 950 625 anchors, the per-level top-k indices, the deltas / decoded boxes of those candidates, the candidates that reach NMS
+    (after clip / small-box / score filters, quirk B3 included), batched_nms' keep indices and the final proposals."""
+    print("stage-level eval at 160^3")
+    import datasets as R_ds
+    shape = (160, 160, 160)
+    ref = build_ref(True, 160).eval()
+    raw = raw_scene_wlh4(shape, 300).numpy().copy()
+    raw[..., 3] = R_ds.BaseDataset.density_to_alpha(raw[..., 3])
+    x = torch.from_numpy(np.ascontiguousarray(np.transpose(raw, (3, 0, 1, 2)))).float()
+    rec = {}
+    o_concat, o_topn, o_nms = R_rpn.concat_box_prediction_layers, R_rpn.RegionProposalNetwork._get_top_n_idx, R_rpn.batched_nms
+
+    def concat(box_cls, box_reg, nd):
+        out = o_concat(box_cls, box_reg, nd)
+        rec["logits"], rec["deltas"] = out[0].detach().reshape(-1).clone(), out[1].detach().clone()
+        return out
+
+    def topn(self, objectness, num_anchors_per_level):
+        r = o_topn(self, objectness, num_anchors_per_level)
+        rec["topk_idx"], rec["per_level"] = r[0].clone(), list(num_anchors_per_level)
+        return r
+
+    def nms(boxes, scores, idxs, thr):
+        keep = o_nms(boxes, scores, idxs, thr)
+        rec["nms_boxes"], rec["nms_scores"], rec["nms_levels"], rec["nms_keep"] = boxes.clone(), scores.clone(), idxs.clone(), keep.clone()
+        return keep
+    R_rpn.concat_box_prediction_layers, R_rpn.RegionProposalNetwork._get_top_n_idx, R_rpn.batched_nms = concat, topn, nms
+    o_decode = ref.rpn.box_coder.decode_list
+
+    def decode_list(deltas_list, anchors_list):
+        out = o_decode(deltas_list, anchors_list)
+        rec["decoded"] = out.detach().clone()
+        return out
+    ref.rpn.box_coder.decode_list = decode_list
+    try:
+        with torch.no_grad():
+            (feats, props, lvls), _, scores = ref([x.clone()])
+    finally:
+        R_rpn.concat_box_prediction_layers, R_rpn.RegionProposalNetwork._get_top_n_idx, R_rpn.batched_nms = o_concat, o_topn, o_nms
+    idx = rec["topk_idx"]
+    logits = rec["logits"]
+    # tie report: equal logits inside a level's selected set / at its selection boundary make the index order implementation-defined (B7)
+    ties, off, k0 = [], 0, 0
+    for n in rec["per_level"]:
+        k = min(2500, n)
+        lv = logits[off:off + n]
+        sel = lv[idx[k0:k0 + k] - off]
+        srt = torch.sort(lv, descending=True).values
+        ties.append([int((sel[1:] == sel[:-1]).sum()), int(k < n and srt[k - 1] == srt[k])])
+        off += n; k0 += k
+    dec = rec["decoded"][0]                       # [T, 8]: 7 box digits + level index
+    # worst-case margin of the NMS decisions: |IoU - thr| over pairs of one level (kept row vs every lower-scored row)
+    nb, nl = rec["nms_boxes"], rec["nms_levels"]
+    margin = 1.0
+    for l in torch.unique(nl):
+        b = nb[nl == l]
+        for i in range(0, b.shape[0], 256):
+            iou = OB.iou_matrix(b[i:i + 256], b)
+            margin = min(margin, float((iou - 0.3).abs().min()))
+    print(f"   candidates {idx.numel()}, reach NMS {nb.shape[0]}, kept {rec['nms_keep'].numel()}, final {props[0].shape[0]}; ties {ties}; "
+          f"min |IoU - 0.3| over same-level pairs {margin:.3e}")
+    save("stages_obb_160_cfg1", shape=list(shape), seed=300, logits=logits, per_level=rec["per_level"], topk_idx=idx, ties=ties,
+         topk_deltas=rec["deltas"][idx], topk_boxes=dec[idx, :7], nms_boxes=nb, nms_scores=rec["nms_scores"], nms_levels=nl,
+         nms_keep=rec["nms_keep"], nms_margin=margin, proposals0=props[0], scores0=scores[0], levels0=lvls[0])
+
+
+def gen_fullsize2():
+    """Full-size goldens for the other two backbones (configs 2-4 use non-cubic grids 200x200x130 and 160x120x64):
+    ResNet-50-3D + RPN, Swin-S-3D + RPN and Swin-S + FCOS, generated by running the reference here.  Inputs are regenerated from the
+    seed by the tests; the fixtures hold sampled features and all proposals / scores."""
+    print("full-size eval, ResNet-50 / Swin-S")
+    only = os.environ.get("GOLDEN_ONLY")
+    cases = [("eval_resnet_obb_200x200x130", (200, 200, 130), True, {"backbone": "resnet"}),
+             ("eval_resnet_aabb_160x120x64", (160, 120, 64), False, {"backbone": "resnet"}),
+             ("eval_swin_obb_160x120x64", (160, 120, 64), True, {"backbone": "swin"}),
+             ("eval_swin_obb_200x200x130", (200, 200, 130), True, {"backbone": "swin"})]
+    for name, shape, rot, kw in cases:
+        if only and only not in name:
+            continue
+        ref = build_ref(rot, 160, **kw).eval()
+        orc = build_oracle(rot, 160, **kw)
+        orc.backbone.eval()
+        x = scene(shape, 310)
+        with torch.no_grad():
+            (feats, props, lvls), _, scores = ref([x.clone()])
+            (ofeats, oprops, olvls), _, oscores, aux = orc([x.clone()])
+        arrs = {"shape": list(shape), "seed": 310, "rotated": rot, "resolution": 160, "pre": 2500, "backbone": kw["backbone"]}
+        for i, (f, of) in enumerate(zip(feats, ofeats)):
+            close(of, f, 5e-4, f"{name} feat{i}")
+            idx, val = subsample(f, 16384)
+            arrs[f"feat{i}_shape"], arrs[f"feat{i}_idx"], arrs[f"feat{i}_val"], arrs[f"feat{i}_absmax"] = list(f.shape), idx, val, f.abs().max()
+        assert props[0].shape == oprops[0].shape, (name, props[0].shape, oprops[0].shape)
+        close(oprops[0], props[0], 2e-3, f"{name} proposals"); close(oscores[0], scores[0], 1e-5, f"{name} scores")
+        arrs["proposals0"], arrs["scores0"], arrs["levels0"] = props[0], scores[0], lvls[0]
+        print(f"   {name}: {props[0].shape[0]} proposals, score range {scores[0].min():.4f}..{scores[0].max():.4f}")
+        save(name, **arrs)
+    fc = [("fcos_eval_obb_swin_200x200x130", (200, 200, 130), True, "swin"), ("fcos_eval_obb_swin_160x120x64", (160, 120, 64), True, "swin")]
+    for name, shape, rot, bbk in fc:
+        if only and only not in name:
+            continue
+        ref, orc = build_fcos(rot, bbk)
+        ref.eval(); orc.backbone.eval()
+        x = scene(shape, 320)
+        with torch.no_grad():
+            boxes, _, scores = ref([x.clone()])
+            oboxes, _, oscores, aux = orc([x.clone()])
+        arrs = {"shape": list(shape), "seed": 320, "shapes": [list(shape)], "rotated": rot, "backbone": bbk, "pre_nms_top_n": 2500,
+                "fpn_post_nms_top_n": 2500, "pre_nms_thresh": 0.0, "min_size": 0.0}
+        for key in ("box_cls", "box_reg", "centerness"):
+            for l, t in enumerate(aux[key]):
+                idx, val = subsample(t, 4096)
+                arrs[f"{key}{l}_idx"], arrs[f"{key}{l}_val"], arrs[f"{key}{l}_absmax"] = idx, val, t.abs().max()
+        assert boxes[0].shape == oboxes[0].shape, (name, boxes[0].shape, oboxes[0].shape)
+        close(oboxes[0], boxes[0], 2e-3, f"{name} boxes"); close(oscores[0], scores[0], 1e-5, f"{name} scores")
+        arrs["boxes0"], arrs["scores0"] = boxes[0], scores[0]
+        print(f"   {name}: {boxes[0].shape[0]} boxes, score range {scores[0].min():.4f}..{scores[0].max():.4f}")
+        save(name, **arrs)
+
+
 def gen_train():
     print("end-to-end train")
     cases = [("train_swin_obb", True, "smooth_l1", [(80, 56, 48)]),      # stochastic depth 0 (the draw is RNG-stream specific)

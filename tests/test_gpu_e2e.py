@@ -195,6 +195,30 @@ def test_block_backward_on_identical_inputs(dev):
         assert rel(a.grad, b.grad) < 1e-3, k
 
 
+def test_head_without_private_convs_hands_back_the_full_input_gradient(dev):
+    """conv_depth == 0 (``--rpn_head_conv_depth 0``, and the default-head path that puts ``rotated_bbox`` into the conv_depth slot,
+    reference nerf_rpn.py:104): the fused cls/bbox GEMM reads the raw FPN feature, so its input gradient must NOT be ReLU-masked
+    (the chain flag was set unconditionally and zeroed dx wherever the feature was <= 0)."""
+    import torch.nn.functional as F
+    from nerf_rpn_amd.model import RPNHead
+    hd = RPNHead(64, 13, 0, rotate=True)
+    seeded_state(hd, 2)
+    hd = hd.to(dev)
+    f = torch.randn(1, 64, 5, 4, 6, generator=torch.Generator().manual_seed(0))         # about half the entries are negative
+    fm, fo = f.clone().to(dev).requires_grad_(True), f.clone().requires_grad_(True)
+    lm, bm = hd([fm])
+    lo = F.conv3d(fo, hd.cls_logits.weight.detach().cpu(), hd.cls_logits.bias.detach().cpu())
+    bo = F.conv3d(fo, hd.bbox_pred.weight.detach().cpu(), hd.bbox_pred.bias.detach().cpu())
+    gl = torch.randn(lo.shape, generator=torch.Generator().manual_seed(1))
+    gb = torch.randn(bo.shape, generator=torch.Generator().manual_seed(2))
+    ((lo * gl).sum() + (bo * gb).sum()).backward()
+    ((lm[0] * gl.to(dev)).sum() + (bm[0] * gb.to(dev)).sum()).backward()
+    assert (fo.grad[f <= 0].abs() > 0).any()
+    err = ((fm.grad.cpu() - fo.grad).abs().max() / fo.grad.abs().max()).item()
+    assert err < 2e-5, err
+    assert ((lm[0].detach().cpu() - lo.detach()).abs().max() / lo.detach().abs().max()).item() < 2e-5
+
+
 def test_proposal_npz_contract(tmp_path, dev):
     """The .npz a trainer writes (reference run_rpn.py:453) has keys 'proposal' [K,6|7] f32 and 'score' [K] f32."""
     m = build(True, 64, dev, pre=300).eval()
