@@ -214,6 +214,35 @@ size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, i
 int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
                     int cout, int wrows, int ksize, int dtype, int flags, void *workspace, const void *relu_mask,
                     nrpn_stream_t stream);
+/* Per-call plan + fused-epilogue extras of a forward / dgrad launch.  Zero-initialise, set `size`, then the fields you need; a NULL
+ * opts pointer (or all defaults) is exactly nrpn_conv3d_fwd.  Every kernel-selection decision of a call is a pure function of
+ * (shape, opts, process defaults): concurrent calls with different plans share no mutable state.
+ *   scale      f32 [Cout]: y = acc * scale + bias -- eval-mode BatchNorm3d folded into the conv that feeds it (feature_extractor.py:345-358:
+ *              scale = gamma / sqrt(running_var + eps), bias = (conv bias - running_mean) * scale + beta), with NRPN_CONV_RELU on top
+ *   relu_mask  as in nrpn_conv3d_fwd;  stats: as in nrpn_conv3d_fwd_stats (rows: nrpn_conv3d_fwd_stats_rows_ex with the same opts)
+ *   tile       NRPN_TILE_*: 0 = chosen per shape; lds_dma / stagger / big_split: -1 = default, 0 / 1; kstep_bytes: 0 = default, 64, 128
+ *   debug      tools only: NRPN_CONV_DEBUG_* bits (timing variants, wrong results) */
+enum { NRPN_TILE_AUTO = 0, NRPN_TILE_128 = 128, NRPN_TILE_256X128_WS = 256, NRPN_TILE_256X256 = 512, NRPN_TILE_256X256_W4 = 1024 };
+typedef struct nrpn_conv_opts {
+  int32_t size;
+  int32_t tile;
+  int32_t lds_dma;
+  int32_t kstep_bytes;
+  int32_t stagger;
+  int32_t big_split;
+  int32_t debug;
+  int32_t reserved;
+  const float *scale;
+  const void *relu_mask;
+  float *stats;
+} nrpn_conv_opts;
+int nrpn_conv3d_fwd_ex(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
+                       int cout, int wrows, int ksize, int dtype, int flags, void *workspace, const nrpn_conv_opts *opts,
+                       nrpn_stream_t stream);
+size_t nrpn_conv3d_fwd_workspace_bytes_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype,
+                                          const nrpn_conv_opts *opts);
+int nrpn_conv3d_fwd_plan_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype, const nrpn_conv_opts *opts);
+int nrpn_conv3d_fwd_stats_rows_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype, const nrpn_conv_opts *opts);
 /* wgrad: the voxel axis is cut into S = nrpn_conv3d_wgrad_slices(...) slices; every (tile, tap, slice) workgroup writes
  * its partial with plain stores into gw_packed f32 [S][taps][wrows][Cin] (fully overwritten: no memset, no atomics --
  * cross-XCD fp32 atomics were ~1/3 of the kernel time); nrpn_unpack_conv_wgrad sums the slices.
@@ -239,8 +268,9 @@ int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, voi
 int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, float *gbias, int nseg, const int32_t *dims,
                              int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
                              nrpn_stream_t stream);
-/* kernel selection of a forward / dgrad launch: 0 = 128-row tile, 1 = 256x256 tile, 2 = 256x256 tile on K slices, 3 = 128-row tile on
- * K slices, 4 = wave-specialised 256x128;  of a wgrad launch: 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */
+/* kernel selection of a forward / dgrad launch: 0 = 128-row tile, 1 = 256x256 tile (8 waves), 2 = 256x256 tile on K slices, 3 = 128-row
+ * tile on K slices, 4 = wave-specialised 256x128, 5 = 256x256 tile on 4 waves, 6 = the same on K slices;  of a wgrad launch:
+ * 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */
 int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
 /* BatchNorm statistics out of the conv epilogue (the conv -> BatchNorm3d pairs of feature_extractor.py:288-377 in training mode):
  * nrpn_conv3d_fwd_stats = nrpn_conv3d_fwd that also writes per-row-group partial (sum, sum of squares) of the STORED bf16 outputs into
@@ -254,15 +284,16 @@ int nrpn_bn_stats_finalize(const float *partials, int nparts, int64_t rows, int 
                            float *running_var, float momentum, nrpn_stream_t stream);
 int nrpn_conv3d_wgrad_plan(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
 /* State: the library keeps NO per-call or per-stream state -- every buffer, workspace and stream comes from the caller.  What is process-wide:
- * (a) the nrpn_set_* switches below, developer knobs for A/B measurements whose defaults are the product configuration (set them before
- * launching, not concurrently with launches); (b) a (kernel, device) cache of granted dynamic-LDS limits (mutex-protected, idempotent);
+ * (a) the nrpn_set_* switches below: TOOLS-ONLY process defaults for A/B measurements (atomics, read once per call; the product path never
+ * calls them -- a caller that needs a non-default plan passes nrpn_conv_opts to the *_ex entry points instead); (b) a (kernel, device) cache of granted dynamic-LDS limits (mutex-protected, idempotent);
  * (c) the thread-local message behind nrpn_last_error(). */
 /* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
 int nrpn_set_conv_kstep_bytes(int kb);
 /* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */
 int nrpn_set_conv_lds_dma(int on);
 /* tuning knob: tile of the bf16 k1/k3 LDS-DMA kernel -- 0 = per shape, 128 = 128x128 (two workgroups per CU), 256 = wave-specialised
- * 256x128 (4 MFMA + 4 LDS-DMA waves), 512 = 256x256 with 8 waves (default for Cout >= 256 when it yields >= 200 workgroups) */
+ * 256x128 (4 MFMA + 4 LDS-DMA waves), 512 = 256x256 with 8 waves (default for Cout >= 256 when it yields >= 200 workgroups),
+ * 1024 = 256x256 with 4 waves (128x128 per wave) */
 int nrpn_set_conv_tile_m(int bm);
 /* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
 int nrpn_set_conv_stagger(int on);
@@ -286,6 +317,18 @@ int nrpn_unpack_stem_wgrad(const float *gw_packed, int cout, int dtype, float *g
                            int64_t slice_floats, nrpn_stream_t stream);
 int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz,
                          int cout, int stride, int dtype, int flags, nrpn_stream_t stream);
+/* "Halo" form of the stem forward for bf16, stride 2, Cout 64 and an even Z (nrpn_stem_halo_supported): a workgroup stages the input halo
+ * of a 4x4x16 block of output voxels in LDS once and reads every MFMA A fragment from it (the im2col form above moves 2.7 kB per output
+ * voxel through the L1 -> LDS path).  Weights: nrpn_pack_stem_weight_halo -> bf16 [Cout][nrpn_stem_halo_kpad()].  Epilogue:
+ * acc * scale + bias (scale optional: eval-mode BatchNorm fold), ReLU with NRPN_CONV_RELU. */
+int nrpn_stem_halo_supported(int gz, int cout, int stride, int dtype);
+int nrpn_stem_halo_kpad(void);
+int nrpn_pack_stem_weight_halo(const float *w_ref, int cout, void *wp, nrpn_stream_t stream);
+int nrpn_conv3d_stem_fwd_halo(const void *x, const void *wp, const float *bias, const float *scale, void *y, int n, int gx, int gy,
+                              int gz, int cout, int flags, nrpn_stream_t stream);
+/* the same with the nrpn_conv_opts extras that apply to the stem: `scale` (eval-mode BatchNorm folded in) with NRPN_CONV_RELU on top */
+int nrpn_conv3d_stem_fwd_ex(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz,
+                            int cout, int stride, int dtype, int flags, const nrpn_conv_opts *opts, nrpn_stream_t stream);
 size_t nrpn_stem_wgrad_workspace_bytes(int n, int gx, int gy, int gz, int cout, int stride, int dtype);
 int nrpn_conv3d_stem_wgrad(const void *x, const void *dy, float *gw_packed, float *gbias, int n, int gx, int gy, int gz,
                            int cout, int stride, int dtype, int accumulate_bias, void *workspace, nrpn_stream_t stream);

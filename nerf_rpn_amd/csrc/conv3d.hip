@@ -13,6 +13,8 @@
 // Replaces torch.nn.Conv3d (MIOpen/cuDNN) in reference feature_extractor.py:331-358, fpn.py:109-110, anchor.py:190-198.
 #include "common.h"
 
+#include <atomic>
+
 typedef __attribute__((ext_vector_type(4))) float f4;
 typedef __attribute__((ext_vector_type(2))) float f2;
 typedef __attribute__((ext_vector_type(16))) float f16v;
@@ -20,7 +22,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((ext_vector_type(4))) short s4v;
 typedef unsigned short bf16s;  // raw bf16 storage
 
-static int g_conv_kb_value();
 
 template <typename T> struct Mma;
 template <> struct Mma<float> {
@@ -121,6 +122,8 @@ struct ConvArgs {
   const void *x;
   const void *w;      // MODE 0: [taps][wrows][Cin];  MODE 1 (stem): [wrows][Kpad], k = tap*4 + c
   const float *bias;
+  const float *scale; // optional f32 [Cout]: y = acc * scale + bias (eval-mode BatchNorm folded into the conv: scale = gamma / sqrt(var + eps),
+                      // bias = (conv bias - mean) * scale + beta); nullptr = 1
   const void *mask;   // optional [M][Cout] (dtype of x): outputs are zeroed where mask <= 0 (ReLU backward of the tensor this dgrad feeds)
   void *y;
   long long M;        // output voxels (N * OX * OY * OZ)
@@ -444,12 +447,13 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + fr;
       const float bv = (has_bias && col < p.Cout) ? p.bias[col] : 0.f;
+      const float sv = (p.scale && col < p.Cout) ? p.scale[col] : 1.f;
       float ssum = 0.f, qsum = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float o = acc[i][j][r] + bv;
+          float o = acc[i][j][r] * sv + bv;
           if (relu) o = fmaxf(o, 0.f);
           const bf16s ob = f32_to_bf16_bits(o);
           *reinterpret_cast<bf16s *>(stage + (i * 32 + frag_row(r, lane)) * PITCH + (j * 32 + fr) * 2) = ob;
@@ -488,13 +492,14 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     const int col = n0 + (wn * TN + j) * 32 + fr;
     if (col >= p.Cout) continue;
     const float bv = has_bias ? p.bias[col] : 0.f;
+    const float sv = p.scale ? p.scale[col] : 1.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, lane);
         if (v < p.M) {
-          float o = acc[i][j][r] + bv;
+          float o = acc[i][j][r] * sv + bv;
           if (relu) o = fmaxf(o, 0.f);
           if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
           if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
@@ -673,13 +678,14 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_ws_kernel(const ConvArgs p)
     const int col = n0 + (wn * TN + j) * 32 + efr;
     if (col >= p.Cout) continue;
     const float bv = has_bias ? p.bias[col] : 0.f;
+    const float sv = p.scale ? p.scale[col] : 1.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
         if (v < p.M) {
-          float o = acc[i][j][r] + bv;
+          float o = acc[i][j][r] * sv + bv;
           if (relu) o = fmaxf(o, 0.f);
           if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
           if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
@@ -696,7 +702,10 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_ws_kernel(const ConvArgs p)
 // 64 B/clk L1 path) and the number of LDS-DMA issues (8 pieces per 32 MFMAs per wave).  Two LDS buffers of 64 KB.
 // Used when Cout >= 256 and the 256x256 tiling still yields ~one workgroup per CU.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool OUTF32, bool STAG = false>
+// DBG (tools-only instantiations, selected by NRPN_CONV_DEBUG_* in the flag word; the production instantiation is DBG = 0 and carries
+// none of these branches): bit 0 = every tap reads the centre voxel ("ideal memory"), bit 1 = no per-K-step barrier / DMA drain.
+// RESULTS ARE WRONG with DBG != 0 (timing diagnosis, tools/diag_big_conv.py).
+template <bool OUTF32, bool STAG = false, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p) {
   typedef bf16s T;
   constexpr int BM = 256, BN = 256, KB = 128, KE = 64, PPR = 8, RSTEP = 64, TM = 4, TN = 2;
@@ -758,7 +767,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   int l_chunk = ks_begin / p.taps, l_tap = ks_begin - l_chunk * p.taps, l_dx = 0, l_dy = 0, l_dz = 0;
   if (p.taps == 27) { l_dx = l_tap / 9 - 1; l_dy = (l_tap / 3) % 3 - 1; l_dz = l_tap % 3 - 1; }
   const long long w_tap_stride = (long long)p.wrows * p.Cin;
-  const bool dbg_alias = (p.flags & NRPN_CONV_DEBUG_ALIAS_TAPS) != 0, dbg_nosync = (p.flags & NRPN_CONV_DEBUG_NO_SYNC) != 0;
+  constexpr bool dbg_alias = (DBG & 1) != 0, dbg_nosync = (DBG & 2) != 0;
   // branch-free: past the last K-step (`live` false) every lane reads out of range, i.e. deposits zeros in the idle buffer
   auto issue = [&](int buf, bool live) {
     char *A = lds + buf * (A_BYTES + B_BYTES);
@@ -767,7 +776,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     const int zshift = (l_dz * p.Cin + c0) * 2;
     const unsigned wshift = (unsigned)(((long long)l_tap * w_tap_stride + c0) * 2);
     const unsigned tapbit = live ? (1u << l_tap) : 0u;
-    if (dbg_alias) {      // timing diagnosis only: every tap reads the centre voxel (27x reuse of one activation tile: "ideal memory")
+    if constexpr (dbg_alias) {      // timing diagnosis only: every tap reads the centre voxel (27x reuse of one activation tile: "ideal memory")
 #pragma unroll
       for (int i = 0; i < A_RPT; ++i) lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * i) * KB, live ? a_voff[i] + (unsigned)(c0 * 2) : kOOB);
     } else {
@@ -876,7 +885,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
         if (sub < 3) {
           load_frags(A, B, sub + 1, af[(sub + 1) & 1], bfv[(sub + 1) & 1]);
         } else {
-          if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
+          if constexpr (!dbg_nosync) __syncthreads();
           load_frags(An, An + A_BYTES, 0, af[0], bfv[0]);
         }
         if (sub < 2 && (sub == 1) == late_issue) issue(buf ^ 1, next_live);
@@ -896,7 +905,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
 #pragma unroll 1
     for (int ks = ks_begin; ks < nk; ++ks) {
       compute((ks - ks_begin) & 1, ks + 1 < nk);
-      if (!dbg_nosync) __syncthreads();      // dbg_nosync: timing diagnosis only (results are garbage)
+      if constexpr (!dbg_nosync) __syncthreads();
     }
   }
 
@@ -938,12 +947,13 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + efr;
         const float bv = (has_bias && col < p.Cout) ? p.bias[col] : 0.f;
+        const float sv = (p.scale && col < p.Cout) ? p.scale[col] : 1.f;
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           const int i = half * 2 + ii;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float o = acc[i][j][r] + bv;
+            float o = acc[i][j][r] * sv + bv;
             if (relu) o = fmaxf(o, 0.f);
             const bf16s ob = f32_to_bf16_bits(o);
             *reinterpret_cast<bf16s *>(stage + (ii * 32 + frag_row(r, elane)) * PITCH + (j * 32 + efr) * 2) = ob;
@@ -990,13 +1000,286 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     const int col = n0 + (wn * TN + j) * 32 + efr;
     if (col >= p.Cout) continue;
     const float bv = has_bias ? p.bias[col] : 0.f;
+    const float sv = p.scale ? p.scale[col] : 1.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
         if (v < p.M) {
-          float o = acc[i][j][r] + bv;
+          float o = acc[i][j][r] * sv + bv;
+          if (relu) o = fmaxf(o, 0.f);
+          if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
+          if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
+          else elem<T>::st(reinterpret_cast<T *>(p.y) + v * p.Cout + col, o);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 tile on FOUR waves (2 x 2, each 128x128 = 16 accumulators = 256 accumulator registers; one wave per SIMD, 512 registers).
+// Per MFMA this is 0.5 ds_read_b128 instead of the 0.75 of the 8-wave kernel (a third less LDS read traffic and energy -- the part is
+// power-limited on real data) at the same global -> LDS traffic; the price is that nothing hides an issue stall of the single wave
+// of a SIMD, so the 16 LDS-DMA pieces per wave per K-step are spread one behind every other MFMA pair of sub-steps 0..2 and the
+// ds_reads of sub-step s+1 sit one behind every second MFMA of sub-step s.  Same rotated K-step (barrier before the MFMAs of the
+// last sub-step) and the same per-accumulator MFMA order as conv_igemm_big_kernel: results are bit-identical to it.
+// Classic layout only (no ragged voxel lists).  Selected per call (nrpn_conv_opts.tile = NRPN_TILE_256X256_W4) or by the plan.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool OUTF32>
+__global__ void __launch_bounds__(256, 1) conv_igemm_big4_kernel(const ConvArgs p) {
+  typedef bf16s T;
+  constexpr int BM = 256, BN = 256, KB = 128, KE = 64, PPR = 8, RSTEP = 32, TM = 4, TN = 4;
+  constexpr int A_RPT = BM / RSTEP, B_RPT = BN / RSTEP;    // 8 + 8 DMA pieces per lane per K-step
+  constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned ntiles = (p.Cout + BN - 1) / BN;
+  const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * ntiles;
+  const unsigned zsplit = blockIdx.x / tiles;                      // K slice (0 unless ksplit > 1)
+  const unsigned tile = xcd_remap(blockIdx.x - zsplit * tiles, tiles);
+  const long long m0 = (long long)(tile / ntiles) * BM;
+  const int n0 = (int)(tile % ntiles) * BN;
+  const int cpt = p.Cin / KE;
+  int ks_begin = 0, nk = p.taps * cpt;
+  if (p.ksplit > 1) {
+    const int per = (nk + p.ksplit - 1) / p.ksplit;
+    ks_begin = zsplit * per;
+    nk = min(nk, ks_begin + per);
+  }
+
+  const int lr = tid / PPR, ls = tid % PPR;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+  unsigned a_voff[A_RPT], a_mask[A_RPT], b_voff[B_RPT];
+  const int yz_b = p.Y * p.Z * p.Cin * 2, zs_b = p.Z * p.Cin * 2;      // byte strides of one x / one y step
+#pragma unroll
+  for (int i = 0; i < A_RPT; ++i) {
+    const int r = lr + RSTEP * i;
+    const long long v = m0 + r;
+    const bool ok = v < p.M;
+    const long long vv = ok ? v : 0;
+    const int oz = (int)(vv % p.Z);
+    const long long t1 = vv / p.Z;
+    const int oy = (int)(t1 % p.Y);
+    const int ox = (int)((t1 / p.Y) % p.X);
+    unsigned m = 0;
+    if (ok) {
+      if (p.taps == 27) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
+          const bool in = (unsigned)(ox + dx) < (unsigned)p.X && (unsigned)(oy + dy) < (unsigned)p.Y && (unsigned)(oz + dz) < (unsigned)p.Z;
+          m |= in ? (1u << t) : 0u;
+        }
+      } else {
+        m = 1u;
+      }
+    }
+    a_mask[i] = ~m | (1u << 27);      // INVERTED: bit t set = tap t reads zeros for this row; bit 27 = "past the last K-step"
+    a_voff[i] = (unsigned)(vv * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < B_RPT; ++i) {
+    const int r = lr + RSTEP * i, row = n0 + r;
+    b_voff[i] = row < p.wrows ? (unsigned)((long long)row * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4) : kOOB;
+  }
+  // K order as in conv_igemm_big_kernel: 64-channel chunk OUTER, tap INNER (one channel slice of the XCD's voxel slab stays in L2)
+  int l_chunk = ks_begin / p.taps, l_tap = ks_begin - l_chunk * p.taps, l_dx = 0, l_dy = 0, l_dz = 0;
+  if (p.taps == 27) { l_dx = l_tap / 9 - 1; l_dy = (l_tap / 3) % 3 - 1; l_dz = l_tap % 3 - 1; }
+  const long long w_tap_stride = (long long)p.wrows * p.Cin;
+  // one DMA piece of the K-step described by (l_tap, l_chunk, l_d*): pieces 0..7 = A rows, 8..15 = B rows.  Branch-free and three
+  // VALU per A piece: bit = bfe(inverted mask, tap), offset = (row offset + tap shift) | bit << 31 -- an offset >= 2^31 is beyond
+  // every descriptor (tensors stay below 2 GiB), so the lane deposits zeros; `live` false selects bit 27 (always set).
+  const bool is27 = p.taps == 27;
+  auto piece = [&](int buf, bool live, int idx) {
+    char *A = lds + buf * (A_BYTES + B_BYTES);
+    char *B = A + A_BYTES;
+    const int c0 = l_chunk * KE;
+    if (idx < A_RPT) {
+      const unsigned sel = live ? (unsigned)l_tap : 27u;
+      const unsigned shift = (unsigned)(l_dx * yz_b + l_dy * zs_b + (l_dz * p.Cin + c0) * 2);
+      const unsigned bit = __builtin_amdgcn_ubfe(a_mask[idx], sel, 1u);
+      lds_dma16(xr, A + (wave_u * (64 / PPR) + RSTEP * idx) * KB, (bit << 31) | (a_voff[idx] + shift));
+    } else {
+      const unsigned wshift = live ? (unsigned)(((long long)l_tap * w_tap_stride + c0) * 2) : kOOB;
+      lds_dma16(wr, B + (wave_u * (64 / PPR) + RSTEP * (idx - A_RPT)) * KB, b_voff[idx - A_RPT] + wshift);
+    }
+  };
+  auto advance = [&]() {      // scalar selects only: the K-step body must stay ONE basic block for the instruction interleave below
+    const int nt = l_tap + 1;
+    const bool wrap = nt == p.taps;
+    l_tap = wrap ? 0 : nt;
+    l_chunk += wrap ? 1 : 0;
+    const int nz = l_dz + 1;
+    const bool cz = nz > 1;
+    const int ny = l_dy + (cz ? 1 : 0);
+    const bool cy = ny > 1;
+    const int nx = l_dx + (cy ? 1 : 0);
+    l_dz = !is27 ? 0 : (wrap ? -1 : (cz ? -1 : nz));
+    l_dy = !is27 ? 0 : (wrap ? -1 : (cy ? -1 : ny));
+    l_dx = !is27 ? 0 : (wrap ? -1 : nx);
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fk = lane >> 5;
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int a_row[TM], b_row[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_row[i] = (wm * TM + i) * 32 + fr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_row[j] = (wn * TN + j) * 32 + fr;
+  auto load_frags = [&](const char *A, const char *B, int s, f4 (&af)[TM], f4 (&bfv)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfv[j] = *reinterpret_cast<const f4 *>(B + b_row[j] * KB + (((s * 2 + fk) ^ ((b_row[j] >> 1) & (PPR - 1))) << 4));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f4 *>(A + a_row[i] * KB + (((s * 2 + fk) ^ ((a_row[i] >> 1) & (PPR - 1))) << 4));
+  };
+
+#pragma unroll
+  for (int q = 0; q < A_RPT + B_RPT; ++q) piece(0, ks_begin < nk, q);
+  advance();
+  __syncthreads();
+  f4 af[2][TM], bfv[2][TN];
+  load_frags(lds, lds + A_BYTES, 0, af[0], bfv[0]);
+  constexpr int kPieces[4] = {8, 8, 0, 0};      // DMA pieces issued in sub-steps 0..3: a whole sub-step (512 MFMA cycles) to land before the barrier
+#pragma unroll 1
+  for (int ks = ks_begin; ks < nk; ++ks) {
+    const int buf = (ks - ks_begin) & 1;
+    const char *A = lds + buf * (A_BYTES + B_BYTES);
+    const char *B = A + A_BYTES;
+    const char *An = lds + (buf ^ 1) * (A_BYTES + B_BYTES);
+    const bool next_live = ks + 1 < nk;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (sub < 3) {
+        load_frags(A, B, sub + 1, af[(sub + 1) & 1], bfv[(sub + 1) & 1]);
+      } else {
+        __syncthreads();
+        load_frags(An, An + A_BYTES, 0, af[0], bfv[0]);
+      }
+      constexpr int kFirst[4] = {0, 8, 16, 16};
+#pragma unroll
+      for (int q = 0; q < kPieces[sub]; ++q) piece(buf ^ 1, next_live, kFirst[sub] + q);
+      if (sub == 1) advance();
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[sub & 1][i], bfv[sub & 1][j]);
+      // pin the interleave: per pair of MFMAs one ds_read of the next sub-step, and (while pieces remain) one LDS-DMA piece
+#pragma unroll
+      for (int q = 0; q < TM + TN; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (q < kPieces[sub]) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    }
+  }
+
+  const bool has_bias = (p.flags & NRPN_CONV_BIAS) && p.bias;
+  const bool relu = p.flags & NRPN_CONV_RELU;
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+  const int efr = elane & 31;
+  if (p.ksplit > 1) {     // fp32 partial of this K slice, plain stores; bias / ReLU / cast happen in splitk_epilogue_kernel
+    float *wsz = p.ws + (long long)zsplit * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + efr;
+      if (col >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
+          if (v < p.M) wsz[v * p.Cout + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
+  if (!OUTF32 && (p.Cout & 7) == 0) {
+    // staged bf16 epilogue (see conv_igemm_big_kernel): 32 rows x 128 columns of the wave's block at a time through LDS (272-byte row
+    // pitch: rows 4 apart land on different banks), out as whole 16-byte pieces, 16 lanes per 256-byte row segment
+    constexpr int PITCH = 272;
+    char *stage = lds + wave * (32 * PITCH);
+    const T *maskp = reinterpret_cast<const T *>(p.mask);
+    T *yp = reinterpret_cast<T *>(p.y);
+    const bool full_tile = m0 + BM <= p.M;
+    float ssum[TN], qsum[TN], bv[TN], sv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + efr;
+      ssum[j] = 0.f; qsum[j] = 0.f;
+      bv[j] = (has_bias && col < p.Cout) ? p.bias[col] : 0.f;
+      sv[j] = (p.scale && col < p.Cout) ? p.scale[col] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float o = acc[i][j][r] * sv[j] + bv[j];
+          if (relu) o = fmaxf(o, 0.f);
+          const bf16s ob = f32_to_bf16_bits(o);
+          *reinterpret_cast<bf16s *>(stage + frag_row(r, elane) * PITCH + (j * 32 + efr) * 2) = ob;
+          if (p.stats && (full_tile || m0 + (wm * TM + i) * 32 + frag_row(r, elane) < p.M)) {
+            const float of = bf16_bits_to_f32(ob);
+            ssum[j] += of;
+            qsum[j] += of * of;
+          }
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int pc = elane + 64 * q;                  // 512 pieces: 32 rows x 16 pieces of 16 bytes
+        const int row = pc >> 4, seg = pc & 15;
+        const long long v = m0 + (wm * TM + i) * 32 + row;
+        const int col = n0 + wn * 128 + seg * 8;
+        if (v < p.M && col < p.Cout) {
+          f4 val = *reinterpret_cast<const f4 *>(stage + row * PITCH + seg * 16);
+          if (maskp) {
+            typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+            const u8v mk = __builtin_bit_cast(u8v, *reinterpret_cast<const f4 *>(maskp + v * p.Cout + col));
+            u8v ov = __builtin_bit_cast(u8v, val);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (bf16_bits_to_f32(mk[e]) > 0.f) ? ov[e] : (unsigned short)0;
+            val = __builtin_bit_cast(f4, ov);
+          }
+          *reinterpret_cast<f4 *>(yp + v * p.Cout + col) = val;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this block before the next one overwrites the stage
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        store_col_stats(p.stats, (m0 / BM) * 2 + wm, p.Cout, n0 + (wn * TN + j) * 32 + efr, ssum[j], qsum[j], elane);
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + efr;
+    if (col >= p.Cout) continue;
+    const float bv = has_bias ? p.bias[col] : 0.f;
+    const float sv = p.scale ? p.scale[col] : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
+        if (v < p.M) {
+          float o = acc[i][j][r] * sv + bv;
           if (relu) o = fmaxf(o, 0.f);
           if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
           if (OUTF32) reinterpret_cast<float *>(p.y)[v * p.Cout + col] = o;
@@ -1009,10 +1292,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
 
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
-                                       int cout, int relu, int nslices, const T *__restrict__ mask) {
+                                       int cout, int relu, int nslices, const T *__restrict__ mask, const float *__restrict__ scale) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     float o = ws[i];
     for (int z = 1; z < nslices; ++z) o += ws[z * total + i];
+    if (scale) o *= scale[i % cout];
     o += bias ? bias[i % cout] : 0.f;
     if (relu) o = fmaxf(o, 0.f);
     if (mask && !(elem<T>::ld(mask + i) > 0.f)) o = 0.f;
@@ -1021,11 +1305,55 @@ __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel selection.  Every decision below is a pure function of (shape, Knobs): a call resolves its Knobs from the process-wide
+// defaults (developer switches, tools only) overridden by the caller's nrpn_conv_opts, so two threads with different plans never
+// touch shared state while launching.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Knobs {
+  int glds;        // 1: LDS-DMA loads (buffer_load ... lds), 0: register-staged loads
+  int bm;          // tile selector: 0 auto, 128, 256 (wave-specialised 256x128), 512 (256x256, 8 waves), 1024 (256x256, 4 waves)
+  int stagger;     // 256x256 8-wave kernel: rotated K-step + staggered DMA issue (default) or the plain loop
+  int big_split;   // mid-size grids run the 256x256 kernel on K slices
+  int kb;          // K-step bytes of the k1/k3 kernels (64 or 128)
+  int dbg;         // tools only: NRPN_CONV_DEBUG_* bits
+};
+static std::atomic<int> g_conv_glds{1}, g_conv_bm{0}, g_conv_stagger{1}, g_conv_big_split{1}, g_conv_kb{128};
+static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
+  Knobs k{g_conv_glds.load(std::memory_order_relaxed), g_conv_bm.load(std::memory_order_relaxed), g_conv_stagger.load(std::memory_order_relaxed),
+          g_conv_big_split.load(std::memory_order_relaxed), g_conv_kb.load(std::memory_order_relaxed),
+          flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER)};
+  if (o) {
+    if (o->tile > 0) k.bm = o->tile;
+    if (o->lds_dma >= 0) k.glds = o->lds_dma ? 1 : 0;
+    if (o->kstep_bytes == 64 || o->kstep_bytes == 128) k.kb = o->kstep_bytes;
+    if (o->stagger >= 0) k.stagger = o->stagger ? 1 : 0;
+    if (o->big_split >= 0) k.big_split = o->big_split ? 1 : 0;
+    k.dbg |= o->debug & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER);
+  }
+  return k;
+}
+extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
+extern "C" int nrpn_set_conv_stagger(int on) { g_conv_stagger = on ? 1 : 0; return NRPN_OK; }
+extern "C" int nrpn_set_conv_big_split(int on) { g_conv_big_split = on ? 1 : 0; return NRPN_OK; }
+extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
+  if (kb != 64 && kb != 128) return nrpn_fail(NRPN_ERR_ARG, "conv k-step must be 64 or 128 bytes");
+  g_conv_kb = kb;
+  return NRPN_OK;
+}
+extern "C" int nrpn_set_conv_tile_m(int bm) {
+  if (bm != 0 && bm != 128 && bm != 256 && bm != 512 && bm != 1024)
+    return nrpn_fail(NRPN_ERR_ARG, "conv tile selector must be 0 (auto), 128 (128x128), 256 (wave-specialised 256x128), 512 (256x256, 8 waves) or "
+                                   "1024 (256x256, 4 waves)");
+  g_conv_bm = bm;
+  return NRPN_OK;
+}
+
 // split the K loop when the (M, N) tiling alone cannot fill 256 CUs (the 10^3 / 5^3 pyramid levels)
-static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes) {
+static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes, const Knobs &kn) {
   const int bn = cout <= 64 ? 64 : 128;
   const long long tiles = cdiv64(M, 128) * ((cout + bn - 1) / bn);
-  const int kb = (g_conv_kb_value() == 128 && (cin * elem_bytes) % 128 == 0) ? 128 : 64;
+  const int kb = (kn.kb == 128 && (cin * elem_bytes) % 128 == 0) ? 128 : 64;
   const int nk = taps * (cin * elem_bytes / kb);
   if (tiles >= 128 || nk < 16) return 1;
   long long s = (384 + tiles - 1) / tiles;
@@ -1037,19 +1365,11 @@ static int conv_ksplit(long long M, int cout, int cin, int taps, int elem_bytes)
   return s < 2 ? 1 : (int)s;
 }
 
-static int g_conv_glds = 1;   // 1: LDS-DMA loads (buffer_load ... lds), 0: register-staged loads
-extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
-static int g_conv_bm = 0;     // 0: choose per shape; 128 / 256 / 512: force the tile (tuning knob, tools/bench_tile.py)
-
 // Mid-size grids (20^3: M = 8000) give only 32-64 tiles of 256x256: run the big kernel on K slices whose fp32 partials are
 // written with plain stores to ws[z][M][Cout] and summed by the epilogue (no atomics).  Returns the slice count, 0 = not used.
-static int g_conv_stagger = 1;     // 1 (default): 256x256 kernel with the DMA issue of waves 4-7 two sub-steps after waves 0-3 (measured +3..9 %)
-extern "C" int nrpn_set_conv_stagger(int on) { g_conv_stagger = on ? 1 : 0; return NRPN_OK; }
-static int g_conv_big_split = 1;   // tuning knob: 0 = mid-size grids never use the K-sliced 256x256 kernel
-extern "C" int nrpn_set_conv_big_split(int on) { g_conv_big_split = on ? 1 : 0; return NRPN_OK; }
-static int conv_big_split(long long M, int cout, int cin, int taps, int elem_bytes) {
-  if (!g_conv_big_split) return 0;
-  if (elem_bytes != 2 || !g_conv_glds || g_conv_kb_value() != 128 || (g_conv_bm != 0 && g_conv_bm != 512) || cout < 256 || (cin * 2) % 128 != 0) return 0;
+static int conv_big_split(long long M, int cout, int cin, int taps, int elem_bytes, const Knobs &kn) {
+  if (!kn.big_split) return 0;
+  if (elem_bytes != 2 || !kn.glds || kn.kb != 128 || (kn.bm != 0 && kn.bm != 512 && kn.bm != 1024) || cout < 256 || (cin * 2) % 128 != 0) return 0;
   const long long tiles = cdiv64(M, 256) * ((cout + 255) / 256);
   // measured inside the bench (20^3 maps): 512->512 (64 tiles, 4 slices) 123 us here vs 204 us on the 128-row kernel, but 256->256
   // (32 tiles, 8 slices of 13 K-steps) 56 us here vs 49 us there -- below ~48 tiles the slices get too short to amortise the 256 KB
@@ -1061,20 +1381,6 @@ static int conv_big_split(long long M, int cout, int cin, int taps, int elem_byt
   while (s > 1 && nk / s < 8) --s;
   return s >= 2 ? s : 0;
 }
-static int g_conv_kb = 128;   // K-step bytes of the k1/k3 kernels (64 or 128); tuning knob, see tools/bench_conv.py
-static int g_conv_kb_value() { return g_conv_kb; }
-extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
-  if (kb != 64 && kb != 128) return nrpn_fail(NRPN_ERR_ARG, "conv k-step must be 64 or 128 bytes");
-  g_conv_kb = kb;
-  return NRPN_OK;
-}
-
-extern "C" int nrpn_set_conv_tile_m(int bm) {
-  if (bm != 0 && bm != 128 && bm != 256 && bm != 512)
-    return nrpn_fail(NRPN_ERR_ARG, "conv tile selector must be 0 (auto), 128 (128x128), 256 (wave-specialised 256x128) or 512 (256x256)");
-  g_conv_bm = bm;
-  return NRPN_OK;
-}
 
 template <typename K>
 static int launch_igemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const ConvArgs &a) {
@@ -1083,18 +1389,25 @@ static int launch_igemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const C
   return NRPN_OK;
 }
 
+// the tile family a (shape, Knobs) pair selects: 0 = 128-row, 1 = 256x256 8-wave, 4 = wave-specialised 256x128, 5 = 256x256 4-wave
+static int conv_tile_kind(long long M, int cout, int cin, int elem_bytes, bool sliced_big, bool ragged, const Knobs &kn) {
+  const bool wide = kn.kb == 128 && (cin * elem_bytes) % 128 == 0;
+  const bool can = kn.glds && wide && cout > 64 && elem_bytes == 2;
+  const long long tiles_big = cdiv64(M, 256) * ((cout + 255) / 256);
+  const bool huge = can && cout >= 256 && (sliced_big || kn.bm == 512 || kn.bm == 1024 || (kn.bm == 0 && tiles_big >= 200));
+  if (huge) return (kn.bm == 1024 && !ragged) ? 5 : 1;
+  if (can && kn.bm == 256 && !ragged) return 4;
+  return 0;
+}
+
 template <typename T, int MODE>
-static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
+static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st, const Knobs &kn) {
   const int bn = (a.Cout <= 64) ? 64 : 128;
   constexpr bool kDma = (MODE == 0);
   // the 128-byte K-step needs Cin*elemsize % 128 == 0; the stem gather keeps the 64-byte step
-  const bool wide = MODE == 0 && g_conv_kb == 128 && (a.Cin * (int)sizeof(T)) % 128 == 0;
-  // 256-row M tiles (each wave owns 128x64: fewer LDS reads and DMA pieces per MFMA) when they still fill the chip
-  const long long tiles256 = cdiv64(a.M, 256) * ((a.Cout + bn - 1) / bn);
-  const bool can = kDma && g_conv_glds && wide && bn == 128 && (a.ksplit <= 1 || a.slices) && sizeof(T) == 2;
-  const long long tiles_big = cdiv64(a.M, 256) * ((a.Cout + 255) / 256);
-  const bool huge = can && a.Cout >= 256 && (a.slices || g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200));
-  const bool big = can && !huge && g_conv_bm == 256 && a.segs.n == 0;      // wave-specialised 256x128: on par with 128x128 (measured), opt-in only
+  const bool wide = MODE == 0 && kn.kb == 128 && (a.Cin * (int)sizeof(T)) % 128 == 0;
+  const int kind = (kDma && (a.ksplit <= 1 || a.slices)) ? conv_tile_kind(a.M, a.Cout, a.Cin, (int)sizeof(T), a.slices != 0, a.segs.n > 0, kn) : 0;
+  const bool huge = kind == 1 || kind == 5, big = kind == 4;
   const int bm = (big || huge) ? 256 : 128;
   if (a.stats) {      // fused BatchNorm statistics exist in the staged bf16 epilogues of the 128-row and 256x256 kernels only
     const bool staged = MODE == 0 && sizeof(T) == 2 && !out_f32 && (a.Cout & 7) == 0 && a.ksplit <= 1 && !big && (huge || wide);
@@ -1105,22 +1418,40 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
 #define NRPN_LC(BN_, OF_, KB_)                                                                                                    \
   do {                                                                                                                           \
     const size_t lds_ = 2 * (size_t)(128 + BN_) * KB_;                                                                           \
-    if (kDma && g_conv_glds) rc = launch_igemm(conv_igemm_kernel<T, BN_, MODE, OF_, KB_, kDma>, grid, lds_, st, a);              \
+    if (kDma && kn.glds) rc = launch_igemm(conv_igemm_kernel<T, BN_, MODE, OF_, KB_, kDma>, grid, lds_, st, a);                  \
     else rc = launch_igemm(conv_igemm_kernel<T, BN_, MODE, OF_, KB_, false>, grid, lds_, st, a);                                 \
   } while (0)
 #define NRPN_LC2(BN_, OF_) do { if (wide) NRPN_LC(BN_, OF_, 128); else NRPN_LC(BN_, OF_, 64); } while (0)
-  if (huge) {
+#define NRPN_LBIG(...)                                                                       \
+  do {                                                                                       \
+    NRPN_LDS((conv_igemm_big_kernel<__VA_ARGS__>), (int)lds_);                               \
+    hipLaunchKernelGGL((conv_igemm_big_kernel<__VA_ARGS__>), grid, dim3(512), lds_, st, a);  \
+  } while (0)
+  if (kind == 5) {
     if constexpr (MODE == 0 && sizeof(T) == 2) {
       const size_t lds_ = 2 * (size_t)(256 + 256) * 128;
-      if (!out_f32 && (g_conv_stagger || (a.flags & NRPN_CONV_DEBUG_STAGGER))) {
-        NRPN_LDS((conv_igemm_big_kernel<false, true>), (int)lds_);
-        hipLaunchKernelGGL((conv_igemm_big_kernel<false, true>), grid, dim3(512), lds_, st, a);
-      } else if (out_f32) {
-        NRPN_LDS((conv_igemm_big_kernel<true>), (int)lds_);
-        hipLaunchKernelGGL(conv_igemm_big_kernel<true>, grid, dim3(512), lds_, st, a);
+      if (out_f32) {
+        NRPN_LDS((conv_igemm_big4_kernel<true>), (int)lds_);
+        hipLaunchKernelGGL(conv_igemm_big4_kernel<true>, grid, dim3(256), lds_, st, a);
       } else {
-        NRPN_LDS((conv_igemm_big_kernel<false>), (int)lds_);
-        hipLaunchKernelGGL(conv_igemm_big_kernel<false>, grid, dim3(512), lds_, st, a);
+        NRPN_LDS((conv_igemm_big4_kernel<false>), (int)lds_);
+        hipLaunchKernelGGL(conv_igemm_big4_kernel<false>, grid, dim3(256), lds_, st, a);
+      }
+    }
+  } else if (huge) {
+    if constexpr (MODE == 0 && sizeof(T) == 2) {
+      const size_t lds_ = 2 * (size_t)(256 + 256) * 128;
+      const int dbg = ((kn.dbg & NRPN_CONV_DEBUG_ALIAS_TAPS) ? 1 : 0) | ((kn.dbg & NRPN_CONV_DEBUG_NO_SYNC) ? 2 : 0);
+      if (!out_f32 && (kn.stagger || (kn.dbg & NRPN_CONV_DEBUG_STAGGER))) {
+        // DBG != 0: tools-only timing variants (wrong results by construction); the production instantiation has no such branch
+        if (dbg == 0) NRPN_LBIG(false, true, 0);
+        else if (dbg == 1) NRPN_LBIG(false, true, 1);
+        else if (dbg == 2) NRPN_LBIG(false, true, 2);
+        else NRPN_LBIG(false, true, 3);
+      } else if (out_f32) {
+        NRPN_LBIG(true, false, 0);
+      } else {
+        NRPN_LBIG(false, false, 0);
       }
     }
   } else if (big) {
@@ -1136,6 +1467,7 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
     }
   } else if (bn == 64) { if (out_f32) NRPN_LC2(64, true); else NRPN_LC2(64, false); }
   else { if (out_f32) NRPN_LC2(128, true); else NRPN_LC2(128, false); }
+#undef NRPN_LBIG
 #undef NRPN_LC2
 #undef NRPN_LC
   if (rc) return rc;
@@ -1143,70 +1475,78 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st) {
   return NRPN_OK;
 }
 
-extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
-  const long long M = (long long)n * gx * gy * gz;
-  const int bs = conv_big_split(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
+static size_t fwd_workspace_bytes(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn) {
+  const int bs = conv_big_split(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, kn);
   if (bs) return (size_t)bs * M * cout * 4;
-  const int s = conv_ksplit(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
+  const int s = conv_ksplit(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, kn);
   return s > 1 ? (size_t)s * M * cout * 4 : 0;
+}
+extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
+  return fwd_workspace_bytes((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr));
+}
+extern "C" size_t nrpn_conv3d_fwd_workspace_bytes_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype,
+                                                     const nrpn_conv_opts *opts) {
+  return fwd_workspace_bytes((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts));
 }
 
 // Which kernel a forward / dgrad launch of this shape selects (mirrors launch_conv + conv3d_fwd_impl; lets tests assert that a
-// shape really exercises the kernel they claim to cover): 0 = 128-row tile, 1 = 256x256 tile, 2 = 256x256 tile on K slices,
-// 3 = 128-row tile on K slices, 4 = wave-specialised 256x128 (opt-in).
-extern "C" int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
-  const long long M = (long long)n * gx * gy * gz;
+// shape really exercises the kernel they claim to cover): 0 = 128-row tile, 1 = 256x256 tile (8 waves), 2 = 256x256 tile on K slices,
+// 3 = 128-row tile on K slices, 4 = wave-specialised 256x128 (opt-in), 5 = 256x256 tile on 4 waves, 6 = the same on K slices.
+static int fwd_plan(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn) {
   const int es = dtype == NRPN_F32 ? 4 : 2, taps = ksize == 3 ? 27 : 1;
-  if (conv_big_split(M, cout, cin, taps, es)) return 2;
-  if (conv_ksplit(M, cout, cin, taps, es) > 1) return 3;
-  const bool wide = g_conv_kb == 128 && (cin * es) % 128 == 0;
-  const bool can = g_conv_glds && wide && cout > 64 && es == 2;
-  const long long tiles_big = cdiv64(M, 256) * ((cout + 255) / 256);
-  if (can && cout >= 256 && (g_conv_bm == 512 || (g_conv_bm == 0 && tiles_big >= 200))) return 1;
-  if (can && g_conv_bm == 256) return 4;
-  return 0;
+  if (conv_big_split(M, cout, cin, taps, es, kn)) return conv_tile_kind(M, cout, cin, es, true, false, kn) == 5 ? 6 : 2;
+  if (conv_ksplit(M, cout, cin, taps, es, kn) > 1) return 3;
+  return conv_tile_kind(M, cout, cin, es, false, false, kn);
+}
+extern "C" int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
+  return fwd_plan((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr));
+}
+extern "C" int nrpn_conv3d_fwd_plan_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype, const nrpn_conv_opts *opts) {
+  return fwd_plan((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts));
 }
 
 static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, const void *mask, void *y, long long M, int gx, int gy, int gz, const Segs *segs,
                            int cin, int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream,
-                           float *stats = nullptr) {
+                           float *stats = nullptr, const nrpn_conv_opts *opts = nullptr) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_fwd: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_fwd: bad dtype %d", dtype);
   NRPN_REQUIRE(M > 0 && gx > 0 && gy > 0 && gz > 0 && cin > 0 && cout > 0 && wrows >= cout, "conv3d_fwd: bad sizes");
   const int es = dtype == NRPN_F32 ? 4 : 2;
   NRPN_REQUIRE((cin * es) % 64 == 0, "conv3d_fwd: Cin*elemsize must be a multiple of 64 bytes (Cin=%d)", cin);
   NRPN_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
+  const Knobs kn = resolve_knobs(opts, flags);
   ConvArgs a{};
   a.x = x; a.w = wp; a.bias = bias; a.mask = mask; a.y = y; a.stats = stats;
+  a.scale = opts ? opts->scale : nullptr;
   a.M = M;
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // classic layout: the kernel splits v into (batch, x, y, z) with these
   if (segs) a.segs = *segs;
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1;
-  a.flags = flags & (3 | NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER);
+  a.flags = flags & 3;
   NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && (long long)a.taps * wrows * cin * es < (1ll << 31),
                "conv3d_fwd: activation / weight tensors must stay below 2 GiB (32-bit buffer offsets)");
   a.x_bytes = (unsigned)(a.M * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);
   const bool out_f32 = (flags & NRPN_CONV_OUT_F32) != 0;
   hipStream_t st = as_stream(stream);
-  const int bs = workspace ? conv_big_split(a.M, cout, cin, a.taps, es) : 0;
+  const int bs = workspace ? conv_big_split(a.M, cout, cin, a.taps, es, kn) : 0;
   if (bs) {
     a.ksplit = bs; a.slices = 1; a.ws = reinterpret_cast<float *>(workspace);
   } else {
-    a.ksplit = workspace ? conv_ksplit(a.M, cout, cin, a.taps, es) : 1;
+    a.ksplit = workspace ? conv_ksplit(a.M, cout, cin, a.taps, es, kn) : 1;
     if (a.ksplit > 1) a.ws = reinterpret_cast<float *>(workspace);
   }
   const int nsl = a.ksplit;
-  int rc = (dtype == NRPN_F32) ? launch_conv<float, 0>(a, true, st) : launch_conv<bf16s, 0>(a, out_f32, st);
+  int rc = (dtype == NRPN_F32) ? launch_conv<float, 0>(a, true, st, kn) : launch_conv<bf16s, 0>(a, out_f32, st, kn);
   if (rc || a.ksplit <= 1) return rc;
   const long long total = a.M * cout;
   const int blocks = (int)min((long long)4096, (total + 255) / 256);
   const float *b = (flags & NRPN_CONV_BIAS) ? bias : nullptr;
   const int relu = (flags & NRPN_CONV_RELU) ? 1 : 0;
   if (dtype == NRPN_F32 || out_f32) {
-    if (dtype == NRPN_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const float *)a.mask);
-    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)a.mask);
+    if (dtype == NRPN_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const float *)a.mask, a.scale);
+    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)a.mask, a.scale);
   } else {
-    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)a.mask);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)a.mask, a.scale);
   }
   NRPN_LAUNCH_CHECK("splitk_epilogue");
   return NRPN_OK;
@@ -1223,13 +1563,18 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
 
 // Rows P of the partial-statistics buffer [P][2][Cout] a forward launch of this shape fills when asked to (0 = the shape runs a kernel
 // without fused statistics: K-sliced, fp32, narrow K-step or the opt-in variants -- use nrpn_bn_stats on the output instead).
-extern "C" int nrpn_conv3d_fwd_stats_rows(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
-  if (dtype != NRPN_BF16 || (cout & 7) != 0 || !g_conv_glds || g_conv_bm == 256) return 0;
-  const long long M = (long long)n * gx * gy * gz;
-  const int plan = nrpn_conv3d_fwd_plan(n, gx, gy, gz, cin, cout, ksize, dtype);
-  if (plan == 1) return (int)(cdiv64(M, 256) * 2);
-  if (plan != 0 || g_conv_kb != 128 || (cin * 2) % 128 != 0) return 0;
+static int fwd_stats_rows(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn) {
+  if (dtype != NRPN_BF16 || (cout & 7) != 0 || !kn.glds || kn.bm == 256) return 0;
+  const int plan = fwd_plan(M, cin, cout, ksize, dtype, kn);
+  if (plan == 1 || plan == 5) return (int)(cdiv64(M, 256) * 2);
+  if (plan != 0 || kn.kb != 128 || (cin * 2) % 128 != 0) return 0;
   return (int)(cdiv64(M, 128) * (cout <= 64 ? 4 : 2));
+}
+extern "C" int nrpn_conv3d_fwd_stats_rows(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
+  return fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr));
+}
+extern "C" int nrpn_conv3d_fwd_stats_rows_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype, const nrpn_conv_opts *opts) {
+  return fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts));
 }
 
 // nrpn_conv3d_fwd + partial BatchNorm statistics of the stored outputs from the same launch (finish them with nrpn_bn_stats_finalize).
@@ -1242,6 +1587,26 @@ extern "C" int nrpn_conv3d_fwd_stats(const void *x, const void *wp, const float 
                          nullptr, stream, stats);
 }
 
+// The general form: nrpn_conv3d_fwd with a per-call plan and the fused-epilogue extras of `opts` (see nerfrpn.h): per-channel scale
+// (eval-mode BatchNorm fold), ReLU mask, BatchNorm statistics partials, tile / K-step / staging overrides.  opts == NULL: nrpn_conv3d_fwd.
+extern "C" int nrpn_conv3d_fwd_ex(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cin,
+                                  int cout, int wrows, int ksize, int dtype, int flags, void *workspace, const nrpn_conv_opts *opts,
+                                  nrpn_stream_t stream) {
+  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0, "conv3d_fwd_ex: bad sizes");
+  NRPN_REQUIRE(!opts || opts->size == (int32_t)sizeof(nrpn_conv_opts), "conv3d_fwd_ex: opts->size must be sizeof(nrpn_conv_opts)");
+  const void *mask = opts ? opts->relu_mask : nullptr;
+  float *stats = opts ? opts->stats : nullptr;
+  NRPN_REQUIRE(!mask || !(flags & NRPN_CONV_OUT_F32) || dtype == NRPN_F32, "conv3d_fwd_ex: relu_mask needs outputs in the input dtype");
+  if (stats) {
+    NRPN_REQUIRE(fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts)) > 0 && !(flags & NRPN_CONV_OUT_F32) &&
+                     wrows == cout && !mask,
+                 "conv3d_fwd_ex: this shape / plan does not run a kernel with fused statistics (nrpn_conv3d_fwd_stats_rows_ex)");
+    workspace = nullptr;
+  }
+  return conv3d_fwd_impl(x, wp, bias, mask, y, (long long)n * gx * gy * gz, gx, gy, gz, nullptr, cin, cout, wrows, ksize, dtype, flags,
+                         workspace, stream, stats, opts);
+}
+
 extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, void *y, int nseg, const int32_t *dims, int cin,
                                       int cout, int wrows, int ksize, int dtype, int flags, void *workspace, nrpn_stream_t stream) {
   Segs sg{};
@@ -1250,14 +1615,17 @@ extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float
   return conv3d_fwd_impl(x, wp, bias, nullptr, y, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, flags, workspace, stream);
 }
 
-extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
-                                    int stride, int dtype, int flags, nrpn_stream_t stream) {
+static int stem_fwd_impl(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
+                         int stride, int dtype, int flags, const nrpn_conv_opts *opts, nrpn_stream_t stream) {
   NRPN_REQUIRE(stride == 1 || stride == 2, "stem: stride must be 1 or 2 (got %d)", stride);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "stem: bad dtype %d", dtype);
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && cout > 0, "stem: bad sizes");
   NRPN_REQUIRE(x && wp && y, "stem: null pointer");
+  NRPN_REQUIRE(!opts || opts->size == (int32_t)sizeof(nrpn_conv_opts), "stem: opts->size must be sizeof(nrpn_conv_opts)");
+  NRPN_REQUIRE(!opts || (!opts->relu_mask && !opts->stats), "stem: relu_mask / stats are not available on the stem");
   ConvArgs a{};
   a.x = x; a.w = wp; a.bias = bias; a.y = y;
+  a.scale = opts ? opts->scale : nullptr;
   a.X = gx; a.Y = gy; a.Z = gz;
   a.OX = (gx + 6 - 7) / stride + 1; a.OY = (gy + 6 - 7) / stride + 1; a.OZ = (gz + 6 - 7) / stride + 1;
   a.M = (long long)n * a.OX * a.OY * a.OZ;
@@ -1267,8 +1635,226 @@ extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *
     NRPN_REQUIRE(xb < (1ll << 31), "stem: input must stay below 2 GiB");
     a.x_bytes = (unsigned)xb; a.w_bytes = 0;
   }
-  if (dtype == NRPN_F32) return launch_conv<float, 1>(a, true, as_stream(stream));
-  return launch_conv<bf16s, 1>(a, false, as_stream(stream));
+  const Knobs kn = resolve_knobs(opts);
+  if (dtype == NRPN_F32) return launch_conv<float, 1>(a, true, as_stream(stream), kn);
+  return launch_conv<bf16s, 1>(a, false, as_stream(stream), kn);
+}
+
+extern "C" int nrpn_conv3d_stem_fwd(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
+                                    int stride, int dtype, int flags, nrpn_stream_t stream) {
+  return stem_fwd_impl(x, wp, bias, y, n, gx, gy, gz, cout, stride, dtype, flags, nullptr, stream);
+}
+
+// nrpn_conv3d_stem_fwd with the fused-epilogue extras of `opts` that apply to the stem: per-channel scale (eval-mode BatchNorm fold)
+// with NRPN_CONV_RELU on top (feature_extractor.py:336-338 conv -> BN -> ReLU in one launch)
+extern "C" int nrpn_conv3d_stem_fwd_ex(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
+                                       int stride, int dtype, int flags, const nrpn_conv_opts *opts, nrpn_stream_t stream) {
+  return stem_fwd_impl(x, wp, bias, y, n, gx, gy, gz, cout, stride, dtype, flags, opts, stream);
+}
+
+
+// =====================================================================================================================
+// Stem forward, "halo" form: Conv3d(4 -> 64, k7, stride 2, pad 3) on bf16 with even Z  (feature_extractor.py:336, VGG / ResNet stems)
+//
+// The im2col kernel above pulls 343 taps x 8 bytes = 2.7 kB through the L1 -> LDS path per output voxel although neighbouring outputs
+// share almost all of it (1.4 GB per 160^3 scene, 200 us).  Here a workgroup owns a 4 x 4 x 16 block of output voxels, stages the
+// 13 x 13 x 40 x 4-channel input halo of that block in LDS ONCE (57 KB: ~230 B per output voxel) and takes every A fragment straight
+// from it: for a fixed (dx, dy) the 7 dz taps x 4 channels of one output voxel are 28 contiguous elements of a z-row, 32 with one
+// unused leading position (stride 2 => the run of output oz starts at the even z = 2 oz - 4), so lane (row, k-half) of the 32x32x16
+// MFMA reads its 8 k-values as ONE ds_read_b128 at  halo[2 oxl + dx][2 oyl + dy][2 ozl + 4 s + 2 k-half]  -- a per-lane base plus a
+// compile-time offset (the 25 K-steps are unrolled).  K = 50 (dx, dy) slots x 32 = 1600 (slot 49 and the leading z position carry zero
+// weights: 86 % of the MFMA work is useful).  B = the weights [64][1600], streamed 2 taps (8 KB) per K-step by LDS-DMA, double-buffered.
+// Row order inside the tile: r = ozl + 16 (oxl & 1) + 32 (oyl + 4 (oxl >> 1)), so the two half-blocks of a 32-row MFMA block are two
+// x-rows = 35 x 256 bytes apart: conflict-free ds_read_b128.  74.8 KB of LDS: two workgroups per CU.
+// =====================================================================================================================
+struct StemHaloArgs {
+  const void *x, *w;
+  const float *bias, *scale;
+  void *y;
+  int N, X, Y, Z, OX, OY, OZ;
+  int tx, ty, tz;           // tiles per axis
+  int flags;
+  unsigned x_bytes, w_bytes;
+};
+namespace sh {
+constexpr int TX = 4, TY = 4, TZ = 16, HX = 13, HY = 14, PITCH = 320, PPRZ = PITCH / 16;     // HY: 13 used rows + 1 pad (x-row stride = 35 * 128 B)
+constexpr int HALO_PIECES = HX * HY * PPRZ;                    // 3640 16-byte pieces
+constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;            // 57 wave-instructions of 1 KiB
+constexpr int HALO_BYTES = HALO_INSTR * 1024;                  // 58368
+constexpr int KTAPS = 50, KROW = KTAPS * 32;                   // packed weight row length (elements)
+constexpr int B_BYTES = 64 * 128;                              // one K-step: 64 output rows x 2 taps x 64 B
+constexpr int LDS_BYTES = HALO_BYTES + 2 * B_BYTES;            // 74752
+}  // namespace sh
+
+__global__ void __launch_bounds__(256, 2) stem_fwd_halo_kernel(const StemHaloArgs p) {
+  using namespace sh;
+  typedef bf16s T;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char *halo = lds;
+  char *Bt = lds + HALO_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // tile -> (n, ox0, oy0, oz0); consecutive workgroups walk z, then y, then x of one scene
+  unsigned t = blockIdx.x;
+  const int tzi = (int)(t % p.tz); t /= p.tz;
+  const int tyi = (int)(t % p.ty); t /= p.ty;
+  const int txi = (int)(t % p.tx);
+  const int n = (int)(t / p.tx);
+  const int ox0 = txi * TX, oy0 = tyi * TY, oz0 = tzi * TZ;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+  // ---- halo: piece q = 64 * instr + lane -> (z-row, 2-z piece); whole pieces are inside or outside the grid (Z even)
+#pragma unroll 1
+  for (int inst = wave_u; inst < HALO_INSTR; inst += 4) {
+    const int q = inst * 64 + lane;
+    const int row = q / PPRZ, pz = q - row * PPRZ;
+    const int hx = row / HY, hy = row - hx * HY;
+    const int ix = 2 * ox0 - 3 + hx, iy = 2 * oy0 - 3 + hy, iz = 2 * oz0 - 4 + 2 * pz;
+    const bool ok = q < HALO_PIECES && hy < 13 && (unsigned)ix < (unsigned)p.X && (unsigned)iy < (unsigned)p.Y && iz >= 0 && iz + 2 <= p.Z;
+    const unsigned off = ok ? (unsigned)(((((long long)n * p.X + ix) * p.Y + iy) * p.Z + iz) * 8) : kOOB;
+    lds_dma16(xr, halo + inst * 1024, off);
+  }
+  // ---- B tile of K-step ks: 64 rows x 8 pieces; this lane owns rows tid / 8 and tid / 8 + 32, physical slot tid % 8
+  const int br = tid >> 3, bs = tid & 7;
+  unsigned b_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = br + 32 * i;
+    b_voff[i] = (unsigned)(r * KROW * 2) + ((bs ^ ((r >> 1) & 7)) << 4);
+  }
+  auto issue_b = [&](int buf, int ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lds_dma16(wr, Bt + buf * B_BYTES + (wave_u * 8 + 32 * i) * 128, b_voff[i] + (unsigned)(ks * 128));
+  };
+  issue_b(0, 0);
+
+  // ---- fragment addresses
+  const int fr = lane & 31, fk = lane >> 5;
+  int a_base[2], b_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int blk = wave * 2 + i;
+    const int ozl = fr & 15, xh = fr >> 4, oyl = blk & 3, oxl = 2 * (blk >> 2) + xh;
+    a_base[i] = ((2 * oxl) * HY + 2 * oyl) * PITCH + 16 * ozl + 16 * fk;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_row[j] = j * 32 + fr;
+  f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < KTAPS / 2; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < KTAPS / 2) issue_b(buf ^ 1, ks + 1);
+    const char *B = Bt + buf * B_BYTES;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int tap = 2 * ks + tt;
+      if (tap >= 49) continue;              // slot 49: zero weights, and its halo offset would leave the staged block
+      const int dx = tap / 7, dy = tap % 7;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f4 af[2], bfv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f4 *>(halo + a_base[i] + (dx * HY + dy) * PITCH + 32 * s2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bfv[j] = *reinterpret_cast<const f4 *>(B + b_row[j] * 128 + ((((tt * 2 + s2) * 2 + fk) ^ ((b_row[j] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], af[i], bfv[j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: scale / bias / ReLU, staged through LDS (the halo is free after the last barrier), 16-byte stores
+  const bool has_bias = (p.flags & NRPN_CONV_BIAS) && p.bias;
+  const bool relu = p.flags & NRPN_CONV_RELU;
+  constexpr int SP = 144;
+  char *stage = lds + wave * (64 * SP);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = j * 32 + fr;
+    const float bv = has_bias ? p.bias[col] : 0.f;
+    const float sv = p.scale ? p.scale[col] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float o = acc[i][j][r] * sv + bv;
+        if (relu) o = fmaxf(o, 0.f);
+        *reinterpret_cast<bf16s *>(stage + (i * 32 + frag_row(r, lane)) * SP + col * 2) = f32_to_bf16_bits(o);
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  T *yp = reinterpret_cast<T *>(p.y);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int pc = lane + 64 * q;                 // 64 rows x 8 pieces
+    const int rl = pc >> 3, seg = pc & 7;
+    const int rr = rl & 31, blk = wave * 2 + (rl >> 5);
+    const int oz = oz0 + (rr & 15), oy = oy0 + (blk & 3), ox = ox0 + 2 * (blk >> 2) + (rr >> 4);
+    if (ox < p.OX && oy < p.OY && oz < p.OZ) {
+      const f4 val = *reinterpret_cast<const f4 *>(stage + rl * SP + seg * 16);
+      *reinterpret_cast<f4 *>(yp + ((((long long)n * p.OX + ox) * p.OY + oy) * p.OZ + oz) * 64 + seg * 8) = val;
+    }
+  }
+}
+
+// halo-form stem weights: reference [64][4][7][7][7] fp32 -> bf16 [64][50 * 32], k = (dx * 7 + dy) * 32 + (dz + 1) * 4 + c; the unused
+// leading z position of every slot and slot 49 are zero
+__global__ void pack_stem_halo_kernel(const float *__restrict__ w, int cout, bf16s *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)cout * sh::KROW) return;
+  const int k = (int)(i % sh::KROW), o = (int)(i / sh::KROW);
+  const int slot = k >> 5, zc = k & 31, zrel = zc >> 2, c = zc & 3;
+  float v = 0.f;
+  if (slot < 49 && zrel >= 1) v = w[((long long)o * 4 + c) * 343 + slot * 7 + (zrel - 1)];
+  out[i] = f32_to_bf16_bits(v);
+}
+
+extern "C" int nrpn_stem_halo_supported(int gz, int cout, int stride, int dtype) {
+  return (dtype == NRPN_BF16 && stride == 2 && cout == 64 && gz % 2 == 0) ? 1 : 0;
+}
+extern "C" int nrpn_stem_halo_kpad(void) { return sh::KROW; }
+
+extern "C" int nrpn_pack_stem_weight_halo(const float *w_ref, int cout, void *wp, nrpn_stream_t stream) {
+  NRPN_REQUIRE(w_ref && wp && cout == 64, "pack_stem_weight_halo: Cout must be 64");
+  hipLaunchKernelGGL(pack_stem_halo_kernel, dim3((unsigned)cdiv64((long long)cout * sh::KROW, 256)), dim3(256), 0, as_stream(stream), w_ref, cout,
+                     (bf16s *)wp);
+  NRPN_LAUNCH_CHECK("pack_stem_weight_halo");
+  return NRPN_OK;
+}
+
+// y [N, (X+1)/2, (Y+1)/2, Z/2, 64] bf16 = stem conv of x [N,X,Y,Z,4] bf16 with wp from nrpn_pack_stem_weight_halo; epilogue:
+// acc * scale + bias, ReLU (NRPN_CONV_BIAS / NRPN_CONV_RELU in flags; scale optional = eval-mode BatchNorm fold)
+extern "C" int nrpn_conv3d_stem_fwd_halo(const void *x, const void *wp, const float *bias, const float *scale, void *y, int n, int gx, int gy,
+                                         int gz, int cout, int flags, nrpn_stream_t stream) {
+  NRPN_REQUIRE(nrpn_stem_halo_supported(gz, cout, 2, NRPN_BF16), "stem_fwd_halo: needs bf16, stride 2, Cout 64 and an even Z (got Z=%d Cout=%d)", gz, cout);
+  NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && x && wp && y, "stem_fwd_halo: bad sizes / null pointer");
+  StemHaloArgs a{};
+  a.x = x; a.w = wp; a.bias = bias; a.scale = scale; a.y = y;
+  a.N = n; a.X = gx; a.Y = gy; a.Z = gz;
+  a.OX = (gx - 1) / 2 + 1; a.OY = (gy - 1) / 2 + 1; a.OZ = (gz - 1) / 2 + 1;
+  a.tx = (a.OX + sh::TX - 1) / sh::TX; a.ty = (a.OY + sh::TY - 1) / sh::TY; a.tz = (a.OZ + sh::TZ - 1) / sh::TZ;
+  a.flags = flags & 3;
+  const long long xb = (long long)n * gx * gy * gz * 8;
+  NRPN_REQUIRE(xb < (1ll << 31), "stem_fwd_halo: input must stay below 2 GiB");
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)(cout * sh::KROW * 2);
+  const long long tiles = (long long)n * a.tx * a.ty * a.tz;
+  NRPN_REQUIRE(tiles < (1ll << 31), "stem_fwd_halo: too many tiles");
+  NRPN_LDS(stem_fwd_halo_kernel, sh::LDS_BYTES);
+  hipLaunchKernelGGL(stem_fwd_halo_kernel, dim3((unsigned)tiles), dim3(256), sh::LDS_BYTES, as_stream(stream), a);
+  NRPN_LAUNCH_CHECK("stem_fwd_halo");
+  return NRPN_OK;
 }
 
 // =====================================================================================================================
@@ -2019,10 +2605,10 @@ __global__ void tap_mask_kernel(unsigned *__restrict__ mask, long long M, int X,
   mask[v] = m;
 }
 
-static int g_wgrad_tr_mode = 1;
+static std::atomic<int> g_wgrad_tr_mode{1};
 extern "C" int nrpn_set_wgrad_transpose_read(int on) { g_wgrad_tr_mode = on ? 1 : 0; return NRPN_OK; }
 
-static int g_wgrad_big = 1;   // 1: 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256 (tuning knob)
+static std::atomic<int> g_wgrad_big{1};   // 1: 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256 (tuning knob)
 extern "C" int nrpn_set_wgrad_big_tile(int on) { g_wgrad_big = on ? 1 : 0; return NRPN_OK; }
 
 // How the voxel axis is cut: every (tile, tap, slice) workgroup writes one partial gradient; the slices are summed by the

@@ -110,12 +110,12 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward_cl(self, x):
-        out = hip_nn.batch_norm(self.bn1, hip_nn.conv3d(self.conv1, x), True)
-        out = hip_nn.batch_norm(self.bn2, hip_nn.conv3d(self.conv2, out), True)
-        out = hip_nn.batch_norm(self.bn3, hip_nn.conv3d(self.conv3, out), False)
+        out = hip_nn.conv_bn(self.conv1, self.bn1, x, True)
+        out = hip_nn.conv_bn(self.conv2, self.bn2, out, True)
+        out = hip_nn.conv_bn(self.conv3, self.bn3, out, False)
         res = x
         if self.downsample is not None:
-            res = hip_nn.batch_norm(self.downsample[1], hip_nn.conv3d(self.downsample[0], x), False)
+            res = hip_nn.conv_bn(self.downsample[0], self.downsample[1], x, False)
         return ops.AddReluFn.apply(out, res, True)
 
     def forward(self, x):
@@ -161,7 +161,7 @@ class ResNet_FPN_256(nn.Module):
         return nn.Sequential(*mods)
 
     def forward_cl(self, x):
-        c = hip_nn.batch_norm(self.bn1, hip_nn.conv3d(self.conv1, x), True)
+        c = hip_nn.conv_bn(self.conv1, self.bn1, x, True)
         if self.is_max_pool:
             c = hip_nn.max_pool(self._pool, c)
         taps = []

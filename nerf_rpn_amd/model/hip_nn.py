@@ -16,14 +16,17 @@ def _pack_of(mod):
     return pk
 
 
-def conv3d(mod, x, relu=False, out_f32=False, segs=None, chain=0, stats=None):
+def conv3d(mod, x, relu=False, out_f32=False, segs=None, chain=0, stats=None, affine=None):
     """nn.Conv3d (k 1|3, stride 1, same padding; or the 4-channel k7 stem) on a channels-last tensor.
-    ``segs``: x is a ragged list [1, sum voxels, 1, 1, C] of grids with these (X, Y, Z) dims (see ``ragged_cat``)."""
+    ``segs``: x is a ragged list [1, sum voxels, 1, 1, C] of grids with these (X, Y, Z) dims (see ``ragged_cat``).
+    ``affine``: (scale, shift) f32 [Cout] of an eval-mode BatchNorm folded behind this conv (``bn_fold``): y = conv_nobias * scale + shift."""
     k = mod.kernel_size[0]
     if k == 7:
         if mod.in_channels != 4 or mod.padding[0] != 3:
             raise NotImplementedError("k7 conv is only implemented for the 4-channel stem")
         cache = mod.__dict__.setdefault("_nrpn_stem", {})
+        if affine is not None:
+            return ops.StemFn.apply(x, mod.weight, mod.bias, mod.stride[0], cache, affine, relu)
         y = ops.StemFn.apply(x, mod.weight, mod.bias, mod.stride[0], cache)
         if relu:
             raise NotImplementedError("stem is always followed by BatchNorm in this model family")
@@ -34,7 +37,7 @@ def conv3d(mod, x, relu=False, out_f32=False, segs=None, chain=0, stats=None):
         raise NotImplementedError(f"Conv3d k={k} stride={mod.stride} padding={mod.padding} has no HIP kernel yet")
     if segs is not None and (k == 7 or mod.stride[0] != 1):
         raise NotImplementedError("ragged voxel lists are supported by the stride-1 k1 / k3 convolutions only")
-    mode = (relu, chain, stats) if stats is not None else ((relu, chain) if chain else relu)
+    mode = (relu, chain, stats, affine) if affine is not None else ((relu, chain, stats) if stats is not None else ((relu, chain) if chain else relu))
     return ops.ConvFn.apply(x, _pack_of(mod), mod.out_channels, mode, out_f32, 1 if segs is None else (1, tuple(segs)), mod.weight, mod.bias)
 
 
@@ -96,6 +99,46 @@ def bn_counters(root):
 import os as _os
 
 FUSED_BN_STATS = _os.environ.get("NRPN_BN_FUSED_STATS", "1") != "0"      # A/B switch; default on
+FOLD_EVAL_BN = _os.environ.get("NRPN_BN_FOLD", "1") != "0"               # A/B switch; default on
+
+
+def bn_fold(conv, bn):
+    """(scale, shift) f32 [C] of an eval-mode BatchNorm3d folded behind ``conv`` (reference conv -> BN -> ReLU, feature_extractor.py:345-358):
+    scale = gamma / sqrt(running_var + eps), shift = (conv bias - running_mean) * scale + beta.  Cached on the parameter / buffer
+    versions and the raw-pointer weight epoch, so an eval forward costs no extra launches after the first."""
+    ts = [conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts) + (bn.eps, ops._weight_epoch)
+    ent = bn.__dict__.get("_nrpn_fold")
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            var = bn.running_var.detach().float()
+            gamma = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(var)
+            beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(var)
+            scale = gamma * torch.rsqrt(var + bn.eps)
+            cb = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(var)
+            shift = (cb - bn.running_mean.detach().float()) * scale + beta
+        ent = (key, scale.contiguous(), shift.contiguous())
+        bn.__dict__["_nrpn_fold"] = ent
+    return ent[1], ent[2]
+
+
+def _can_fold(conv, bn, x):
+    """eval-mode BatchNorm behind a conv the kernels can carry it in (stride-1 k1 / k3 and the stem), and nothing needs a gradient."""
+    if not FOLD_EVAL_BN or bn.training or bn.running_mean is None:
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return False
+    k = conv.kernel_size[0]
+    return k == 7 or k == 1 or (k == 3 and conv.stride[0] == 1)
+
+
+def conv_bn(conv, bn, x, relu, counted=False):
+    """conv -> BatchNorm3d [-> ReLU]: one launch in eval mode (BatchNorm folded into the conv epilogue), conv (+ fused statistics) ->
+    normalisation pass in training mode."""
+    if _can_fold(conv, bn, x):
+        return conv3d(conv, x, relu=relu, affine=bn_fold(conv, bn))
+    holder = {} if (FUSED_BN_STATS and (bn.training or bn.running_mean is None) and conv.kernel_size[0] != 7) else None
+    return batch_norm(bn, conv3d(conv, x, stats=holder), relu, counted, holder)
 
 
 def batch_norm(mod, x, relu, counted=False, stats=None):
@@ -127,7 +170,12 @@ def run_modules(mods, x, counted=False):
         nxt = mods[i + 1] if i + 1 < len(mods) else None
         nxt2 = mods[i + 2] if i + 2 < len(mods) else None
         if isinstance(m, nn.Conv3d):
-            if isinstance(nxt, nn.BatchNorm3d):
+            if isinstance(nxt, nn.BatchNorm3d) and _can_fold(m, nxt, x):
+                # eval mode: BatchNorm (+ ReLU) are the conv's epilogue -- no separate normalisation pass over the activation
+                fuse = isinstance(nxt2, nn.ReLU)
+                x = conv3d(m, x, relu=fuse, affine=bn_fold(m, nxt))
+                i += 3 if fuse else 2
+            elif isinstance(nxt, nn.BatchNorm3d):
                 # training-mode statistics come out of the conv's epilogue where its kernel has them (nrpn_conv3d_fwd_stats)
                 holder = {} if (FUSED_BN_STATS and (nxt.training or nxt.running_mean is None)) else None
                 x = conv3d(m, x, stats=holder)

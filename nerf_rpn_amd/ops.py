@@ -645,10 +645,12 @@ def _seg_dims(segs):
     return (ctypes.c_int32 * len(flat))(*flat)
 
 
-def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask=None, stats=None):
+def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask=None, stats=None, scale=None, tile=0):
     """segs: None, or the (X, Y, Z) dims of the grids laid end to end in x = [1, sum(X*Y*Z), 1, 1, C] (ragged list).
     stats: None, or a dict that asks for BatchNorm statistics out of the conv epilogue: when the shape's kernel has them, the launch
-    fills stats['partials'] = f32 [P, 2, cout] (see nrpn_conv3d_fwd_stats); otherwise the dict stays empty."""
+    fills stats['partials'] = f32 [P, 2, cout] (see nrpn_conv3d_fwd_stats); otherwise the dict stays empty.
+    scale: None or f32 [cout]: y = acc * scale + bias (eval-mode BatchNorm folded into the conv, nrpn_conv_opts.scale).
+    tile: per-call kernel selection (lib.TILE_*; 0 = the library's choice for the shape)."""
     import ctypes
     n, gx, gy, gz, cin = x.shape
     y = torch.empty((n, gx, gy, gz, cout), dtype=out_dtype, device=x.device)
@@ -656,22 +658,33 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask
         flags |= CONV_OUT_F32
     if bias is not None:
         flags |= CONV_BIAS
-    if stats is not None and segs is None and mask is None and out_dtype == x.dtype and wrows == cout:
-        rows = query("conv3d_fwd_stats_rows", n, gx, gy, gz, cin, cout, ksize, _dt(x))
-        if rows > 0:
-            part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
-            call("conv3d_fwd_stats", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(part), _s())
-            stats["partials"] = part
-            return y
-    wsb = query("conv3d_fwd_workspace_bytes", n, gx, gy, gz, cin, cout, ksize, _dt(x))
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-    if segs is None or ksize == 1:
-        call("conv3d_fwd", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), _p(mask), _s())
-    else:
+    if segs is not None and ksize != 1:
+        if scale is not None or mask is not None or tile:
+            raise lib.NrpnError("ragged conv launches take no per-call options")
+        wsb = query("conv3d_fwd_workspace_bytes", n, gx, gy, gz, cin, cout, ksize, _dt(x))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
         dims = _seg_dims(segs)
         call("conv3d_fwd_ragged", _p(x), _p(wp), _p(bias), _p(y), len(segs), ctypes.addressof(dims), cin, cout, wrows, ksize, _dt(x), flags,
              _p(ws), _s())
+        return y
+    opts = lib.ConvOpts(tile=tile or CONV_TILE[0], scale=_p(scale), relu_mask=_p(mask))
+    if stats is not None and segs is None and mask is None and out_dtype == x.dtype and wrows == cout:
+        rows = query("conv3d_fwd_stats_rows_ex", n, gx, gy, gz, cin, cout, ksize, _dt(x), opts.ptr())
+        if rows > 0:
+            part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+            opts.stats = part.data_ptr()
+            call("conv3d_fwd_ex", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, 0, opts.ptr(), _s())
+            stats["partials"] = part
+            return y
+    wsb = query("conv3d_fwd_workspace_bytes_ex", n, gx, gy, gz, cin, cout, ksize, _dt(x), opts.ptr())
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    call("conv3d_fwd_ex", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), opts.ptr(), _s())
     return y
+
+
+# Tile override of every forward / dgrad launch of this process ([0] = lib.TILE_*; 0 = the library's per-shape choice).  A per-call
+# nrpn_conv_opts field underneath -- NOT a library global -- so it is safe next to other threads; bench.py / tools set it for A/B runs.
+CONV_TILE = [int(_os.environ.get("NRPN_CONV_TILE", "0"))]
 
 
 # wgrad workspace = [27-bit tap mask per voxel (k3) | per-slice bias partials]; the masks depend only on the grid, so one workspace per
@@ -713,9 +726,11 @@ class ConvFn(torch.autograd.Function):
         segs = None
         chain = 0
         stats = None
-        if isinstance(relu, tuple):        # (relu, chain[, stats holder]): see CHAIN_* below and _conv_fwd
+        affine = None
+        if isinstance(relu, tuple):        # (relu, chain[, stats holder[, affine]]): see CHAIN_* below and _conv_fwd
             relu, chain, *rest = relu
             stats = rest[0] if rest else None
+            affine = rest[1] if len(rest) > 1 else None
         if isinstance(nw, tuple):          # (nw, segs): ragged voxel list, x = [1, sum voxels, 1, 1, C]
             nw, segs = nw
         weights, biases = wb[:nw], wb[nw:]
@@ -729,6 +744,13 @@ class ConvFn(torch.autograd.Function):
             if bias.numel() < rows_total:
                 bias = torch.cat([bias, bias.new_zeros(rows_total - bias.numel())])
         out_dtype = torch.float32 if out_f32 else x.dtype
+        if affine is not None:
+            # eval-mode BatchNorm folded into this conv: y = acc * scale + shift (the conv's own bias is inside `shift`); forward only --
+            # the HIP path has no eval-mode BatchNorm backward either (BatchNormFn.backward)
+            if any(ctx.needs_input_grad):
+                raise lib.NrpnError("conv with a folded eval-mode BatchNorm is a no-grad forward (run under torch.no_grad())")
+            scale, shift = affine
+            return _conv_fwd(x, wp, shift, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, None, scale)
         y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, stats)
         ctx.save_for_backward(x, y if relu else None, wpd, *weights)
         ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None, segs, chain)
@@ -837,26 +859,49 @@ class ConvFn(torch.autograd.Function):
         return (*gws, *gbs)
 
 
+STEM_HALO = [_os.environ.get("NRPN_STEM_HALO", "1") != "0"]      # A/B switch: halo-form stem forward (bf16, stride 2, even Z, Cout 64); default on
+
+
 class StemFn(torch.autograd.Function):
     """Conv3d(4 -> C, k7, pad 3, stride s) on [N,X,Y,Z,4] (reference feature_extractor.py:336,341)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, cache):
+    def forward(ctx, x, weight, bias, stride, cache, affine=None, relu=False):
         _chk(x)
-        key = (weight.data_ptr(), weight._version, x.dtype, _weight_epoch)
+        n, gx, gy, gz, _ = x.shape
+        cout = weight.shape[0]
+        halo = STEM_HALO[0] and bool(query("stem_halo_supported", gz, cout, stride, _dt(x)))
+        key = (weight.data_ptr(), weight._version, x.dtype, _weight_epoch, halo)
         if cache.get("key") != key:
             PACK_COUNT["stem"] += 1
-            kpad = query("stem_kpad", _dt(x))
-            wp = torch.empty((weight.shape[0], kpad), dtype=x.dtype, device=x.device)
-            call("pack_stem_weight", _p(weight.detach().contiguous()), weight.shape[0], _dt(x), _p(wp), _s())
+            wc = weight.detach().contiguous()
+            if halo:      # bf16 [Cout][50 * 32]: (dx, dy) slot major, 8 z positions x 4 channels inside a slot
+                wp = torch.empty((cout, query("stem_halo_kpad")), dtype=x.dtype, device=x.device)
+                call("pack_stem_weight_halo", _p(wc), cout, _p(wp), _s())
+            else:
+                kpad = query("stem_kpad", _dt(x))
+                wp = torch.empty((cout, kpad), dtype=x.dtype, device=x.device)
+                call("pack_stem_weight", _p(wc), cout, _dt(x), _p(wp), _s())
             cache["key"], cache["wp"] = key, wp
         wp = cache["wp"]
-        n, gx, gy, gz, _ = x.shape
         o = [(g - 1) // stride + 1 for g in (gx, gy, gz)]
-        cout = weight.shape[0]
         y = torch.empty((n, o[0], o[1], o[2], cout), dtype=x.dtype, device=x.device)
+        if affine is not None:       # eval-mode BatchNorm (+ ReLU) folded into the stem: no-grad forward only
+            if any(ctx.needs_input_grad):
+                raise lib.NrpnError("stem with a folded eval-mode BatchNorm is a no-grad forward (run under torch.no_grad())")
+            scale, shift = affine
+            if halo:
+                call("conv3d_stem_fwd_halo", _p(x), _p(wp), _p(shift), _p(scale), _p(y), n, gx, gy, gz, cout, CONV_BIAS | (CONV_RELU if relu else 0), _s())
+            else:
+                opts = lib.ConvOpts(scale=_p(scale))
+                call("conv3d_stem_fwd_ex", _p(x), _p(wp), _p(shift), _p(y), n, gx, gy, gz, cout, stride, _dt(x),
+                     CONV_BIAS | (CONV_RELU if relu else 0), opts.ptr(), _s())
+            return y
         b = bias.detach().float().contiguous() if bias is not None else None
-        call("conv3d_stem_fwd", _p(x), _p(wp), _p(b), _p(y), n, gx, gy, gz, cout, stride, _dt(x), CONV_BIAS if b is not None else 0, _s())
+        if halo:
+            call("conv3d_stem_fwd_halo", _p(x), _p(wp), _p(b), 0, _p(y), n, gx, gy, gz, cout, CONV_BIAS if b is not None else 0, _s())
+        else:
+            call("conv3d_stem_fwd", _p(x), _p(wp), _p(b), _p(y), n, gx, gy, gz, cout, stride, _dt(x), CONV_BIAS if b is not None else 0, _s())
         ctx.save_for_backward(x, weight)
         ctx.meta = (stride, bias is not None)
         ctx.sinks = (_sink(weight), _sink(bias))
@@ -888,7 +933,7 @@ class StemFn(torch.autograd.Function):
         if direct_bias:
             bsink.notify()
             gb = None
-        return None, gw, gb, None, None
+        return None, gw, gb, None, None, None, None
 
 
 class BatchNormFn(torch.autograd.Function):

@@ -379,3 +379,174 @@ def test_batchnorm_statistics_from_the_conv_epilogue(cin, cout, grid, rows_expec
     for a, b in zip(out[True][4:], out[False][4:]):
         scale = b.float().abs().max().item() + 1e-12
         assert (a.float() - b.float()).abs().max().item() <= 2e-2 * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,grid,k", [
+    (64, 64, (2, 9, 8, 7), 3),          # 128-row kernel, 64-column tiles
+    (128, 256, (1, 12, 10, 9), 3),      # 128-row kernel on K slices (small grid): the fold lives in splitk_epilogue_kernel
+    (256, 256, (1, 40, 40, 33), 3),     # 256x256 kernel (bf16) / 128-row kernel (fp32)
+    (512, 512, (1, 20, 20, 20), 3),     # 256x256 kernel on K slices (bf16)
+    (128, 256, (1, 20, 16, 10), 1),     # 1x1x1 lateral
+])
+def test_eval_batchnorm_folded_into_the_conv_epilogue(cin, cout, grid, k, dtype, dev):
+    """eval mode: conv -> BatchNorm3d -> ReLU runs as ONE launch (per-channel scale + shift + ReLU in the conv epilogue,
+    nrpn_conv_opts.scale) and must match torch's conv -> batch_norm(running statistics) -> relu (reference feature_extractor.py:345-358)."""
+    from nerf_rpn_amd.model import hip_nn
+    n, gx, gy, gz = grid
+    torch.manual_seed(cin + gx + k)
+    conv = nn.Conv3d(cin, cout, k, padding=k // 2)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+        conv.bias.uniform_(-0.5, 0.5)
+        conv.weight.mul_(3.0)
+    x = torch.randn(n, cin, gx, gy, gz)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        conv.weight.data = conv.weight.data.bfloat16().float()
+    seq = nn.Sequential(conv, bn, nn.ReLU()).eval()
+    with torch.no_grad():
+        ref = seq(x)
+    hseq = nn.Sequential(nn.Conv3d(cin, cout, k, padding=k // 2), nn.BatchNorm3d(cout), nn.ReLU()).to(dev).eval()
+    hseq.load_state_dict(seq.state_dict())
+    xh = cl(x).to(dev).to(dtype)
+    with torch.no_grad():
+        folded = hip_nn.run_modules(hseq, xh)
+        hip_nn.FOLD_EVAL_BN = False
+        try:
+            separate = hip_nn.run_modules(hseq, xh)
+        finally:
+            hip_nn.FOLD_EVAL_BN = True
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert relerr(cf(folded.float().cpu()), ref) < tol
+    # the fold rounds once (fp32 affine on the accumulator) where the two-kernel path rounds the conv output to bf16 first: it is at
+    # least as close to the fp32 reference as the separate path
+    if dtype == torch.bfloat16:
+        assert relerr(cf(folded.float().cpu()), ref) <= relerr(cf(separate.float().cpu()), ref) * 1.05 + 1e-4
+    # a second forward reuses the cached (scale, shift): no change; an in-place parameter update invalidates the cache
+    with torch.no_grad():
+        again = hip_nn.run_modules(hseq, xh)
+        assert torch.equal(again, folded)
+        hseq[1].running_mean.add_(0.25)
+        moved = hip_nn.run_modules(hseq, xh)
+    assert not torch.equal(moved, folded)
+
+
+def test_eval_stem_with_folded_batchnorm(dev):
+    from nerf_rpn_amd.model import hip_nn
+    torch.manual_seed(4)
+    for dtype, grid in ((torch.bfloat16, (34, 26, 20)), (torch.float32, (18, 15, 12)), (torch.bfloat16, (17, 15, 13))):      # halo kernel / im2col kernels
+        conv, bn = nn.Conv3d(4, 64, 7, stride=2, padding=3), nn.BatchNorm3d(64)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+        x = torch.rand(2, 4, *grid)
+        if dtype == torch.bfloat16:
+            x = x.bfloat16().float()
+            conv.weight.data = conv.weight.data.bfloat16().float()
+        seq = nn.Sequential(conv, bn, nn.ReLU()).eval()
+        with torch.no_grad():
+            ref = seq(x)
+        hseq = nn.Sequential(nn.Conv3d(4, 64, 7, stride=2, padding=3), nn.BatchNorm3d(64), nn.ReLU()).to(dev).eval()
+        hseq.load_state_dict(seq.state_dict())
+        with torch.no_grad():
+            got = hip_nn.run_modules(hseq, cl(x).to(dev).to(dtype))
+        assert relerr(cf(got.float().cpu()), ref) < (2e-5 if dtype == torch.float32 else 2e-2), (dtype, grid)
+
+
+def test_stem_halo_kernel_on_a_multi_tile_grid(dev):
+    """bf16 stem forward (halo form: 4x4x16 output blocks, input halo staged once in LDS) on a grid with several tiles per axis and
+    ragged last tiles, two scenes; against torch fp32 on bf16-rounded operands and against the im2col kernel it replaces."""
+    from nerf_rpn_amd import lib, ops
+    from nerf_rpn_amd.model import hip_nn
+    torch.manual_seed(9)
+    grid = (70, 44, 72)                           # output 35 x 22 x 36: 9 x 6 x 3 tiles, ragged in every axis
+    assert lib.query("stem_halo_supported", grid[2], 64, 2, lib.BF16) == 1
+    conv = nn.Conv3d(4, 64, 7, stride=2, padding=3)
+    conv.weight.data = conv.weight.data.bfloat16().float()
+    x = torch.rand(2, 4, *grid).bfloat16().float()
+    with torch.no_grad():
+        ref = conv(x)
+    h = nn.Conv3d(4, 64, 7, stride=2, padding=3).to(dev)
+    h.load_state_dict(conv.state_dict())
+    xh = cl(x).to(dev).bfloat16()
+    with torch.no_grad():
+        got = hip_nn.conv3d(h, xh)
+        ops.STEM_HALO[0] = False
+        try:
+            old = hip_nn.conv3d(h, xh)
+        finally:
+            ops.STEM_HALO[0] = True
+    assert relerr(cf(got.float().cpu()), ref) < 1e-2
+    assert relerr(got.float().cpu(), old.float().cpu()) < 1e-2
+
+
+def _conv_case(dev, n, grid, cin, cout, seed=0):
+    from nerf_rpn_amd import ops
+    torch.manual_seed(seed)
+    x = torch.randn(n, *grid, cin, device=dev).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
+    wp, _ = ops.PackedWeight().get([w], torch.bfloat16, cout, False)
+    bias = torch.randn(cout, device=dev)
+    return x, wp, bias
+
+
+@pytest.mark.parametrize("cin,cout,grid,plan", [(256, 256, (40, 40, 33), 5), (512, 512, (20, 20, 20), 6), (256, 512, (40, 30, 32), 5)])
+def test_four_wave_256x256_kernel_is_bit_identical_to_the_eight_wave_kernel(cin, cout, grid, plan, dev):
+    """conv_igemm_big4_kernel (4 waves x 128x128, selected per call through nrpn_conv_opts.tile) keeps the per-accumulator MFMA order of
+    conv_igemm_big_kernel: outputs, ReLU-masked outputs and the BatchNorm statistics partials must be EQUAL, also on K slices."""
+    from nerf_rpn_amd import lib, ops
+    x, wp, bias = _conv_case(dev, 1, grid, cin, cout)
+    o4 = lib.ConvOpts(tile=lib.TILE_256X256_W4)
+    assert lib.query("conv3d_fwd_plan_ex", 1, *grid, cin, cout, 3, lib.BF16, o4.ptr()) == plan
+    assert lib.query("conv3d_fwd_plan", 1, *grid, cin, cout, 3, lib.BF16) == plan - 4
+    scale = torch.rand(cout, device=dev) + 0.5
+    mask = torch.randn(1, *grid, cout, device=dev).bfloat16()
+    for kw in (dict(), dict(scale=scale), dict(mask=mask)):
+        a = ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU if "mask" not in kw else 0, torch.bfloat16, tile=lib.TILE_256X256, **kw)
+        b = ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU if "mask" not in kw else 0, torch.bfloat16, tile=lib.TILE_256X256_W4, **kw)
+        assert torch.equal(a, b), (kw.keys(), (a.float() - b.float()).abs().max().item())
+    if plan == 5:
+        sa, sb = {}, {}
+        ops._conv_fwd(x, wp, bias, cout, cout, 3, 0, torch.bfloat16, stats=sa, tile=lib.TILE_256X256)
+        ops._conv_fwd(x, wp, bias, cout, cout, 3, 0, torch.bfloat16, stats=sb, tile=lib.TILE_256X256_W4)
+        assert sa["partials"].shape == sb["partials"].shape
+        # same values summed over the same 128 rows per partial row, in a different order inside a lane: fp32 rounding only
+        assert torch.allclose(sa["partials"], sb["partials"], rtol=1e-5, atol=1e-3)
+    f4 = ops._conv_fwd(x, wp, bias, cout, cout, 3, 0, torch.float32, tile=lib.TILE_256X256_W4)
+    f8 = ops._conv_fwd(x, wp, bias, cout, cout, 3, 0, torch.float32, tile=lib.TILE_256X256)
+    assert torch.equal(f4, f8)
+
+
+def test_two_threads_with_different_plans_share_no_state(dev):
+    """no global state except what the caller passes.  Two host threads launch the same conv on their own streams with
+    DIFFERENT per-call plans (nrpn_conv_opts.tile) at the same time, many times; every result must equal the single-threaded one
+    of its own plan (the process-wide nrpn_set_* knobs are never touched)."""
+    import threading
+    from nerf_rpn_amd import lib, ops
+    grid, cin, cout = (40, 40, 33), 256, 256
+    x, wp, bias = _conv_case(dev, 1, grid, cin, cout, seed=3)
+    tiles = [lib.TILE_128, lib.TILE_256X256_W4]
+    want = [ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU, torch.bfloat16, tile=t) for t in tiles]
+    plans = [lib.query("conv3d_fwd_plan_ex", 1, *grid, cin, cout, 3, lib.BF16, lib.ConvOpts(tile=t).ptr()) for t in tiles]
+    assert plans == [0, 5]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    y = ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU, torch.bfloat16, tile=tiles[i])
+                    if not torch.equal(y, want[i]):
+                        errors.append((i, "mismatch"))
+            st.synchronize()
+        except Exception as e:          # noqa: BLE001
+            errors.append((i, repr(e)))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors

@@ -103,3 +103,103 @@ def test_fullsize_train_step_is_finite_and_deterministic(dev):
     l1, g1_ = run()
     assert math.isfinite(l0) and torch.isfinite(g0).all() and g0.abs().max().item() > 0
     assert l0 == l1 and torch.equal(g0, g1_), (l0, l1, (g0 - g1_).abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# ResNet-50-3D and Swin-S-3D (+ FCOS) at the non-cubic sizes SURVEY 8d names for configs 2-4: 200 x 200 x 130 (the reference's benchmark
+# shape) and 160 x 120 x 64.  Fixtures: tests/golden/make_golden.py::gen_fullsize2 (the reference run in the build container).
+# ------------------------------------------------------------------------------------------------------------------------------------
+RPN_CASES2 = ["eval_resnet_obb_200x200x130", "eval_resnet_aabb_160x120x64", "eval_swin_obb_160x120x64", "eval_swin_obb_200x200x130"]
+FCOS_CASES2 = ["fcos_eval_obb_swin_200x200x130", "fcos_eval_obb_swin_160x120x64"]
+
+
+def _scene2(g):
+    return torch.rand(4, *[int(s) for s in g["shape"]], generator=torch.Generator().manual_seed(int(g["seed"])))
+
+
+def _assert_kernel_coverage(backbone, shape):
+    """Which kernels these shapes select (nrpn_conv3d_fwd_plan: 0 = 128-row tile, 1 = 256x256 tile, 2 = 256x256 on K slices, 3 = 128-row on
+    K slices): the fixtures are only worth their size if they reach the paths the small ones do not."""
+    from nerf_rpn_amd import lib
+    q = lambda *a: lib.query("conv3d_fwd_plan", *a)
+    X, Y, Z = shape
+    if backbone == "resnet":
+        l0 = [-(-(-(-v // 2)) // 2) for v in (X, Y, Z)]          # stem stride 2 + max-pool 3/2/1
+        g = [l0]
+        for _ in range(3):
+            g.append([-(-v // 2) for v in g[-1]])
+        assert q(1, *g[0], 64, 64, 3, lib.BF16) == 0                       # 64-column tile of the 128-row kernel
+        assert q(1, *g[1], 128, 128, 3, lib.BF16) == 3 and q(1, *g[3], 512, 512, 3, lib.BF16) == 3      # K-sliced small levels
+        assert q(1, *g[3], 512, 2048, 1, lib.F32) == 3                     # 2048-channel 1x1x1 expansion (+ the 2048-channel BatchNorm after it)
+        if shape == (200, 200, 130):
+            assert q(1, *g[0], 64, 256, 1, lib.BF16) == 1 and q(1, *g[0], 256, 256, 3, lib.BF16) == 1    # 256x256 tile at 50x50x33
+        else:
+            assert q(1, *g[0], 256, 256, 3, lib.BF16) == 2                 # 40x30x16: 256x256 tile on K slices
+    else:
+        t0 = [(v - 4) // 4 + 1 for v in (X, Y, Z)]                        # patch embedding k4 s4
+        assert any(v % 4 for v in t0)                                      # window padding in stage 0 (50 -> 52 / 30 -> 32 tokens)
+        assert q(1, *t0, 96, 288, 1, lib.BF16) == 0 and (96 * 2) % 128 != 0     # 96-channel stage: the 64-byte K-step path (bf16)
+        assert (96 * 4) % 128 == 0 and (192 * 2) % 128 == 0                     # ... fp32 and the 192-channel stage take the 128-byte step
+
+
+@pytest.mark.parametrize("name", RPN_CASES2)
+def test_fullsize_other_backbones_fp32_match_reference(name, golden, dev):
+    g = golden(name)
+    bbk, rot = str(g["backbone"]), bool(g["rotated"])
+    _assert_kernel_coverage(bbk, tuple(int(v) for v in g["shape"]))
+    m = build(rot, 160, dev, backbone=bbk).eval()
+    with torch.no_grad():
+        (feats, props, lvls), losses, scores = m([_scene2(g).to(dev)])
+    assert losses == {}
+    assert_eval_matches(name, g, feats, props, lvls, scores, 1, dev)
+
+
+# bf16 bounds (features: max error of the sampled values relative to the level's absolute maximum; proposals: fraction of the
+# reference's top-300 matched by a bf16 proposal at IoU > 0.9, IoU by the CPU oracle).  ResNet-50 runs 53 conv layers and Swin-S 24
+# blocks of LayerNorm / softmax / GELU in bf16 storage, against 20 layers for VGG19 (2e-2 / 0.95 above).
+BF16_BOUNDS = {"resnet": (3e-2, 0.90), "swin": (4e-2, 0.85)}
+
+
+@pytest.mark.parametrize("name", RPN_CASES2)
+def test_fullsize_other_backbones_bf16_within_stated_bound(name, golden, dev):
+    from oracle import boxes as OB
+    g = golden(name)
+    bbk, rot = str(g["backbone"]), bool(g["rotated"])
+    m = build(rot, 160, dev, backbone=bbk).eval()
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        (feats, props, lvls), _, scores = m([_scene2(g).to(dev)])
+    ferr_max, worst = BF16_BOUNDS[bbk][0], 0.0
+    for i, f in enumerate(feats):
+        assert list(f.shape) == g[f"feat{i}_shape"].tolist()
+        got = f.float().contiguous().reshape(-1)[T(g[f"feat{i}_idx"], dev)].cpu()
+        err = (got - T(g[f"feat{i}_val"])).abs().max().item() / float(g[f"feat{i}_absmax"])
+        worst = max(worst, err)
+    rp, gp = T(g["proposals0"])[:300], props[0].float().cpu()
+    assert gp.shape[0] > 0 and torch.isfinite(scores[0]).all()
+    iou = OB.iou_matrix(rp, gp) if rot else OB.aabb_iou_matrix(rp, gp)
+    frac = (iou.max(dim=1).values > 0.9).float().mean().item()
+    print(f"[bf16 bound] {name}: feature err {worst:.4f} of level max, top-300 matched {frac:.3f}")
+    assert worst <= ferr_max, (name, worst)
+    assert frac >= BF16_BOUNDS[bbk][1], (name, frac)
+
+
+@pytest.mark.parametrize("name", FCOS_CASES2)
+def test_fullsize_fcos_swin_matches_reference(name, golden, dev):
+    """config 4: Swin-S + FCOS head (OBB) at full size, fp32 against the reference's boxes / scores."""
+    import test_gpu_fcos as TF
+    g = golden(name)
+    _assert_kernel_coverage("swin", tuple(int(v) for v in g["shape"]))
+    m = TF.build(True, "swin", dev).eval()
+    with torch.no_grad():
+        boxes, losses, scores = m([_scene2(g).to(dev)])
+    assert losses == {}
+    rp, rs = T(g["boxes0"]), T(g["scores0"])
+    gp, gs = boxes[0].cpu(), scores[0].cpu()
+    allow = max(5, rp.shape[0] // 50)
+    assert abs(gp.shape[0] - rp.shape[0]) <= allow, (name, gp.shape, rp.shape)
+    near = (gs[None, :] - rs[:, None]).abs() <= 3e-6
+    diff = (gp[None, :, 1:] - rp[:, None, 1:]).abs()
+    tol = 3e-3 + 2e-4 * rp[:, 1:].abs()[:, None, :]
+    ok = ((diff <= tol).all(dim=2) & near & (gp[None, :, 0] == rp[:, None, 0])).any(dim=1)
+    assert (~ok).sum() <= allow, (name, int((~ok).sum()), rp.shape[0])

@@ -1,0 +1,172 @@
+"""Integer stages of the eval path on the REFERENCE's real candidate distribution at BASELINE configs[1] size (one 160^3 x 4 grid,
+VGG19-EF + FPN + RPN, OBB, --normalize_density): the fixture `stages_obb_160_cfg1` (tests/golden/make_golden.py::gen_stages) holds the
+reference's raw logits of all 950 625 anchors, its per-level top-k indices, the deltas / decoded boxes of those candidates, the
+candidates that reach batched_nms, its keep indices and the final proposals (reference rpn.py:292-370, utils.py:215-265).  Each HIP
+stage is fed the reference's OWN tensors and must return equal indices / keep masks (north_star: "anchor indices / NMS keep-masks
+bit-exact"), boxes within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAME = "stages_obb_160_cfg1"
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def _table(dev):
+    from nerf_rpn_amd import ops
+    return ops.AnchorTable((160, 160, 160), [(40, 40, 40), (20, 20, 20), (10, 10, 10), (5, 5, 5)], device=dev)
+
+
+def _canonical(idx, val):
+    """(score desc, index asc) order of a candidate list: the order torch.topk leaves open for equal scores (quirk B7)."""
+    order = np.lexsort((idx, -val.astype(np.float64)))
+    return idx[order]
+
+
+def test_topk_indices_equal_the_reference(golden, dev):
+    from nerf_rpn_amd import ops
+    g = golden(NAME)
+    tab = _table(dev)
+    assert tab.counts == [int(v) for v in g["per_level"]] and tab.total == g["logits"].shape[0]
+    logits = T(g["logits"], dev)
+    idx, val = ops.segmented_topk(logits, tab.offsets, 2500)
+    got = idx.cpu().numpy()
+    ref = np.asarray(g["topk_idx"]).astype(np.int64)
+    lg = np.asarray(g["logits"])
+    k0 = 0
+    for l, n in enumerate(tab.counts):
+        k = min(2500, n)
+        r = ref[k0:k0 + k]
+        h = got[l][:k].astype(np.int64)
+        assert (h >= 0).all()
+        # the selected SET is always defined (no tie at the selection boundary in this fixture) ...
+        assert int(g["ties"][l][1]) == 0
+        assert np.array_equal(np.sort(h), np.sort(r)), l
+        # ... and so is the order up to permutations inside runs of exactly equal logits
+        assert np.array_equal(h, _canonical(r, lg[r])), l
+        if int(g["ties"][l][0]) == 0:
+            assert np.array_equal(h, r), l
+        assert np.array_equal(val[l][:k].cpu().numpy(), lg[h]), l
+        if k < 2500:
+            assert (got[l][k:] < 0).all()
+        k0 += k
+
+
+def test_decode_of_the_reference_candidates(golden, dev):
+    from nerf_rpn_amd import ops
+    g = golden(NAME)
+    tab = _table(dev)
+    idx = T(g["topk_idx"], dev).long()
+    deltas = torch.zeros((tab.total, 8), dtype=torch.float32, device=dev)
+    deltas[idx] = T(g["topk_deltas"], dev)
+    boxes = ops.decode_boxes(tab, deltas, idx, 1).cpu()
+    ref = T(g["topk_boxes"])
+    # north_star: box regressions within 1e-4 (relative; the angle column near the +-pi/2 wrap is compared modulo pi)
+    err = (boxes[:, :6] - ref[:, :6]).abs() / ref[:, :6].abs().clamp_min(1.0)
+    assert err.max().item() <= 1e-4, err.max().item()
+    dth = (boxes[:, 6] - ref[:, 6]).abs()
+    dth = torch.minimum(dth, (dth - 3.141592).abs())
+    assert dth.max().item() <= 1e-4, dth.max().item()
+
+
+def _hip_candidates(g, dev):
+    from nerf_rpn_amd import ops
+    tab = _table(dev)
+    idx = T(g["topk_idx"], dev).long()
+    deltas = torch.zeros((tab.total, 8), dtype=torch.float32, device=dev)
+    deltas[idx] = T(g["topk_deltas"], dev)
+    logits = T(g["logits"], dev)
+    cand = idx.to(torch.int32)
+    boxes = ops.decode_boxes(tab, deltas, cand.long(), 1)
+    counts = [min(2500, n) for n in tab.counts]
+    slot_level = torch.cat([torch.full((c,), l, dtype=torch.int32, device=dev) for l, c in enumerate(counts)]).contiguous()
+    valid = torch.ones(cand.numel(), dtype=torch.uint8, device=dev)
+    return ops.filter_candidates(boxes, logits[idx].contiguous(), slot_level, valid, (160, 160, 160), 1e-3, 0.0, False)
+
+
+def test_filter_reproduces_the_candidates_that_reach_nms(golden, dev):
+    """clip (drop OBBs whose centre leaves the grid, scores NOT dropped with them: quirk B3) / small-box / score filters."""
+    g = golden(NAME)
+    fb, fs, fl, cnt = _hip_candidates(g, dev)
+    m = int(cnt.item())
+    rb, rs, rl = T(g["nms_boxes"]), T(g["nms_scores"]), T(g["nms_levels"])
+    assert m == rb.shape[0], (m, rb.shape)
+    assert torch.equal(fl[:m].cpu().long(), rl.long())
+    assert (fs[:m].cpu() - rs).abs().max().item() <= 1e-6
+    err = (fb[:m, :6].cpu() - rb[:, :6]).abs() / rb[:, :6].abs().clamp_min(1.0)
+    assert err.max().item() <= 1e-4, err.max().item()
+
+
+def _first_difference_is_a_threshold_tie(boxes, levels, keep_ref, keep_hip, thr, eps):
+    """Greedy NMS processes a level's rows in order; the first row where the two keep masks disagree must be a row whose fate hangs on
+    a pair with |IoU - thr| < eps against an earlier kept row (everything after such a flip may cascade)."""
+    from oracle import boxes as OB
+    explained = []
+    for l in torch.unique(levels).tolist():
+        sel = torch.where(levels == l)[0]
+        a, b = keep_ref[sel], keep_hip[sel]
+        if torch.equal(a, b):
+            continue
+        first = int(torch.where(a != b)[0][0])
+        kept_before = sel[:first][a[:first]]
+        iou = OB.iou_matrix(boxes[sel[first]][None].double(), boxes[kept_before].double())[0]
+        gap = (iou - thr).abs().min().item() if iou.numel() else 1.0
+        assert gap < eps, (l, first, gap)
+        explained.append((l, first, gap))
+    return explained
+
+
+def test_nms_keep_mask_on_the_reference_candidates(golden, dev):
+    """The reference's 8 355 candidates (its own fp32 boxes; they cluster, IoUs sit around the 0.3 threshold) through the HIP bitmask
+    NMS: the keep mask must EQUAL batched_nms' (utils.py:215-265).  The only admissible deviation is a decision whose IoU is within
+    1e-5 of the threshold (device sinf / cosf vs the CPU's), and it must be the FIRST difference of its level -- asserted, not
+    assumed, and listed in the failure message."""
+    from nerf_rpn_amd import ops
+    g = golden(NAME)
+    rb, rl = T(g["nms_boxes"], dev), T(g["nms_levels"], dev).to(torch.int32)
+    n = rb.shape[0]
+    keep = ops.nms3d_sorted(rb.contiguous(), rl.contiguous(), 0.3).cpu().bool()
+    ref = torch.zeros(n, dtype=torch.bool)
+    ref[T(g["nms_keep"]).long()] = True
+    assert int(ref.sum()) == g["nms_keep"].shape[0]
+    if not torch.equal(keep, ref):
+        expl = _first_difference_is_a_threshold_tie(T(g["nms_boxes"]), T(g["nms_levels"]).long(), ref, keep, 0.3, 1e-5)
+        pytest.fail(f"keep masks differ at threshold ties only: {expl} -- kept {int(keep.sum())} vs reference {int(ref.sum())}")
+    # final order = score-descending over the kept rows (ties: lower index first)
+    sc = T(g["nms_scores"]).numpy()
+    kept = np.where(keep.numpy())[0]
+    assert np.array_equal(_canonical(kept, sc[kept]), _canonical(np.asarray(g["nms_keep"]).astype(np.int64), sc[np.asarray(g["nms_keep"])]))
+
+
+def test_whole_postprocess_on_the_reference_logits(golden, dev):
+    """logits + deltas of the reference -> top-k -> decode -> filter -> NMS -> top 2500 through RegionProposalNetwork.filter_proposals:
+    every proposal row equals the reference's (boxes 1e-4, scores 1e-6, same level), no allowance."""
+    from test_gpu_e2e import build
+    g = golden(NAME)
+    m = build(True, 160, dev).eval()
+    tab = _table(dev)
+    idx = T(g["topk_idx"], dev).long()
+    deltas = torch.zeros((1, tab.total, 8), dtype=torch.float32, device=dev)
+    deltas[0, idx] = T(g["topk_deltas"], dev)
+    logits = T(g["logits"], dev)[None]
+    with torch.no_grad():
+        boxes, scores, levels = m.rpn.filter_proposals(tab, logits, deltas, [(160, 160, 160)], None)
+    rp, rs, rl = T(g["proposals0"]), T(g["scores0"]), T(g["levels0"])
+    gp, gs, gl = boxes[0].cpu(), scores[0].cpu(), levels[0].cpu()
+    assert gp.shape == rp.shape, (gp.shape, rp.shape)
+    # rows whose scores are exactly tied may swap (B7); compare in the canonical order (score desc, then x centre) inside tie runs
+    def canon(p, s, l):
+        order = np.lexsort((p[:, 0].numpy(), -s.numpy().astype(np.float64)))
+        return p[order], s[order], l[order]
+    gp, gs, gl = canon(gp, gs, gl)
+    rp, rs, rl = canon(rp, rs, rl)
+    assert (gs - rs).abs().max().item() <= 1e-6
+    assert torch.equal(gl.long(), rl.long())
+    err = (gp[:, :6] - rp[:, :6]).abs() / rp[:, :6].abs().clamp_min(1.0)
+    assert err.max().item() <= 1e-4, err.max().item()
