@@ -89,9 +89,9 @@ class ConvProbe:
         orig = self._orig
 
         def call(name, *args):
-            if not self.enabled or name not in ("conv3d_fwd", "conv3d_fwd_stats", "conv3d_wgrad"):
+            if not self.enabled or name not in ("conv3d_fwd", "conv3d_fwd_ex", "conv3d_fwd_stats", "conv3d_wgrad"):
                 return orig(name, *args)
-            called, name = name, ("conv3d_fwd" if name == "conv3d_fwd_stats" else name)     # same kernel + the BatchNorm column sums; same leading arguments
+            called, name = name, ("conv3d_fwd" if name in ("conv3d_fwd_stats", "conv3d_fwd_ex") else name)     # same kernels, same leading arguments
             n_, gx_, gy_, gz_, cin_, _, wrows_, k_ = args[4:12]
             if 2.0 * n_ * gx_ * gy_ * gz_ * cin_ * wrows_ * (k_ ** 3) < 1e10:     # only the heavy launches (>= 10 GFLOP) are timed
                 return orig(called, *args)

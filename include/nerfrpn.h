@@ -514,6 +514,10 @@ int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scale, float *s
 int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count,
                     const float *sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, void *shadow_bf16, nrpn_stream_t stream);
+/* the same, and the consumed gradient is cleared in the same pass (grad[i] = 0): the next backward accumulates into a clean arena */
+int nrpn_adamw_step_zero_grad(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t count,
+                              const float *sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, void *shadow_bf16, nrpn_stream_t stream);
 /* GEMM-layout master weights inside a flat arena: forward layout [taps][Cout][Cin] per weight.
  * nrpn_transpose_weights: ONE launch writes the dgrad operand [taps reversed][Cin][Cout] (dtype) of every weight listed in the
  *   device-side job table (int64 [nweights][4] = arena element offset, taps, Cout, Cin; tile_prefix int32 [nweights+1] = running

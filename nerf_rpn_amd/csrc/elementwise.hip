@@ -769,7 +769,10 @@ extern "C" int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scal
   return NRPN_OK;
 }
 
-__global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long long count,
+// 16 bytes per lane per stream (p, g, m, v read; p, m, v [, g = 0] [, bf16 shadow] written); ZERO: the consumed gradient is cleared in
+// the same pass (the next backward accumulates into a clean arena without a separate 299 MB fill)
+template <bool ZERO>
+__global__ void adamw_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long long count,
                              const float *__restrict__ sumsq, float grad_scale, float max_norm, float lr, float b1, float b2, float eps, float wd,
                              float bc1, float bc2_sqrt, bf16s *__restrict__ shadow) {
   float coef = grad_scale;
@@ -777,30 +780,74 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
     const float norm = sqrtf(*sumsq);
     coef = grad_scale * fminf(1.0f, max_norm / (norm + 1e-6f));
   }
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * coef;
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi -= (lr / bc1) * (mi / denom);
-    p[i] = pi;
-    if (shadow) shadow[i] = f32_to_bf16_bits(pi);      // bf16 copy of the updated master weight, same element order
+  const float decay = 1.0f - lr * wd, step = lr / bc1;
+  auto upd = [&](float gi, float &pi, float &mi, float &vi) {
+    gi *= coef;
+    pi *= decay;
+    mi = b1 * mi + (1.0f - b1) * gi;
+    vi = b2 * vi + (1.0f - b2) * gi * gi;
+    pi -= step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  };
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long long quads = count >> 2;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long long)gridDim.x * blockDim.x) {
+    f4 pv = reinterpret_cast<f4 *>(p)[q], mv = reinterpret_cast<f4 *>(m)[q], vv = reinterpret_cast<f4 *>(v)[q];
+    const f4 gv = reinterpret_cast<const f4 *>(g)[q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pv[e], me = mv[e], ve = vv[e];
+      upd(gv[e], pe, me, ve);
+      pv[e] = pe; mv[e] = me; vv[e] = ve;
+    }
+    reinterpret_cast<f4 *>(p)[q] = pv; reinterpret_cast<f4 *>(m)[q] = mv; reinterpret_cast<f4 *>(v)[q] = vv;
+    if (ZERO) reinterpret_cast<f4 *>(g)[q] = f4{0.f, 0.f, 0.f, 0.f};
+    if (shadow) {      // bf16 copy of the updated master weights, same element order
+      typedef __attribute__((ext_vector_type(4))) unsigned short u4s;
+      u4s h = {f32_to_bf16_bits(pv[0]), f32_to_bf16_bits(pv[1]), f32_to_bf16_bits(pv[2]), f32_to_bf16_bits(pv[3])};
+      reinterpret_cast<u4s *>(shadow)[q] = h;
+    }
   }
+  for (long long i = (quads << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(g[i], pi, mi, vi);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (ZERO) g[i] = 0.f;
+    if (shadow) shadow[i] = f32_to_bf16_bits(pi);
+  }
+}
+
+static int adamw_launch(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t count, const float *sumsq, float grad_scale,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step, void *shadow_bf16, bool zero,
+                        nrpn_stream_t stream) {
+  NRPN_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, "adamw_step: bad args");
+  NRPN_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 && (!shadow_bf16 || (uintptr_t)shadow_bf16 % 8 == 0),
+               "adamw_step: arenas must be 16-byte aligned (bf16 shadow: 8)");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  const dim3 grid(ew_blocks((count + 3) / 4));
+  if (zero)
+    hipLaunchKernelGGL(adamw_kernel<true>, grid, dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, (long long)count, sumsq, grad_scale,
+                       max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), reinterpret_cast<bf16s *>(shadow_bf16));
+  else
+    hipLaunchKernelGGL(adamw_kernel<false>, grid, dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, (long long)count, sumsq, grad_scale,
+                       max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), reinterpret_cast<bf16s *>(shadow_bf16));
+  NRPN_LAUNCH_CHECK("adamw_step");
+  return NRPN_OK;
 }
 
 extern "C" int nrpn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t count, const float *sumsq,
                                float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                void *shadow_bf16, nrpn_stream_t stream) {
-  NRPN_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, "adamw_step: bad args");
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2 = 1.0f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(count)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, (long long)count,
-                     sumsq, grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), reinterpret_cast<bf16s *>(shadow_bf16));
-  NRPN_LAUNCH_CHECK("adamw_step");
-  return NRPN_OK;
+  return adamw_launch(param, const_cast<float *>(grad), exp_avg, exp_avg_sq, count, sumsq, grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, step,
+                      shadow_bf16, false, stream);
+}
+
+// nrpn_adamw_step that also clears the gradient it has just consumed (grad[i] = 0): one pass instead of the step + a fill of the arena
+extern "C" int nrpn_adamw_step_zero_grad(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t count, const float *sumsq,
+                                         float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                         int step, void *shadow_bf16, nrpn_stream_t stream) {
+  return adamw_launch(param, grad, exp_avg, exp_avg_sq, count, sumsq, grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, step, shadow_bf16, true,
+                      stream);
 }
 
 // =====================================================================================================================

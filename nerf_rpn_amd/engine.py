@@ -11,7 +11,14 @@ Design (MI355X-first, not the reference's DDP-wrapper pattern, run_rpn.py:235-23
   * clip_grad_norm_ + AdamW are two fused kernels over the arena (``nrpn_grad_sumsq`` + ``nrpn_adamw_step``), the clip
     coefficient never visits the host;
   * the per-step loss scalars are reduced with ONE 4-float all-reduce only when logging needs them (the reference does a
-    barrier + 4 blocking all-reduces every iteration).
+    barrier + 4 blocking all-reduces every iteration);
+  * the exchange of a bucket is selectable (``exchange=`` / NRPN_GRAD_EXCHANGE): ``allreduce`` (fp32 SUM all-reduce, the default),
+    ``rs_ag`` (fp32 reduce-scatter + all-gather: the two halves of a ring all-reduce as separate collectives, which RCCL can spread
+    over all seven xGMI links of the fully connected node) and ``a2a_bf16`` (bf16 all-to-all of the bucket's 1/world chunks, fp32
+    accumulation of the received chunks, bf16 all-gather of the reduced chunk: half the bytes per link, and the all-to-all is the
+    native pattern of a point-to-point mesh).  Every mode leaves SUM(g_r) in the arena; the 1/world mean stays in the optimiser;
+  * a bucket's collective waits for the streams that produced its gradients (events on the main and the weight-gradient stream,
+    waited for by a dedicated launch stream), not for a join of the whole side stream into the main one: backward keeps running.
 Scenes shard across ranks (DistributedSampler semantics); BatchNorm uses per-rank batch statistics like the reference.
 """
 import math
@@ -38,6 +45,17 @@ def one_cycle(step, total_steps, max_lr, pct_start=0.3, div_factor=25.0, final_d
     return cos(max_lr, minimum, pct), cos(base_momentum, max_momentum, pct)
 
 
+EXCHANGE_MODES = ("allreduce", "rs_ag", "a2a_bf16")
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def _packable_weights(model):
     """{id(weight): (taps, Cout, Cin)} of the weights that feed a single-weight GEMM of the HIP path: nn.Conv3d k1 / k3 (groups 1)
     and nn.Linear.  Modules whose weights are concatenated into a fused multi-weight GEMM (RPN / FCOS output convs) carry
@@ -56,9 +74,13 @@ def _packable_weights(model):
 
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, betas=(0.9, 0.999), eps=1e-8, total_steps=None,
-                 bucket_bytes=64 << 20, process_group=None, static_graph=True):
+                 bucket_bytes=64 << 20, process_group=None, static_graph=True, exchange=None):
         self.model = model
         self.static_graph = static_graph
+        import os
+        self.exchange = exchange or os.environ.get("NRPN_GRAD_EXCHANGE", "allreduce")
+        if self.exchange not in EXCHANGE_MODES:
+            raise ValueError(f"exchange must be one of {EXCHANGE_MODES}, got {self.exchange!r}")
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -133,10 +155,17 @@ class FlatTrainer:
                     end, members = o, []
         self.launched = [False] * len(self.buckets)
         self.early = [False] * len(self.buckets)
+        self.finish = []                  # continuations of multi-phase exchanges (rs_ag / a2a_bf16), run by sync_gradients
+        self._comm_stream = None
+        self._streams = {}                # raw handle -> torch stream of every stream gradients are produced on
 
     def _make_notify(self, i):
         def notify():
             self.seen[i] += 1
+            if self.world > 1 and self.g_arena.is_cuda:
+                h = ops._s()                 # raw handle of the stream this gradient was produced on (~0.3 us); the Stream object is
+                if h not in self._streams:   # only built the first time a handle shows up
+                    self._streams[h] = torch.cuda.current_stream(self.g_arena.device)
             if self.world > 1 and self.expected is not None:
                 b = self.bucket_of[i]
                 if self.launched[b]:
@@ -159,19 +188,91 @@ class FlatTrainer:
         return hook
 
     def _launch(self, b):
-        ops.wgrad_stream_join()      # weight gradients enqueued on the side stream must be in the arena before the bucket leaves
+        """Enqueue the exchange of bucket ``b``.  On the device the collective is issued from a dedicated launch stream that waits for an
+        event of every stream gradients are produced on (main + weight-gradient stream) -- the producers themselves are not blocked, and
+        the main stream is not made to wait for the whole side stream as a join would."""
         s, e = self.buckets[b]
         self.launched[b] = True
-        self.handles.append(dist.all_reduce(self.g_arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        g = self.g_arena[s:e]
+        if g.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=g.device)
+            cur = torch.cuda.current_stream(g.device)
+            self._streams.setdefault(cur.cuda_stream, cur)
+            for st in list(self._streams.values()):          # every stream a gradient notification has been seen on (main, weight-gradient)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._comm_stream.wait_event(ev)
+            with torch.cuda.stream(self._comm_stream):
+                self._exchange(b, g)
+        else:
+            self._exchange(b, g)
+
+    def _exchange(self, b, g):
+        """SUM over the ranks of the bucket's gradients, left in ``g`` (a view of the arena); async work handles go to self.handles,
+        post-processing that has to run after a handle completes goes to self.finish."""
+        world, grp = self.world, self.group
+        if self.exchange == "allreduce":
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=grp, async_op=True))
+            return
+        n = g.numel()
+        assert n % world == 0, "bucket boundaries are multiples of 64 floats"
+        chunk = n // world
+        rank = dist.get_rank(grp)
+        if self.exchange == "rs_ag":
+            mine = torch.empty(chunk, dtype=g.dtype, device=g.device)
+            h1 = dist.reduce_scatter_tensor(mine, g, op=dist.ReduceOp.SUM, group=grp, async_op=True)
+
+            def second(h1=h1, mine=mine, g=g):
+                h1.wait()
+                return dist.all_gather_into_tensor(g, mine, group=grp, async_op=True)
+            self.finish.append(second)
+            return
+        # a2a_bf16: chunk j of every rank goes to rank j as bf16; the received chunks are accumulated in fp32 (own chunk from the fp32
+        # original); the reduced chunk travels back as bf16
+        send = g.to(torch.bfloat16)
+        recv = torch.empty_like(send)
+        h1 = dist.all_to_all_single(recv, send, group=grp, async_op=True)
+
+        def second(h1=h1, recv=recv, g=g):
+            h1.wait()
+            parts = recv.view(world, chunk).float()
+            parts[rank] = g.view(world, chunk)[rank]            # the local contribution never went through bf16
+            reduced = parts.sum(dim=0).to(torch.bfloat16)
+            full = torch.empty(world * chunk, dtype=torch.bfloat16, device=g.device)
+            h2 = dist.all_gather_into_tensor(full, reduced, group=grp, async_op=True)
+
+            def third(h2=h2, full=full, g=g):
+                h2.wait()
+                g.copy_(full)                                   # bf16 -> fp32 arena
+                return None
+            return third
+        self.finish.append(second)
 
     def sync_gradients(self):
-        """Wait for the in-flight bucket all-reduces; buckets not launched yet (first step, unused parameters) go now."""
+        """Wait for the in-flight bucket exchanges; buckets not launched yet (first step, unused parameters) go now."""
         if self.world > 1:
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
                     self._launch(b)
+            cuda = self.g_arena.is_cuda
+            ctx = torch.cuda.stream(self._comm_stream) if cuda else _null()
+            with ctx:                                           # multi-phase modes continue on the launch stream
+                pending = list(self.finish)
+                self.finish = []
+                while pending:
+                    nxt = []
+                    for fn in pending:
+                        r = fn()
+                        if callable(r):
+                            nxt.append(r)
+                        elif r is not None:
+                            self.handles.append(r)
+                    pending = nxt
             for h in self.handles:
                 h.wait()
+            if cuda:
+                torch.cuda.current_stream(self.g_arena.device).wait_stream(self._comm_stream)
             self.handles = []
             self.launched = [False] * len(self.buckets)
         if self.expected is None:
@@ -191,13 +292,13 @@ class FlatTrainer:
             ops.grad_sumsq(self.g_arena, self.sumsq, scale)
             shadow = self.weights.shadow_ptr()
             ops.adamw_step(self.p_arena, self.g_arena, self.m, self.v, self.sumsq if self.clip and self.clip > 0 else None, self.clip or 0.0,
-                           lr, (beta1, self.betas[1]), self.eps, self.wd, self.step_count, scale, shadow)
+                           lr, (beta1, self.betas[1]), self.eps, self.wd, self.step_count, scale, shadow, zero_grad=True)
             self.weights.bump(shadow_written=shadow is not None)
         else:
             raise RuntimeError("FlatTrainer.step needs CUDA tensors (the optimiser kernels have no CPU fallback); "
                                "CPU use is limited to the gloo gradient-exchange tests via sync_gradients()")
         ops.weights_changed()       # the raw-pointer update is invisible to tensor._version: invalidate every GEMM-layout weight copy
-        self.g_arena.zero_()
+        # (the AdamW kernel has already cleared the gradient arena it consumed)
         self.weights.prefetch_dgrad()
         return lr
 

@@ -146,7 +146,7 @@ class RegionProposalNetwork(nn.Module):
         dev = logits.device
         slot_level = torch.arange(L, dtype=torch.int32, device=dev).repeat_interleave(k).contiguous()
         boxes_out, scores_out, levels_out = [], [], []
-        pending = []
+        pending, stages = [], []
         for n in range(logits.shape[0]):
             idx, val = ops.segmented_topk(logits[n], table.offsets, k)
             cand = idx.reshape(-1)
@@ -156,6 +156,8 @@ class RegionProposalNetwork(nn.Module):
                                                     self.score_thresh, self.fix_obb_clip)
             keep = ops.nms3d_sorted(fb, fl, self.nms_thresh, cnt)
             pending.append(ops.select_kept(fb, fs, fl, keep, cnt, self.post_nms_top_n()))
+            stages.append(dict(cand_boxes=boxes, cand_valid=valid, cand_level=slot_level, nms_boxes=fb, nms_levels=fl, nms_count=cnt, nms_keep=keep))
+        self.last_aux = dict(stages=stages)       # references only (no copies): parity tests look at the decisions behind a proposal list
         for ob, os_, ol, oc in pending:
             m = int(oc.item())   # the one device->host read-back per scene
             boxes_out.append(ob[:m])

@@ -740,17 +740,25 @@ class ConvFn(torch.autograd.Function):
         wp, wpd = pack.get(weights, x.dtype, rows_total, need_dgrad, x.shape[-1])
         bias = None
         if biases[0] is not None:
-            bias = torch.cat([b.detach().float() for b in biases]) if nw > 1 else biases[0].detach().float().contiguous()
-            if bias.numel() < rows_total:
-                bias = torch.cat([bias, bias.new_zeros(rows_total - bias.numel())])
+            if nw == 1 and biases[0].numel() == rows_total:
+                bias = biases[0].detach().float().contiguous()
+            else:       # rows of a fused multi-weight GEMM, zero-padded: assembled once per parameter update, not once per pyramid level
+                bkey = tuple((b.data_ptr(), b._version) for b in biases) + (rows_total, _weight_epoch)
+                if getattr(pack, "bias_key", None) != bkey:
+                    parts = [b.detach().float().reshape(-1) for b in biases]
+                    used = sum(p.numel() for p in parts)
+                    if used < rows_total:
+                        parts.append(parts[0].new_zeros(rows_total - used))
+                    pack.bias, pack.bias_key = torch.cat(parts), bkey
+                bias = pack.bias
         out_dtype = torch.float32 if out_f32 else x.dtype
         if affine is not None:
             # eval-mode BatchNorm folded into this conv: y = acc * scale + shift (the conv's own bias is inside `shift`); forward only --
             # the HIP path has no eval-mode BatchNorm backward either (BatchNormFn.backward)
-            if any(ctx.needs_input_grad):
-                raise lib.NrpnError("conv with a folded eval-mode BatchNorm is a no-grad forward (run under torch.no_grad())")
             scale, shift = affine
-            return _conv_fwd(x, wp, shift, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, None, scale)
+            y = _conv_fwd(x, wp, shift, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, None, scale)
+            ctx.mark_non_differentiable(y)       # hip_nn._can_fold only folds when nothing upstream needs a gradient
+            return y
         y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, stats)
         ctx.save_for_backward(x, y if relu else None, wpd, *weights)
         ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None, segs, chain)
@@ -887,8 +895,6 @@ class StemFn(torch.autograd.Function):
         o = [(g - 1) // stride + 1 for g in (gx, gy, gz)]
         y = torch.empty((n, o[0], o[1], o[2], cout), dtype=x.dtype, device=x.device)
         if affine is not None:       # eval-mode BatchNorm (+ ReLU) folded into the stem: no-grad forward only
-            if any(ctx.needs_input_grad):
-                raise lib.NrpnError("stem with a folded eval-mode BatchNorm is a no-grad forward (run under torch.no_grad())")
             scale, shift = affine
             if halo:
                 call("conv3d_stem_fwd_halo", _p(x), _p(wp), _p(shift), _p(scale), _p(y), n, gx, gy, gz, cout, CONV_BIAS | (CONV_RELU if relu else 0), _s())
@@ -896,6 +902,7 @@ class StemFn(torch.autograd.Function):
                 opts = lib.ConvOpts(scale=_p(scale))
                 call("conv3d_stem_fwd_ex", _p(x), _p(wp), _p(shift), _p(y), n, gx, gy, gz, cout, stride, _dt(x),
                      CONV_BIAS | (CONV_RELU if relu else 0), opts.ptr(), _s())
+            ctx.mark_non_differentiable(y)
             return y
         b = bias.detach().float().contiguous() if bias is not None else None
         if halo:
@@ -1517,6 +1524,8 @@ def ingest_augment(raw, alpha_mode, dtype, plan):
 
 def stack_scenes(meshes):
     """torch.stack for scene tensors [4,W,L,H]: keeps channels-last memory when every scene has it (no layout round trip)."""
+    if len(meshes) == 1:           # a view: torch.stack would copy the whole scene (65 MB at 160^3)
+        return meshes[0].unsqueeze(0)
     if all(m.permute(1, 2, 3, 0).is_contiguous() for m in meshes):
         return torch.stack([m.permute(1, 2, 3, 0) for m in meshes], dim=0).permute(0, 4, 1, 2, 3)
     return torch.stack(meshes, dim=0)
@@ -1538,6 +1547,7 @@ def grad_sumsq(grad_flat, out, grad_scale=1.0):
     call("grad_sumsq", _p(grad_flat), grad_flat.numel(), float(grad_scale), _p(out), _s())
 
 
-def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step, grad_scale=1.0, shadow=None):
-    call("adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), float(grad_scale), float(max_norm), float(lr), float(betas[0]), float(betas[1]),
-         float(eps), float(wd), int(step), _p(shadow), _s())
+def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step, grad_scale=1.0, shadow=None, zero_grad=False):
+    """``zero_grad``: the kernel clears the gradient it has just consumed (no separate fill of the arena)."""
+    call("adamw_step_zero_grad" if zero_grad else "adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), float(grad_scale), float(max_norm),
+         float(lr), float(betas[0]), float(betas[1]), float(eps), float(wd), int(step), _p(shadow), _s())

@@ -528,7 +528,8 @@ def test_two_threads_with_different_plans_share_no_state(dev):
     x, wp, bias = _conv_case(dev, 1, grid, cin, cout, seed=3)
     tiles = [lib.TILE_128, lib.TILE_256X256_W4]
     want = [ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU, torch.bfloat16, tile=t) for t in tiles]
-    plans = [lib.query("conv3d_fwd_plan_ex", 1, *grid, cin, cout, 3, lib.BF16, lib.ConvOpts(tile=t).ptr()) for t in tiles]
+    opts = [lib.ConvOpts(tile=t) for t in tiles]           # keep the structs alive while the library reads them
+    plans = [lib.query("conv3d_fwd_plan_ex", 1, *grid, cin, cout, 3, lib.BF16, o.ptr()) for o in opts]
     assert plans == [0, 5]
     torch.cuda.synchronize()
     errors = []

@@ -48,10 +48,56 @@ def test_eval_matches_reference(name, golden, dev):
     with torch.no_grad():
         (feats, props, lvls), losses, scores = m(xs)
     assert losses == {}
-    assert_eval_matches(name, g, feats, props, lvls, scores, len(xs), dev)
+    size = tuple(max(int(x.shape[d]) for x in xs) for d in (1, 2, 3))        # batched scenes are padded to the per-axis maximum
+    assert_eval_matches(name, g, feats, props, lvls, scores, len(xs), dev, m.rpn.last_aux, [size] * len(xs))
 
 
-def assert_eval_matches(name, g, feats, props, lvls, scores, nscenes, dev):
+def _explain_unmatched(name, scene, rp, rs, rl, gp, gs, gl, bad, aux, mesh_size, rotated, nms_thr=0.3):
+    """Every reference row without an exact partner must be accounted for by one of the three documented mechanisms, detected in the
+    HIP path's OWN stage tensors (RegionProposalNetwork.last_aux) -- no blanket percentage:
+      B3   quirk B3 (reference utils.py:359-367 vs rpn.py:348-351): an OBB whose centre lies within the box tolerance of a grid face is dropped
+           on one side and kept on the other; the reference drops boxes WITHOUT their scores, so from that candidate on every box of the
+           level is paired with its neighbour's score.  Accepted: the row's box (and level) has a partner, only the score is a
+           neighbour's.  Requires such a boundary candidate to exist in that level.
+      NMS  a suppression decision whose IoU is within 1e-4 of the threshold (features differ by ~1e-5 from the CPU's): the row has no
+           partner at all, but overlaps a kept HIP proposal of its level at |IoU - thr| < 1e-4 -- or is downstream of one: a flipped keep
+           changes which later boxes of the level survive, so once a level has a threshold event its later rows are accepted.
+    Returns the enumerated list [(row, mechanism)]; raises on any row that none of them explains."""
+    from oracle import boxes as OB
+    st = aux["stages"][scene]
+    cb, cv, cl = st["cand_boxes"].cpu(), st["cand_valid"].cpu().bool(), st["cand_level"].cpu().long()
+    size = torch.tensor([float(v) for v in mesh_size])
+    b3_levels = set()
+    if rotated:
+        c = cb[:, :3]
+        slack = 2e-3 + 1e-4 * size                      # the box tolerance of this test: a centre this close to a face can fall on either side
+        near = ((c.abs() < slack) | ((c - size).abs() < slack)).any(dim=1) & cv
+        b3_levels = set(cl[near].tolist())
+    tol = 2e-3 + 1e-4 * rp.abs()
+    out, nms_levels = [], set()
+    iou_fn = OB.iou_matrix if rotated else OB.aabb_iou_matrix
+    for b in bad.tolist():
+        lvl = int(rl[b])
+        same = gl.long() == lvl
+        boxok = same & ((gp - rp[b]).abs() <= tol[b]).all(dim=1)
+        if lvl in b3_levels and boxok.any():
+            out.append((b, "B3"))
+            continue
+        cand = torch.where(same)[0]
+        if cand.numel():
+            iou = iou_fn(rp[b][None].double(), gp[cand].double())[0]
+            if ((iou - nms_thr).abs() < 1e-4).any():
+                nms_levels.add(lvl)
+                out.append((b, "NMS"))
+                continue
+        if lvl in nms_levels or lvl in b3_levels:
+            out.append((b, "downstream"))
+            continue
+        raise AssertionError((name, scene, "unexplained proposal row", b, rp[b].tolist(), float(rs[b]), lvl))
+    return out
+
+
+def assert_eval_matches(name, g, feats, props, lvls, scores, nscenes, dev, aux=None, mesh_sizes=None):
     """Features / proposals / scores / levels of an eval forward against a golden fixture captured from the reference."""
     xs = range(nscenes)
     for i, f in enumerate(feats):
@@ -68,22 +114,24 @@ def assert_eval_matches(name, g, feats, props, lvls, scores, nscenes, dev):
         if nscenes > 1:
             gp, gl, gs = gp[gs > 0], gl[gs > 0], gs[gs > 0]
             rp, rl, rs = rp[rs > 0], rl[rs > 0], rs[rs > 0]
-        assert abs(gp.shape[0] - rp.shape[0]) <= max(2, rp.shape[0] // 100), (name, gp.shape, rp.shape)
         # rows are ordered by score; two proposals whose scores differ by < 2e-6 may legitimately swap (GPU expf/sigmoid
         # differ from the CPU's in the last ulp), so each reference row is matched to the best row among its score-ties.
         near = (gs[None, :] - rs[:, None]).abs() <= 2e-6
         diff = (gp[None, :, :] - rp[:, None, :]).abs()
         tol = 2e-3 + 1e-4 * rp.abs()[:, None, :]
         ok = ((diff <= tol).all(dim=2) & near & (gl[None, :] == rl[:, None])).any(dim=1)
-        # An OBB whose centre sits on the grid boundary can be dropped on one side and kept on the other; with the
-        # reference's box/score misalignment (quirk B3) that shifts the pairing of the following rows, and an IoU within
-        # 1e-6 of the NMS threshold can flip one decision: allow 1.5 % of the rows to differ.
-        if (~ok).sum() > max(2, int(0.015 * rp.shape[0])):
-            bad = torch.where(~ok)[0]
-            j = diff[bad].amax(dim=2).argmin(dim=1)
-            msg = [(int(b), rp[b].tolist(), float(rs[b]), float(rl[b]), int(jj), gp[jj].tolist(), float(gs[jj]), float(gl[jj]))
-                   for b, jj in zip(bad[:4], j[:4])]
-            raise AssertionError((name, int((~ok).sum()), msg))
+        bad = torch.where(~ok)[0]
+        if bad.numel() == 0:
+            assert gp.shape[0] == rp.shape[0], (name, gp.shape, rp.shape)
+            continue
+        if aux is None:
+            raise AssertionError((name, i, "rows without a partner and no stage tensors to explain them", bad[:8].tolist()))
+        rotated = rp.shape[1] == 7
+        expl = _explain_unmatched(name, i, rp, rs, rl, gp, gs, gl, bad, aux, mesh_sizes[i], rotated)
+        kinds = {k: sum(1 for _, m in expl if m == k) for k in ("B3", "NMS", "downstream")}
+        print(f"[explained] {name}[{i}]: {len(expl)} of {rp.shape[0]} rows: {kinds}")
+        # a level hit by one of the mechanisms can lose / gain a few rows at the post-NMS cut
+        assert abs(gp.shape[0] - rp.shape[0]) <= len(expl), (name, gp.shape, rp.shape)
 
 
 @pytest.mark.parametrize("name", ["train_aabb", "train_obb", "train_obb_iou", "train_obb_giou", "train_obb_diou", "train_aabb_batch2",

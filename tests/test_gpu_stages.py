@@ -160,13 +160,20 @@ def test_whole_postprocess_on_the_reference_logits(golden, dev):
     rp, rs, rl = T(g["proposals0"]), T(g["scores0"]), T(g["levels0"])
     gp, gs, gl = boxes[0].cpu(), scores[0].cpu(), levels[0].cpu()
     assert gp.shape == rp.shape, (gp.shape, rp.shape)
-    # rows whose scores are exactly tied may swap (B7); compare in the canonical order (score desc, then x centre) inside tie runs
-    def canon(p, s, l):
-        order = np.lexsort((p[:, 0].numpy(), -s.numpy().astype(np.float64)))
-        return p[order], s[order], l[order]
-    gp, gs, gl = canon(gp, gs, gl)
-    rp, rs, rl = canon(rp, rs, rl)
-    assert (gs - rs).abs().max().item() <= 1e-6
-    assert torch.equal(gl.long(), rl.long())
-    err = (gp[:, :6] - rp[:, :6]).abs() / rp[:, :6].abs().clamp_min(1.0)
-    assert err.max().item() <= 1e-4, err.max().item()
+    # Order-insensitive inside runs of equal scores (fp32 sigmoid saturates: exact ties, whose order torch leaves open, quirk B7): every
+    # reference row must have its own HIP row with the same level, a score within 1e-6 and a box within 1e-4 -- a one-to-one matching
+    assert (gs.sort(descending=True).values - rs.sort(descending=True).values).abs().max().item() <= 1e-6
+    used = torch.zeros(gp.shape[0], dtype=torch.bool)
+    unmatched = []
+    for i in range(rp.shape[0]):
+        cand = torch.where(((gs - rs[i]).abs() <= 1e-6) & (gl.long() == int(rl[i])) & ~used)[0]
+        if cand.numel():
+            d = (gp[cand][:, :6] - rp[i, :6]).abs() / rp[i, :6].abs().clamp_min(1.0)
+            dth = (gp[cand][:, 6] - rp[i, 6]).abs()
+            dth = torch.minimum(dth, (dth - 3.141592).abs())
+            ok = (d.max(dim=1).values <= 1e-4) & (dth <= 1e-4)
+            if ok.any():
+                used[cand[torch.where(ok)[0][0]]] = True
+                continue
+        unmatched.append(i)
+    assert not unmatched, (len(unmatched), unmatched[:10])
