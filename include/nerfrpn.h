@@ -66,6 +66,16 @@ int nrpn_rotated_iou_loss_f32(const float *pred, const float *target, int64_t n,
  *   max_mesh_dim over 2 extreme points x 4 views x (u,v).  One workgroup, fixed summation order. */
 int nrpn_projection_loss_f32(const float *pred, const float *target, int64_t n, int box_dim, const float *views, const float *intrinsics,
                              float beta, float max_mesh_dim, float *out, nrpn_stream_t stream);
+/* Proposal metrics on the device (eval.py:14-81, 319-395).  [a25 / f1]
+ * nrpn_recall_match_f32: the greedy GT <-> proposal matching of evaluate_box_proposals_recall on one scene's IoU matrix
+ *   overlaps [P][G] (MODIFIED in place: retired rows / columns become -1) -> covered[j] = overlap recorded in round j, j < min(P, G);
+ *   ties resolve to the first maximum (torch.max), G <= 1024.
+ * nrpn_ap_mark: VOC-AP bookkeeping over ALL detections of the evaluation set: order [n] = detection indices in descending score order,
+ *   best_iou [n] / key [n] = each detection's best IoU and (scene, GT) key in [0, num_keys); tp[r] = 1 iff detection order[r] has
+ *   best_iou > iou_thresh and is the highest-ranked such detection of its key (eval.py:352-371).  first_ws: int32 [num_keys] scratch. */
+int nrpn_recall_match_f32(float *overlaps, int num_proposals, int num_gt, float *covered, nrpn_stream_t stream);
+int nrpn_ap_mark(const int64_t *order, const float *best_iou, const int64_t *key, int64_t n, int64_t num_keys, float iou_thresh,
+                 int32_t *first_ws, uint8_t *tp, nrpn_stream_t stream);
 /* all pairs: a [n,w], b [m,w] -> iou [n,m]; w = 6 (AABB x1..z2) or 7 (OBB)   (box_iou_3d, model/utils.py:387-458) */
 int nrpn_iou3d_matrix_f32(const float *a, const float *b, float *iou, int64_t n, int64_t m, int box_dim,
                           nrpn_stream_t stream);

@@ -1105,3 +1105,98 @@ extern "C" int nrpn_rpn_sampled_loss_f32(const float *logits, const float *delta
   NRPN_LAUNCH_CHECK("sampled_loss");
   return NRPN_OK;
 }
+
+// =====================================================================================================================
+// Proposal metrics on the device (reference eval.py:14-81 recall, 319-395 VOC AP)  [a25 / f1]
+// =====================================================================================================================
+// Greedy GT <-> proposal matching of evaluate_box_proposals_recall: min(P, G) rounds of "take the GT whose best remaining proposal
+// overlaps most, record that overlap, retire both".  One workgroup per scene; per-GT (max, arg-max) live in LDS and only the columns
+// whose arg-max row has just been retired are rescanned.  torch.max semantics on ties: the FIRST (lowest-index) maximum, for rows and
+// for GTs -- a GT that overlaps nothing still retires proposal 0 (or the first remaining one), exactly as the reference does.
+constexpr int kRecallMaxGt = 1024;
+__global__ void __launch_bounds__(256) recall_match_kernel(float *__restrict__ ov, int P, int G, float *__restrict__ covered) {
+  __shared__ float cmax[kRecallMaxGt];
+  __shared__ int carg[kRecallMaxGt];
+  __shared__ int pick[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto scan_col = [&](int g) {        // one wave: (max, lowest arg-max) of column g over the rows
+    float best = -3.0e38f;
+    int arg = 0x7fffffff;
+    for (int r = lane; r < P; r += 64) {
+      const float v = ov[(long long)r * G + g];
+      if (v > best) { best = v; arg = r; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off, 64);
+      const int oa = __shfl_xor(arg, off, 64);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) { cmax[g] = best; carg[g] = arg; }
+  };
+  for (int g = wave; g < G; g += 4) scan_col(g);
+  __syncthreads();
+  const int rounds = min(P, G);
+  for (int j = 0; j < rounds; ++j) {
+    if (wave == 0) {                  // first GT attaining the largest column maximum
+      float best = -3.0e38f;
+      int arg = 0x7fffffff;
+      for (int g = lane; g < G; g += 64)
+        if (cmax[g] > best) { best = cmax[g]; arg = g; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oa = __shfl_xor(arg, off, 64);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+      }
+      if (lane == 0) { pick[0] = arg; pick[1] = carg[arg]; covered[j] = best; }
+    }
+    __syncthreads();
+    const int gi = pick[0], bi = pick[1];
+    for (int g = tid; g < G; g += 256) ov[(long long)bi * G + g] = -1.f;     // retire the proposal ...
+    for (int r = tid; r < P; r += 256) ov[(long long)r * G + gi] = -1.f;     // ... and the ground-truth box
+    __syncthreads();
+    for (int g = wave; g < G; g += 4)
+      if (g == gi || carg[g] == bi) scan_col(g);                              // only these columns changed their maximum
+    __syncthreads();
+  }
+}
+
+extern "C" int nrpn_recall_match_f32(float *overlaps, int num_proposals, int num_gt, float *covered, nrpn_stream_t stream) {
+  NRPN_REQUIRE(overlaps && covered && num_proposals > 0 && num_gt > 0, "recall_match: bad args");
+  NRPN_REQUIRE(num_gt <= kRecallMaxGt, "recall_match: at most %d ground-truth boxes per scene (got %d)", kRecallMaxGt, num_gt);
+  hipLaunchKernelGGL(recall_match_kernel, dim3(1), dim3(256), 0, as_stream(stream), overlaps, num_proposals, num_gt, covered);
+  NRPN_LAUNCH_CHECK("recall_match");
+  return NRPN_OK;
+}
+
+// VOC AP bookkeeping: detection `order[r]` (rank r in the global score order) is a true positive iff its best IoU exceeds the threshold
+// and no higher-ranked detection claimed the same (scene, GT) key -- i.e. it holds the MINIMUM rank among the qualifying detections of its
+// key.  Pass 1: integer atomicMin of the rank into first[key] (associative: deterministic); pass 2: compare.  first[] must be
+// pre-filled with INT_MAX by the caller (ap_mark does it).
+__global__ void ap_first_kernel(const int64_t *__restrict__ order, const float *__restrict__ best_iou, const int64_t *__restrict__ key, int64_t n,
+                                float thr, int *__restrict__ first) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const long long d = order[r];
+  if (best_iou[d] > thr) atomicMin(first + key[d], (int)r);
+}
+__global__ void ap_tp_kernel(const int64_t *__restrict__ order, const float *__restrict__ best_iou, const int64_t *__restrict__ key, int64_t n,
+                             float thr, const int *__restrict__ first, uint8_t *__restrict__ tp) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const long long d = order[r];
+  tp[r] = (best_iou[d] > thr && first[key[d]] == (int)r) ? 1 : 0;
+}
+
+extern "C" int nrpn_ap_mark(const int64_t *order, const float *best_iou, const int64_t *key, int64_t n, int64_t num_keys, float iou_thresh,
+                            int32_t *first_ws, uint8_t *tp, nrpn_stream_t stream) {
+  NRPN_REQUIRE(order && best_iou && key && first_ws && tp && n > 0 && num_keys > 0 && n < (1ll << 31), "ap_mark: bad args");
+  hipStream_t st = as_stream(stream);
+  NRPN_HIP(hipMemsetAsync(first_ws, 0x7f, (size_t)num_keys * 4, st));       // 0x7f7f7f7f > any rank
+  const dim3 grid((unsigned)cdiv64(n, 256));
+  hipLaunchKernelGGL(ap_first_kernel, grid, dim3(256), 0, st, order, best_iou, key, n, iou_thresh, first_ws);
+  hipLaunchKernelGGL(ap_tp_kernel, grid, dim3(256), 0, st, order, best_iou, key, n, iou_thresh, first_ws, tp);
+  NRPN_LAUNCH_CHECK("ap_mark");
+  return NRPN_OK;
+}

@@ -157,6 +157,7 @@ class FlatTrainer:
         self.early = [False] * len(self.buckets)
         self.finish = []                  # continuations of multi-phase exchanges (rs_ag / a2a_bf16), run by sync_gradients
         self._comm_stream = None
+        self.exchange_events = None       # set to [] to collect (start, end) events around the exchange wait of every step
         self._streams = {}                # raw handle -> torch stream of every stream gradients are produced on
 
     def _make_notify(self, i):
@@ -282,7 +283,14 @@ class FlatTrainer:
 
     def step(self):
         ops.wgrad_stream_join()
-        self.sync_gradients()
+        if self.exchange_events is not None and self.g_arena.is_cuda:      # bench: how long the main stream waits for the exchange after
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # backward has been enqueued in full
+            a.record()
+            self.sync_gradients()
+            b.record()
+            self.exchange_events.append((a, b))
+        else:
+            self.sync_gradients()
         lr, beta1 = self.lr, self.betas[0]
         if self.total_steps:
             lr, beta1 = one_cycle(self.step_count, self.total_steps, self.lr)

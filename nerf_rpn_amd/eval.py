@@ -1,40 +1,53 @@
-"""Proposal metrics with the reference's function names and return dicts (reference nerf_rpn/eval.py:14-81, 319-395).
+"""Proposal metrics with the reference's function names and return dicts (reference nerf_rpn/eval.py:14-81, 319-395), on the device:
 
-The IoU matrices (the expensive part: rotated IoU of up to 2500 proposals x G boxes per scene) come from one fused HIP kernel
-launch per scene (``ops.iou3d_matrix``); the greedy matching that follows is index bookkeeping on the small host copy."""
+  recall : one fused IoU-matrix launch per scene (``ops.iou3d_matrix``) + one launch of the greedy GT <-> proposal matching
+           (``nrpn_recall_match_f32``: per-GT maxima in LDS, min(P, G) rounds) -- the reference runs min(P, G) rounds of two full
+           matrix reductions in Python per scene;
+  AP     : IoU matrices and per-detection best GT per scene, ONE global sort of all detections, and the "first detection that claims a
+           ground-truth box is the true positive" rule as two integer-atomic launches (``nrpn_ap_mark``) instead of a Python loop over every
+           detection with one rotated-IoU call each; cumulative sums and the precision envelope are device scans.
+Inputs may live on the host or the device; results come back as host tensors, as the reference returns them."""
 import torch
 
 from . import ops
+from .lib import call
 
 
-def _iou(proposals, gt):
-    dev = proposals.device if proposals.is_cuda else (gt.device if gt.is_cuda else torch.device("cuda"))
-    return ops.iou3d_matrix(proposals.to(dev).float(), gt.to(dev).float()).cpu()
+def _dev(*ts):
+    for t in ts:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _iou(proposals, gt, dev):
+    return ops.iou3d_matrix(proposals.to(dev).float(), gt.to(dev).float())
+
+
+def recall_match(overlaps):
+    """overlaps [P, G] (device, consumed) -> covered [min(P, G)]: the overlaps recorded by the reference's greedy matching (eval.py:41-61)."""
+    p, g = overlaps.shape
+    covered = torch.zeros(g, dtype=torch.float32, device=overlaps.device)
+    if p and g:
+        ov = overlaps.contiguous()
+        call("recall_match_f32", ov.data_ptr(), p, g, covered.data_ptr(), ops._s())
+    return covered
 
 
 def evaluate_box_proposals_recall(proposals_list, proposal_scores_list, gt_boxes_list, thresholds=None, limit=None):
     gt_overlaps = []
     num_pos = 0
     for proposals, scores, gt_boxes in zip(proposals_list, proposal_scores_list, gt_boxes_list):
-        order = torch.argsort(scores, descending=True)
-        proposals = proposals[order]
         if proposals.shape[0] == 0 or gt_boxes.shape[0] == 0:
             continue
+        dev = _dev(proposals, gt_boxes)
+        order = torch.argsort(scores.to(dev), descending=True, stable=True)
+        proposals = proposals.to(dev)[order]
         num_pos += gt_boxes.shape[0]
         if limit is not None and len(proposals) > limit:
             proposals = proposals[:limit]
-        overlaps = _iou(proposals, gt_boxes)
-        covered = torch.zeros(gt_boxes.shape[0])
-        for j in range(min(proposals.shape[0], gt_boxes.shape[0])):
-            best_per_gt, arg_per_gt = overlaps.max(dim=0)
-            gt_ovr, gt_ind = best_per_gt.max(dim=0)
-            assert gt_ovr >= 0
-            box_ind = arg_per_gt[gt_ind]
-            covered[j] = overlaps[box_ind, gt_ind]
-            overlaps[box_ind, :] = -1
-            overlaps[:, gt_ind] = -1
-        gt_overlaps.append(covered)
-    gt_overlaps = torch.cat(gt_overlaps, dim=0) if gt_overlaps else torch.zeros(0, dtype=torch.float32)
+        gt_overlaps.append(recall_match(_iou(proposals, gt_boxes, dev)))
+    gt_overlaps = torch.cat(gt_overlaps, dim=0).cpu() if gt_overlaps else torch.zeros(0, dtype=torch.float32)
     gt_overlaps, _ = torch.sort(gt_overlaps)
     if thresholds is None:
         thresholds = torch.arange(0.5, 0.95 + 1e-5, 0.05, dtype=torch.float32)
@@ -47,41 +60,40 @@ def evaluate_box_proposals_recall(proposals_list, proposal_scores_list, gt_boxes
 def evaluate_box_proposals_ap(proposals_list, proposal_scores_list, gt_boxes_list, iou_thresh=0.25, top_k=None):
     """Pascal-VOC AP at one IoU threshold (eval.py:319-395)."""
     num_gt = 0
-    scene_ids, scores_all, best_iou, best_gt = [], [], [], []
+    dev = _dev(*proposals_list, *gt_boxes_list)
+    gmax = max([int(g.shape[0]) for g in gt_boxes_list] + [1])
+    scores_all, best_iou, keys = [], [], []
     for i, (proposals, scores, gt_boxes) in enumerate(zip(proposals_list, proposal_scores_list, gt_boxes_list)):
+        proposals, scores = proposals.to(dev), scores.to(dev)
         if top_k is not None and len(proposals) > top_k:
-            ids = torch.argsort(scores, descending=True)[:top_k]
+            ids = torch.argsort(scores, descending=True, stable=True)[:top_k]
             proposals, scores = proposals[ids], scores[ids]
         num_gt += gt_boxes.shape[0]
         if len(proposals) == 0:
             continue
-        ov = _iou(proposals, gt_boxes)                      # one launch per scene instead of one per detection
-        m, a = ov.max(dim=1)
-        scene_ids.append(torch.full((len(proposals),), i, dtype=torch.int64))
-        scores_all.append(scores.cpu())
-        best_iou.append(m)
-        best_gt.append(a)
-    scene_ids, scores_all = torch.cat(scene_ids), torch.cat(scores_all)
-    best_iou, best_gt = torch.cat(best_iou), torch.cat(best_gt)
-    order = torch.argsort(scores_all, descending=True)
-    scene_ids, best_iou, best_gt = scene_ids[order], best_iou[order], best_gt[order]
-    used = [torch.zeros(len(g), dtype=torch.bool) for g in gt_boxes_list]
-    tp = torch.zeros(len(order), dtype=torch.bool)
-    fp = torch.zeros(len(order), dtype=torch.bool)
-    for i in range(len(order)):
-        s, g = int(scene_ids[i]), int(best_gt[i])
-        if best_iou[i] > iou_thresh and not used[s][g]:
-            tp[i] = True
-            used[s][g] = True
+        if gt_boxes.shape[0] == 0:      # every detection of a scene without ground truth is a false positive
+            m = torch.full((len(proposals),), -1.0, device=dev)
+            a = torch.zeros(len(proposals), dtype=torch.int64, device=dev)
         else:
-            fp[i] = True
-    tp, fp = torch.cumsum(tp, dim=0), torch.cumsum(fp, dim=0)
+            m, a = _iou(proposals, gt_boxes, dev).max(dim=1)        # one launch per scene instead of one per detection
+        scores_all.append(scores.float())
+        best_iou.append(m)
+        keys.append(a + i * gmax)
+    scores_all, best_iou, keys = torch.cat(scores_all), torch.cat(best_iou).contiguous(), torch.cat(keys).contiguous()
+    n = scores_all.numel()
+    order = torch.argsort(scores_all, descending=True, stable=True).contiguous()
+    first = torch.empty(len(gt_boxes_list) * gmax, dtype=torch.int32, device=dev)
+    tpm = torch.empty(n, dtype=torch.uint8, device=dev)
+    call("ap_mark", order.data_ptr(), best_iou.data_ptr(), keys.data_ptr(), n, first.numel(), float(iou_thresh), first.data_ptr(), tpm.data_ptr(),
+         ops._s())
+    tp = torch.cumsum(tpm.long(), dim=0)
+    fp = torch.cumsum(1 - tpm.long(), dim=0)
     recalls = tp / num_gt
     precisions = tp / (tp + fp)
-    mrec = torch.cat((torch.tensor([0.0]), recalls, torch.tensor([1.0])))
-    mpre = torch.cat((torch.tensor([0.0]), precisions, torch.tensor([0.0])))
-    for i in range(mpre.size(0) - 1, 0, -1):
-        mpre[i - 1] = torch.max(mpre[i - 1], mpre[i])
+    zero, one = recalls.new_zeros(1), recalls.new_ones(1)
+    mrec = torch.cat((zero, recalls, one))
+    mpre = torch.cat((zero, precisions, zero))
+    mpre = torch.flip(torch.cummax(torch.flip(mpre, (0,)), dim=0).values, (0,))       # precision envelope (eval.py:386-388)
     idx = torch.where(mrec[1:] != mrec[:-1])[0]
     ap = torch.sum((mrec[idx + 1] - mrec[idx]) * mpre[idx + 1])
-    return {"ap": ap, "precisions": precisions, "recalls": recalls, "thresholds": iou_thresh, "num_det": tp + fp}
+    return {"ap": ap.cpu(), "precisions": precisions.cpu(), "recalls": recalls.cpu(), "thresholds": iou_thresh, "num_det": (tp + fp).cpu()}

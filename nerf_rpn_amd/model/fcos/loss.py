@@ -106,6 +106,17 @@ class FCOSLossComputation(object):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         return tensor
 
+    def normalisers(self, num_pos, ctr_sum):
+        """(positives per rank averaged over the ranks, clamped at 1; centerness-target sum averaged over the ranks) -- the two scalars the
+        data-parallel FCOS loss exchanges per step (reference fcos/loss.py:533-550).  ``ctr_sum`` None = this rank has no positive location:
+        it still takes part in the second reduction (the reference's dummy reduce, loss.py:588), otherwise the other ranks would hang."""
+        n = float(self.world_size)
+        num_pos_avg = max(self.reduce_sum(num_pos.to(torch.int64).reshape(1)).item() / n, 1.0)
+        if ctr_sum is None:
+            ctr_sum = torch.zeros((), dtype=torch.float32, device=num_pos.device)
+        norm = self.reduce_sum(ctr_sum.detach().float().reshape(1)).item() / n
+        return num_pos_avg, norm
+
     def prepare_targets(self, geom, targets, pad_sizes, device):
         """labels int8 [total] {1, 0, -1 = padding}, reg_targets [total, 6|8] (stride-normalised), num_pos int32 [1]."""
         return ops.fcos_targets(geom, [t.float() for t in targets], pad_sizes, self.center_sampling_radius, self.norm_reg_targets,
@@ -135,16 +146,12 @@ class FCOSLossComputation(object):
         labels, reg_targets, num_pos = self.prepare_targets(geom, targets, pad_sizes, logits.device)
         pos_inds = torch.nonzero(labels > 0).squeeze(1)
         reg_p, rt_p, ctr_p = reg[pos_inds], reg_targets[pos_inds], ctr[pos_inds]
-        num_gpus = self.world_size
-        total_num_pos = self.reduce_sum(num_pos.to(torch.int64)).item()
-        num_pos_avg = max(total_num_pos / float(num_gpus), 1.0)
+        ctr_t = self.compute_centerness_targets(rt_p) if pos_inds.numel() else None
+        num_pos_avg, norm = self.normalisers(num_pos, ctr_t.sum() if ctr_t is not None else None)
         cls_loss = ops.FocalLossFn.apply(logits, labels, 0.25) / num_pos_avg
         self.last_aux = {"labels": labels, "reg_targets": reg_targets, "pos": pos_inds}
         if pos_inds.numel() == 0:
-            self.reduce_sum(ctr_p.new_tensor([0.0]))
             return cls_loss, reg_p.sum(), ctr_p.sum()
-        ctr_t = self.compute_centerness_targets(rt_p)
-        norm = self.reduce_sum(ctr_t.sum()).item() / float(num_gpus)
         if self.iou_loss_type != "smooth_l1":
             reg_loss = self.box_reg_loss_func(reg_p, rt_p, ctr_t) / norm
         else:

@@ -192,3 +192,30 @@ def test_one_cycle_matches_torch():
         opt.step()
         if step < 49:
             sched.step()
+
+
+def _fcos_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if os.path.exists("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_rpn_amd.model.fcos.loss import FCOSLossComputation
+    ev = FCOSLossComputation.__new__(FCOSLossComputation)         # the reductions only: the rest of the loss runs on HIP kernels
+    ev.world_size = world
+    out = []
+    # step 1: rank 0 has 3 positives (centerness sum 1.5), rank 1 none; step 2: 4 and 6 positives; step 3: nobody has any
+    for num_pos, ctr in (((3, 1.5), (0, None)), ((4, 2.0), (6, 1.0)), ((0, None), (0, None))):
+        n, c = (num_pos, ctr)[rank]
+        out.append(ev.normalisers(torch.tensor([n], dtype=torch.int32), None if c is None else torch.tensor(c)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fcos_loss_normalisers_across_ranks():
+    """num_pos / centerness-sum exchange of the data-parallel FCOS loss (reference fcos/loss.py:533-550, 588): both ranks get the same two
+    scalars, a rank without positives still joins the second reduction (no hang), and all-empty steps clamp to 1 / 0."""
+    res = _run_ranks(_fcos_worker, ())
+    (_, a), (_, b) = res
+    assert a == b
+    assert a[0] == (1.5, 0.75) and a[1] == (5.0, 1.5) and a[2] == (1.0, 0.0)

@@ -28,6 +28,56 @@ def test_metrics_match_reference(golden, dev):
         assert abs(evaluate_box_proposals_ap(P, S, G, iou_thresh=0.25, top_k=50)["ap"].item() - float(g[f"{tag}_ap25"])) < 1e-6
 
 
+def test_device_metrics_on_proposal_sized_sets_match_the_oracle(dev):
+    """recall matching (nrpn_recall_match_f32) and AP marking (nrpn_ap_mark) at the sizes the evaluation runs at -- 2500 proposals per
+    scene, ground-truth boxes that overlap nothing (their column is all zeros: torch.max's first-index tie rule decides which proposal
+    they retire), duplicated detections of one GT, a scene without proposals and one without ground truth -- against the CPU oracle
+    (oracle/metrics.py, pinned to the reference by metrics.npz): recall counts exact, AP 1e-6."""
+    from nerf_rpn_amd.eval import evaluate_box_proposals_ap, evaluate_box_proposals_recall
+    from oracle import metrics as OM
+    g = torch.Generator().manual_seed(17)
+
+    def boxes(n, lo, hi, smin, smax, rot):
+        c = torch.rand(n, 3, generator=g) * (hi - lo) + lo
+        s = torch.rand(n, 3, generator=g) * (smax - smin) + smin
+        if rot:
+            return torch.cat([c, s, (torch.rand(n, 1, generator=g) - 0.5) * 3.1], dim=1)
+        return torch.cat([c - s / 2, c + s / 2], dim=1)
+    for rot in (True, False):
+        P, S, G = [], [], []
+        for sc, (n, ngt) in enumerate(((2500, 40), (1200, 7), (0, 5), (300, 0), (2500, 90))):
+            gt = boxes(ngt, 20, 140, 8, 40, rot)
+            parts = [boxes(max(n - 6 * min(ngt, 30), 0), 0, 160, 4, 30, rot)]
+            if ngt and n:
+                near = gt[:min(ngt, 30)].repeat_interleave(6, dim=0).clone()
+                near[:, :3] += torch.randn(near.shape[0], 3, generator=g) * 1.5
+                if not rot:
+                    near[:, 3:] += torch.randn(near.shape[0], 3, generator=g) * 1.5
+                    near[:, 3:] = torch.maximum(near[:, 3:], near[:, :3] + 1.0)
+                parts.append(near)
+            p = torch.cat(parts)[:n] if n else torch.zeros((0, 7 if rot else 6))
+            if ngt > 3:
+                gt[-3:, :3] += 500.0          # three boxes far outside: they overlap nothing
+                if not rot:
+                    gt[-3:, 3:] += 500.0
+            P.append(p); S.append(torch.rand(p.shape[0], generator=g)); G.append(gt)
+        for thr, limit in ((torch.tensor([0.5]), 300), (torch.arange(0.25, 1.0, 0.05), None)):
+            got = evaluate_box_proposals_recall([p.to(dev) for p in P], [s.to(dev) for s in S], [b.to(dev) for b in G], thresholds=thr, limit=limit)
+            ref = OM.recall(P, S, G, thr, limit)
+            assert got["num_pos"] == ref["num_pos"]
+            assert torch.equal((got["gt_overlaps"][:, None] >= thr[None]).sum(0), (ref["gt_overlaps"][:, None] >= thr[None]).sum(0))     # counts exact
+            assert torch.allclose(got["gt_overlaps"], ref["gt_overlaps"], atol=1e-5) and abs(got["ar"].item() - ref["ar"].item()) < 1e-6
+        keep = [i for i, b in enumerate(G) if b.shape[0]]        # the reference (and the oracle) index an empty IoU matrix for a scene without GT
+        Pa, Sa, Ga = [P[i] for i in keep], [S[i] for i in keep], [G[i] for i in keep]
+        for thr, top_k in ((0.25, None), (0.5, 300)):
+            got = evaluate_box_proposals_ap([p.to(dev) for p in Pa], [s.to(dev) for s in Sa], [b.to(dev) for b in Ga], iou_thresh=thr, top_k=top_k)
+            ref = OM.average_precision(Pa, Sa, Ga, thr, top_k)
+            assert abs(got["ap"].item() - ref["ap"].item()) < 1e-6, (rot, thr, got["ap"].item(), ref["ap"].item())
+            # here such a scene contributes false positives only
+            more = evaluate_box_proposals_ap([p.to(dev) for p in P], [s.to(dev) for s in S], [b.to(dev) for b in G], iou_thresh=thr, top_k=top_k)
+            assert more["ap"].item() <= got["ap"].item() + 1e-9
+
+
 def test_command_line_train_eval_roundtrip(tmp_path, dev):
     from nerf_rpn_amd.run_rpn import main
     rng = np.random.default_rng(0)
