@@ -306,19 +306,19 @@ def cpu_baseline(budget_s=60.0):
         return warm, timed
 
     all_cores = torch.get_num_threads()
-    warm, timed = run(all_cores, 2, 3)
-    best = sum(timed) / len(timed)
-    out = {"value": round(1.0 / best, 5), "unit": "scenes/sec", "cores": all_cores, "kind": "port",
-           "sample": f"fwd+bwd of one {GRID}^3x4 scene (VGG19-EF+FPN+RPN, OBB, fp32, no optimiser step): {len(warm)} warm-up "
-                     f"({', '.join(f'{t:.1f}' for t in warm)} s) + {len(timed)} timed passes ({', '.join(f'{t:.1f}' for t in timed)} s), mean; "
-                     f"bounded to ~{budget_s:.0f} s per thread count",
-           "passes_s": [round(t, 2) for t in timed]}
-    if all_cores > 8:
-        w8, t8 = run(8, 1, 2)
-        out["threads_8"] = {"value": round(len(t8) / sum(t8), 5), "unit": "scenes/sec", "cores": 8, "warmup_s": [round(t, 2) for t in w8],
-                            "passes_s": [round(t, 2) for t in t8]}
-        torch.set_num_threads(all_cores)
-    return out
+    runs = {}
+    for threads, warm_max, timed_max in ((all_cores, 2, 3), (32, 1, 2), (8, 1, 2)):
+        if threads > all_cores or threads in runs:
+            continue
+        warm, timed = run(threads, warm_max, timed_max)
+        runs[threads] = {"value": round(len(timed) / sum(timed), 5), "unit": "scenes/sec", "cores": threads, "warmup_s": [round(t, 2) for t in warm],
+                         "passes_s": [round(t, 2) for t in timed]}
+    torch.set_num_threads(all_cores)
+    best = max(runs.values(), key=lambda r: r["value"])      # the oracle's best thread count on this host (oversubscription hurts torch's CPU convs)
+    return {"value": best["value"], "unit": "scenes/sec", "cores": best["cores"], "kind": "port",
+            "sample": f"fwd+bwd of one {GRID}^3x4 scene (VGG19-EF+FPN+RPN, OBB, fp32, no optimiser step): per thread count 1-2 warm-up + 2-3 timed "
+                      f"passes, mean, each bounded to ~{budget_s:.0f} s; value = the best thread count ({best['cores']} of {all_cores} host threads)",
+            "by_threads": {str(k): v for k, v in sorted(runs.items())}}
 
 
 def eval_forward_protocol(dtype_name, dev, iters=20, warm=3):

@@ -37,7 +37,7 @@ def _p(t):
 # instead of each draining the chip on its own.  Consumers of the arena (optimiser step, bucket all-reduce) call wgrad_stream_join().
 # On by default for arena training (every gradient of the layer has a GradSink); NRPN_WGRAD_STREAM=0 or set_wgrad_stream(False) keeps
 # everything on the current stream.  Measured on the 160^3 VGG19-FPN step: 12.8 -> 12.0 ms.
-_WGRAD_SIDE = {"enabled": _os.environ.get("NRPN_WGRAD_STREAM", "1") != "0", "streams": {}, "dirty": False}
+_WGRAD_SIDE = {"enabled": _os.environ.get("NRPN_WGRAD_STREAM", "1") != "0", "streams": {}, "dirty": False, "prefetch": False}
 
 
 def set_wgrad_stream(enabled):
@@ -56,7 +56,7 @@ def _wgrad_side_stream(device):
 
 def wgrad_stream_join():
     """Make the current stream wait for every weight-gradient kernel enqueued on the side stream so far."""
-    if _WGRAD_SIDE["dirty"]:
+    if _WGRAD_SIDE["dirty"] or _WGRAD_SIDE["prefetch"]:      # wgrads of this backward pass / an operand refresh enqueued after the last step
         joined = True
         for st in _WGRAD_SIDE["streams"].values():
             cur = torch.cuda.current_stream(st.device)
@@ -65,7 +65,7 @@ def wgrad_stream_join():
             else:
                 cur.wait_stream(st)
         if joined:
-            _WGRAD_SIDE["dirty"] = False
+            _WGRAD_SIDE["dirty"] = _WGRAD_SIDE["prefetch"] = False
 
 
 def _chk(*ts):
@@ -572,7 +572,8 @@ class ArenaWeights:
             ev.record(side)
         _DGRAD_READY["event"] = ev
         _DGRAD_READY["waited"] = set()
-        _WGRAD_SIDE["dirty"] = True      # a step() with no backward in between still joins the side stream before it rewrites the arena
+        _WGRAD_SIDE["prefetch"] = True   # a step() with no backward in between still joins the side stream before it rewrites the arena
+                                         # (a flag of its own: "dirty" also decides whether a backward pass queues its end-of-pass join)
 
 
 _DGRAD_READY = {"event": None, "waited": set()}
