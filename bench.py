@@ -137,9 +137,12 @@ class ConvProbe:
         vox, cin_, cout_, _k = shape
         code = self.lib.BF16 if dtype_name == "bf16" else self.lib.F32
         if name == "conv3d_fwd":     # ask the library which kernel launch_conv selects for this shape
-            plan = self.lib.query("conv3d_fwd_plan", 1, vox, 1, 1, cin_, cout_, _k, code)
+            g = round(vox ** (1.0 / 3.0))
+            dims = (g, g, g) if g ** 3 == vox else (vox, 1, 1)        # the bench grids are cubes: the plan depends on the grid, not only on M
+            plan = self.lib.query("conv3d_fwd_plan", 1, *dims, cin_, cout_, _k, code)
             kernel = {0: "conv_igemm_kernel", 1: "conv_igemm_big_kernel", 2: "conv_igemm_big_kernel (K slices)",
-                      3: "conv_igemm_kernel (K slices)", 4: "conv_igemm_ws_kernel"}[plan]
+                      3: "conv_igemm_kernel (K slices)", 4: "conv_igemm_ws_kernel", 5: "conv_igemm_big4_kernel", 6: "conv_igemm_big4_kernel (K slices)",
+                      7: "conv_halo_kernel"}[plan]
         else:
             kernel = "conv_wgrad_big_kernel" if self.lib.query("conv3d_wgrad_plan", 1, vox, 1, 1, cin_, cout_, cout_, _k, code) else "conv_wgrad_kernel"
         es = 2 if dtype_name == "bf16" else 4
@@ -344,7 +347,7 @@ def eval_forward_protocol(dtype_name, dev, iters=20, warm=3):
 def conv_source_hash():
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv3d.hip", "common.h"):
+    for f in ("conv3d.hip", "conv_halo.hip", "conv_common.cuh", "common.h"):
         h.update(open(os.path.join(ROOT, "nerf_rpn_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

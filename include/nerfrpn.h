@@ -232,7 +232,8 @@ int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias, void *y, i
  *   relu_mask  as in nrpn_conv3d_fwd;  stats: as in nrpn_conv3d_fwd_stats (rows: nrpn_conv3d_fwd_stats_rows_ex with the same opts)
  *   tile       NRPN_TILE_*: 0 = chosen per shape; lds_dma / stagger / big_split: -1 = default, 0 / 1; kstep_bytes: 0 = default, 64, 128
  *   debug      tools only: NRPN_CONV_DEBUG_* bits (timing variants, wrong results) */
-enum { NRPN_TILE_AUTO = 0, NRPN_TILE_128 = 128, NRPN_TILE_256X128_WS = 256, NRPN_TILE_256X256 = 512, NRPN_TILE_256X256_W4 = 1024 };
+enum { NRPN_TILE_AUTO = 0, NRPN_TILE_128 = 128, NRPN_TILE_256X128_WS = 256, NRPN_TILE_256X256 = 512, NRPN_TILE_256X256_W4 = 1024,
+       NRPN_TILE_HALO = 2048 /* 3x3x3 bf16 only: 4x8x8 voxel blocks whose input halo is staged once per channel chunk */ };
 typedef struct nrpn_conv_opts {
   int32_t size;
   int32_t tile;
@@ -279,8 +280,8 @@ int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, fl
                              int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
                              nrpn_stream_t stream);
 /* kernel selection of a forward / dgrad launch: 0 = 128-row tile, 1 = 256x256 tile (8 waves), 2 = 256x256 tile on K slices, 3 = 128-row
- * tile on K slices, 4 = wave-specialised 256x128, 5 = 256x256 tile on 4 waves, 6 = the same on K slices;  of a wgrad launch:
- * 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */
+ * tile on K slices, 4 = wave-specialised 256x128, 5 = 256x256 tile on 4 waves, 6 = the same on K slices,
+ * 7 = halo form of the 3x3x3 kernel;  of a wgrad launch: 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */
 int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype);
 /* BatchNorm statistics out of the conv epilogue (the conv -> BatchNorm3d pairs of feature_extractor.py:288-377 in training mode):
  * nrpn_conv3d_fwd_stats = nrpn_conv3d_fwd that also writes per-row-group partial (sum, sum of squares) of the STORED bf16 outputs into
@@ -305,6 +306,9 @@ int nrpn_set_conv_lds_dma(int on);
  * 256x128 (4 MFMA + 4 LDS-DMA waves), 512 = 256x256 with 8 waves (default for Cout >= 256 when it yields >= 200 workgroups),
  * 1024 = 256x256 with 4 waves (128x128 per wave) */
 int nrpn_set_conv_tile_m(int bm);
+/* tools-only default: 1 (default) = the halo form (NRPN_TILE_HALO) is chosen automatically where it applies (bf16 3x3x3, Cout >= 256, grids its
+ * 4x8x8 blocks cover with <= 12 % waste and >= 200 workgroups), 0 = only on request */
+int nrpn_set_conv_halo_auto(int on);
 /* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
 int nrpn_set_conv_stagger(int on);
 /* tuning knob: 1 (default) = mid-size grids (16..199 tiles of 256x256) run the 256x256 kernel on K slices; 0 = 128-row kernel */

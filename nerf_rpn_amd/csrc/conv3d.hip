@@ -11,148 +11,7 @@
 // issued before the current step's MFMAs so HBM/L2 latency hides under the matrix work.
 //
 // Replaces torch.nn.Conv3d (MIOpen/cuDNN) in reference feature_extractor.py:331-358, fpn.py:109-110, anchor.py:190-198.
-#include "common.h"
-
-#include <atomic>
-
-typedef __attribute__((ext_vector_type(4))) float f4;
-typedef __attribute__((ext_vector_type(2))) float f2;
-typedef __attribute__((ext_vector_type(16))) float f16v;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
-typedef __attribute__((ext_vector_type(4))) short s4v;
-typedef unsigned short bf16s;  // raw bf16 storage
-
-
-template <typename T> struct Mma;
-template <> struct Mma<float> {
-  static __device__ __forceinline__ void run(f16v &acc, const f4 &a, const f4 &b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<bf16s> {
-  static __device__ __forceinline__ void run(f16v &acc, const f4 &a, const f4 &b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc, 0, 0, 0);
-  }
-};
-
-__device__ __forceinline__ f4 ldg16(const void *p) { return *reinterpret_cast<const f4 *>(p); }
-// 16-byte raw-buffer load: a lane whose offset is >= the descriptor's num_records gets zeros from the hardware, so border
-// taps / tail rows need no branch and no select -- every load of a K-step issues back to back.
-typedef __attribute__((ext_vector_type(4))) unsigned int u4v;
-constexpr unsigned kOOB = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f4 bufld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ f4 zero4() { f4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
-
-// XCD-aware workgroup order.  The dispatcher places linear workgroup id b on XCD b % 8 (observed, speed only); each XCD has
-// a private 4 MiB L2.  Remapping id -> (id % 8) * ceil(n/8) + id / 8 hands every XCD one CONTIGUOUS range of logical tiles,
-// so neighbouring tiles (which share halo voxels / weight panels / K-slices) hit the same L2 instead of eight different ones.
-__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
-  const unsigned q = n / 8, r = n % 8, xcd = id % 8, slot = id / 8;
-  // bijective for any n: the first r XCDs own q+1 ids, the rest q
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-
-// 16-byte LDS-DMA: each lane's 16 bytes land at (wave-uniform lds_dst) + 16 * lane; out-of-range lanes deposit zeros
-// (verified on hardware by tools/probe_glds.hip)
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, void *lds_dst, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_dst, 16, voff, 0, 0, 0);
-}
-
-// C/D fragment of the 32x32 MFMA: register r of lane l holds (row, col) = ((r&3) + 8*(r>>2) + 4*(l>>5), l&31)
-__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-// =====================================================================================================================
-// forward / dgrad
-// =====================================================================================================================
-// Ragged voxel lists: several grids laid end to end ((level, scene) segments of a weight-sharing head run in ONE launch).
-// n == 0 means the classic layout: N copies of one X*Y*Z grid.
-constexpr int kMaxSeg = 16;
-struct Segs {
-  int n;
-  int start[kMaxSeg + 1];                 // first voxel of each segment, start[n] = total
-  int X[kMaxSeg], Y[kMaxSeg], Z[kMaxSeg];
-};
-
-// voxel -> coordinates inside its grid, that grid's dims and its segment id (no dynamic indexing of the kernel-argument struct)
-__device__ __forceinline__ int locate_voxel(const Segs &s, long long v, int cX, int cY, int cZ, int &x, int &y, int &z, int &X, int &Y,
-                                            int &Z) {
-  int seg = 0;
-  long long local = v;
-  if (s.n > 0) {
-    X = s.X[0]; Y = s.Y[0]; Z = s.Z[0];
-    int st = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxSeg; ++k)
-      if (k < s.n && v >= s.start[k]) { X = s.X[k]; Y = s.Y[k]; Z = s.Z[k]; st = s.start[k]; seg = k; }
-    local = v - st;
-  } else {
-    X = cX; Y = cY; Z = cZ;
-  }
-  z = (int)(local % Z);
-  const long long t1 = local / Z;
-  y = (int)(t1 % Y);
-  x = (int)((t1 / Y) % X);
-  return seg;
-}
-
-static int fill_segs(Segs &sg, int nseg, const int32_t *dims, long long &M) {
-  if (nseg < 1 || nseg > kMaxSeg || !dims) return nrpn_fail(NRPN_ERR_ARG, "ragged conv: 1..%d segments", kMaxSeg);
-  sg.n = nseg;
-  long long off = 0;
-  for (int k = 0; k < nseg; ++k) {
-    if (dims[3 * k] <= 0 || dims[3 * k + 1] <= 0 || dims[3 * k + 2] <= 0) return nrpn_fail(NRPN_ERR_ARG, "ragged conv: bad segment %d", k);
-    sg.start[k] = (int)off; sg.X[k] = dims[3 * k]; sg.Y[k] = dims[3 * k + 1]; sg.Z[k] = dims[3 * k + 2];
-    off += (long long)dims[3 * k] * dims[3 * k + 1] * dims[3 * k + 2];
-    if (off >= (1ll << 31)) return nrpn_fail(NRPN_ERR_ARG, "ragged conv: too many voxels");
-  }
-  for (int k = nseg; k <= kMaxSeg; ++k) sg.start[k] = (int)off;
-  M = off;
-  return 0;
-}
-
-struct ConvArgs {
-  const void *x;
-  const void *w;      // MODE 0: [taps][wrows][Cin];  MODE 1 (stem): [wrows][Kpad], k = tap*4 + c
-  const float *bias;
-  const float *scale; // optional f32 [Cout]: y = acc * scale + bias (eval-mode BatchNorm folded into the conv: scale = gamma / sqrt(var + eps),
-                      // bias = (conv bias - mean) * scale + beta); nullptr = 1
-  const void *mask;   // optional [M][Cout] (dtype of x): outputs are zeroed where mask <= 0 (ReLU backward of the tensor this dgrad feeds)
-  void *y;
-  long long M;        // output voxels (N * OX * OY * OZ)
-  int X, Y, Z;        // input grid
-  int OX, OY, OZ;     // output grid (== input for MODE 0)
-  int Cin, Cout;      // Cout = stored output channels (row length of y)
-  int wrows;          // rows per tap in the packed weights (>= Cout; rows >= wrows read as zero)
-  int taps;           // 1, 27 (MODE 0) or 343 (MODE 1)
-  int stride;         // MODE 1 only
-  int flags;
-  unsigned x_bytes, w_bytes;   // extents for the raw-buffer descriptors (out-of-range lanes read 0)
-  int ksplit;         // > 1: workgroup id / tiles owns a slice of the K loop and stores its fp32 partial into ws[slice][M][Cout]
-  float *ws;          // [ksplit][M][Cout] fp32 partials (plain stores, summed in slice order by splitk_epilogue_kernel: deterministic)
-  int slices;         // 1: the K slices run on the 256x256 kernel (mid-size grids, conv_big_split); 0: on the 128-row kernel
-  Segs segs;          // MODE 0 only: ragged voxel list (n > 0) instead of N copies of X*Y*Z
-  float *stats;       // optional (bf16 staged epilogues only): per row-group partial BatchNorm statistics [P][2][Cout] = (sum, sum of squares)
-                      // of the STORED (bf16-rounded) outputs; row group = the rows one wave row covers (see nrpn_conv3d_fwd_stats_rows)
-};
-
-// per-column (sum, sum of squares) of the values a lane holds in its C fragments -> partial statistics row `pidx` (lanes l and l^32 hold
-// the two row halves of the same 32 columns)
-__device__ __forceinline__ void store_col_stats(float *stats, long long pidx, int cout, int col, float s, float q, int lane) {
-  s += __shfl_xor(s, 32, 64);
-  q += __shfl_xor(q, 32, 64);
-  if (lane < 32 && col < cout) {
-    stats[(pidx * 2) * cout + col] = s;
-    stats[(pidx * 2 + 1) * cout + col] = q;
-  }
-}
+#include "conv_common.cuh"
 
 template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128>
 __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(const ConvArgs p) {
@@ -1290,6 +1149,10 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big4_kernel(const ConvArgs 
   }
 }
 
+// conv_halo.hip: the "halo" form of the 3x3x3 implicit GEMM (4 x 8 x 8 voxel blocks, input halo staged once per channel chunk)
+namespace hk { constexpr int TX = 4, TY = 8, TZ = 8; }
+int nrpn_launch_conv_halo(const ConvArgs &a, unsigned workgroups, hipStream_t st);
+
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
                                        int cout, int relu, int nslices, const T *__restrict__ mask, const float *__restrict__ scale) {
@@ -1312,17 +1175,18 @@ __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float
 // ---------------------------------------------------------------------------------------------------------------------
 struct Knobs {
   int glds;        // 1: LDS-DMA loads (buffer_load ... lds), 0: register-staged loads
-  int bm;          // tile selector: 0 auto, 128, 256 (wave-specialised 256x128), 512 (256x256, 8 waves), 1024 (256x256, 4 waves)
+  int bm;          // tile selector: 0 auto, 128, 256 (wave-specialised 256x128), 512 (256x256, 8 waves), 1024 (256x256, 4 waves), 2048 (halo form)
   int stagger;     // 256x256 8-wave kernel: rotated K-step + staggered DMA issue (default) or the plain loop
   int big_split;   // mid-size grids run the 256x256 kernel on K slices
   int kb;          // K-step bytes of the k1/k3 kernels (64 or 128)
   int dbg;         // tools only: NRPN_CONV_DEBUG_* bits
+  int halo_auto;   // 1 (default): the halo form is chosen automatically where it applies (40^3-class grids), 0: only on request (tile 2048)
 };
-static std::atomic<int> g_conv_glds{1}, g_conv_bm{0}, g_conv_stagger{1}, g_conv_big_split{1}, g_conv_kb{128};
+static std::atomic<int> g_conv_glds{1}, g_conv_bm{0}, g_conv_stagger{1}, g_conv_big_split{1}, g_conv_kb{128}, g_conv_halo_auto{1};
 static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
   Knobs k{g_conv_glds.load(std::memory_order_relaxed), g_conv_bm.load(std::memory_order_relaxed), g_conv_stagger.load(std::memory_order_relaxed),
           g_conv_big_split.load(std::memory_order_relaxed), g_conv_kb.load(std::memory_order_relaxed),
-          flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER)};
+          flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER), g_conv_halo_auto.load(std::memory_order_relaxed)};
   if (o) {
     if (o->tile > 0) k.bm = o->tile;
     if (o->lds_dma >= 0) k.glds = o->lds_dma ? 1 : 0;
@@ -1334,6 +1198,7 @@ static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
   return k;
 }
 extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
+extern "C" int nrpn_set_conv_halo_auto(int on) { g_conv_halo_auto = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_stagger(int on) { g_conv_stagger = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_big_split(int on) { g_conv_big_split = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
@@ -1342,9 +1207,9 @@ extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
   return NRPN_OK;
 }
 extern "C" int nrpn_set_conv_tile_m(int bm) {
-  if (bm != 0 && bm != 128 && bm != 256 && bm != 512 && bm != 1024)
-    return nrpn_fail(NRPN_ERR_ARG, "conv tile selector must be 0 (auto), 128 (128x128), 256 (wave-specialised 256x128), 512 (256x256, 8 waves) or "
-                                   "1024 (256x256, 4 waves)");
+  if (bm != 0 && bm != 128 && bm != 256 && bm != 512 && bm != 1024 && bm != 2048)
+    return nrpn_fail(NRPN_ERR_ARG, "conv tile selector must be 0 (auto), 128 (128x128), 256 (wave-specialised 256x128), 512 (256x256, 8 waves), "
+                                   "1024 (256x256, 4 waves) or 2048 (halo form of the 3x3x3 kernel)");
   g_conv_bm = bm;
   return NRPN_OK;
 }
@@ -1387,6 +1252,20 @@ static int launch_igemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const C
   if (lds > 64 * 1024) NRPN_LDS(kernel, (int)lds);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
   return NRPN_OK;
+}
+
+// Halo form (conv_halo_kernel): bf16 3x3x3 on a classic grid whose 4 x 8 x 8 blocks waste little and still fill the chip.
+struct Grid { int n, gx, gy, gz; };
+static long long halo_tiles(const Grid &g) {
+  return (long long)g.n * ((g.gx + hk::TX - 1) / hk::TX) * ((g.gy + hk::TY - 1) / hk::TY) * ((g.gz + hk::TZ - 1) / hk::TZ);
+}
+static bool halo_ok(const Grid &g, int cin, int cout, int taps, int elem_bytes, bool out_f32, const Knobs &kn) {
+  if (g.n <= 0 || taps != 27 || elem_bytes != 2 || out_f32 || !kn.glds || (cin % 32) != 0 || (cout & 7) != 0 || cout < 256) return false;
+  if (kn.bm != 2048 && !(kn.bm == 0 && kn.halo_auto)) return false;
+  const long long tiles = halo_tiles(g) * ((cout + 255) / 256);
+  const double waste = (double)halo_tiles(g) * 256.0 / ((double)g.n * g.gx * g.gy * g.gz);
+  if (kn.bm == 2048) return true;                       // forced (tools / tests): any grid
+  return tiles >= 200 && waste <= 1.12;
 }
 
 // the tile family a (shape, Knobs) pair selects: 0 = 128-row, 1 = 256x256 8-wave, 4 = wave-specialised 256x128, 5 = 256x256 4-wave
@@ -1475,34 +1354,37 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st, const Kn
   return NRPN_OK;
 }
 
-static size_t fwd_workspace_bytes(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn) {
+static size_t fwd_workspace_bytes(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn, const Grid &g) {
+  if (halo_ok(g, cin, cout, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, false, kn)) return 0;
   const int bs = conv_big_split(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, kn);
   if (bs) return (size_t)bs * M * cout * 4;
   const int s = conv_ksplit(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, kn);
   return s > 1 ? (size_t)s * M * cout * 4 : 0;
 }
 extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
-  return fwd_workspace_bytes((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr));
+  return fwd_workspace_bytes((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr), Grid{n, gx, gy, gz});
 }
 extern "C" size_t nrpn_conv3d_fwd_workspace_bytes_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype,
                                                      const nrpn_conv_opts *opts) {
-  return fwd_workspace_bytes((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts));
+  return fwd_workspace_bytes((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts), Grid{n, gx, gy, gz});
 }
 
 // Which kernel a forward / dgrad launch of this shape selects (mirrors launch_conv + conv3d_fwd_impl; lets tests assert that a
 // shape really exercises the kernel they claim to cover): 0 = 128-row tile, 1 = 256x256 tile (8 waves), 2 = 256x256 tile on K slices,
-// 3 = 128-row tile on K slices, 4 = wave-specialised 256x128 (opt-in), 5 = 256x256 tile on 4 waves, 6 = the same on K slices.
-static int fwd_plan(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn) {
+// 3 = 128-row tile on K slices, 4 = wave-specialised 256x128 (opt-in), 5 = 256x256 tile on 4 waves, 6 = the same on K slices,
+// 7 = halo form of the 3x3x3 kernel (4 x 8 x 8 voxel blocks).
+static int fwd_plan(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn, const Grid &g) {
   const int es = dtype == NRPN_F32 ? 4 : 2, taps = ksize == 3 ? 27 : 1;
+  if (halo_ok(g, cin, cout, taps, es, false, kn)) return 7;
   if (conv_big_split(M, cout, cin, taps, es, kn)) return conv_tile_kind(M, cout, cin, es, true, false, kn) == 5 ? 6 : 2;
   if (conv_ksplit(M, cout, cin, taps, es, kn) > 1) return 3;
   return conv_tile_kind(M, cout, cin, es, false, false, kn);
 }
 extern "C" int nrpn_conv3d_fwd_plan(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
-  return fwd_plan((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr));
+  return fwd_plan((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr), Grid{n, gx, gy, gz});
 }
 extern "C" int nrpn_conv3d_fwd_plan_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype, const nrpn_conv_opts *opts) {
-  return fwd_plan((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts));
+  return fwd_plan((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts), Grid{n, gx, gy, gz});
 }
 
 static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, const void *mask, void *y, long long M, int gx, int gy, int gz, const Segs *segs,
@@ -1528,6 +1410,14 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
   a.x_bytes = (unsigned)(a.M * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);
   const bool out_f32 = (flags & NRPN_CONV_OUT_F32) != 0;
   hipStream_t st = as_stream(stream);
+  if (!segs && dtype == NRPN_BF16) {
+    const Grid g{(int)(M / ((long long)gx * gy * gz)), gx, gy, gz};
+    if (halo_ok(g, cin, cout, a.taps, es, out_f32, kn)) {
+      const long long wgs = halo_tiles(g) * ((cout + 255) / 256);
+      NRPN_REQUIRE(wgs < (1ll << 31), "conv3d_fwd: too many tiles");
+      return nrpn_launch_conv_halo(a, (unsigned)wgs, st);
+    }
+  }
   const int bs = workspace ? conv_big_split(a.M, cout, cin, a.taps, es, kn) : 0;
   if (bs) {
     a.ksplit = bs; a.slices = 1; a.ws = reinterpret_cast<float *>(workspace);
@@ -1563,18 +1453,19 @@ extern "C" int nrpn_conv3d_fwd(const void *x, const void *wp, const float *bias,
 
 // Rows P of the partial-statistics buffer [P][2][Cout] a forward launch of this shape fills when asked to (0 = the shape runs a kernel
 // without fused statistics: K-sliced, fp32, narrow K-step or the opt-in variants -- use nrpn_bn_stats on the output instead).
-static int fwd_stats_rows(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn) {
+static int fwd_stats_rows(long long M, int cin, int cout, int ksize, int dtype, const Knobs &kn, const Grid &g) {
   if (dtype != NRPN_BF16 || (cout & 7) != 0 || !kn.glds || kn.bm == 256) return 0;
-  const int plan = fwd_plan(M, cin, cout, ksize, dtype, kn);
+  const int plan = fwd_plan(M, cin, cout, ksize, dtype, kn, g);
+  if (plan == 7) return (int)(halo_tiles(g) * 2);
   if (plan == 1 || plan == 5) return (int)(cdiv64(M, 256) * 2);
   if (plan != 0 || kn.kb != 128 || (cin * 2) % 128 != 0) return 0;
   return (int)(cdiv64(M, 128) * (cout <= 64 ? 4 : 2));
 }
 extern "C" int nrpn_conv3d_fwd_stats_rows(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
-  return fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr));
+  return fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr), Grid{n, gx, gy, gz});
 }
 extern "C" int nrpn_conv3d_fwd_stats_rows_ex(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype, const nrpn_conv_opts *opts) {
-  return fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts));
+  return fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts), Grid{n, gx, gy, gz});
 }
 
 // nrpn_conv3d_fwd + partial BatchNorm statistics of the stored outputs from the same launch (finish them with nrpn_bn_stats_finalize).
@@ -1598,7 +1489,7 @@ extern "C" int nrpn_conv3d_fwd_ex(const void *x, const void *wp, const float *bi
   float *stats = opts ? opts->stats : nullptr;
   NRPN_REQUIRE(!mask || !(flags & NRPN_CONV_OUT_F32) || dtype == NRPN_F32, "conv3d_fwd_ex: relu_mask needs outputs in the input dtype");
   if (stats) {
-    NRPN_REQUIRE(fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts)) > 0 && !(flags & NRPN_CONV_OUT_F32) &&
+    NRPN_REQUIRE(fwd_stats_rows((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(opts), Grid{n, gx, gy, gz}) > 0 && !(flags & NRPN_CONV_OUT_F32) &&
                      wrows == cout && !mask,
                  "conv3d_fwd_ex: this shape / plan does not run a kernel with fused statistics (nrpn_conv3d_fwd_stats_rows_ex)");
     workspace = nullptr;

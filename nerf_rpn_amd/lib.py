@@ -18,7 +18,7 @@ CONV_BIAS, CONV_RELU, CONV_OUT_F32 = 1, 2, 4
 
 _lib = None
 
-TILE_AUTO, TILE_128, TILE_256X128_WS, TILE_256X256, TILE_256X256_W4 = 0, 128, 256, 512, 1024
+TILE_AUTO, TILE_128, TILE_256X128_WS, TILE_256X256, TILE_256X256_W4, TILE_HALO = 0, 128, 256, 512, 1024, 2048
 
 
 class ConvOpts(ctypes.Structure):

@@ -499,7 +499,8 @@ def test_four_wave_256x256_kernel_is_bit_identical_to_the_eight_wave_kernel(cin,
     x, wp, bias = _conv_case(dev, 1, grid, cin, cout)
     o4 = lib.ConvOpts(tile=lib.TILE_256X256_W4)
     assert lib.query("conv3d_fwd_plan_ex", 1, *grid, cin, cout, 3, lib.BF16, o4.ptr()) == plan
-    assert lib.query("conv3d_fwd_plan", 1, *grid, cin, cout, 3, lib.BF16) == plan - 4
+    o8 = lib.ConvOpts(tile=lib.TILE_256X256)
+    assert lib.query("conv3d_fwd_plan_ex", 1, *grid, cin, cout, 3, lib.BF16, o8.ptr()) == plan - 4
     scale = torch.rand(cout, device=dev) + 0.5
     mask = torch.randn(1, *grid, cout, device=dev).bfloat16()
     for kw in (dict(), dict(scale=scale), dict(mask=mask)):
@@ -551,3 +552,42 @@ def test_two_threads_with_different_plans_share_no_state(dev):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n,grid,cin,cout", [(1, (40, 40, 40), 256, 256), (1, (37, 42, 29), 256, 256), (2, (12, 16, 19), 128, 512), (1, (9, 8, 8), 64, 264)])
+def test_halo_form_of_the_3x3x3_kernel(n, grid, cin, cout, dev):
+    """conv_halo_kernel (4 x 8 x 8 voxel blocks, input halo staged once per 32-channel chunk, slot-major LDS tiles; nrpn_conv_opts.tile =
+    NRPN_TILE_HALO) against the default kernel of the shape and against torch fp32 on the bf16-rounded operands: exact grids, ragged
+    blocks in every axis, two scenes, a Cout that is not a multiple of the 256-column tile; bias / scale / ReLU / ReLU mask /
+    BatchNorm statistics partials."""
+    from nerf_rpn_amd import lib, ops
+    x, wp, bias = _conv_case(dev, n, grid, cin, cout, seed=cin + grid[0])
+    oh = lib.ConvOpts(tile=lib.TILE_HALO)
+    assert lib.query("conv3d_fwd_plan_ex", n, *grid, cin, cout, 3, lib.BF16, oh.ptr()) == 7
+    scale = torch.rand(cout, device=dev) + 0.5
+    mask = torch.randn(n, *grid, cout, device=dev).bfloat16()
+    for kw in (dict(), dict(scale=scale), dict(mask=mask)):
+        flags = lib.CONV_RELU if "mask" not in kw else 0
+        a = ops._conv_fwd(x, wp, bias, cout, cout, 3, flags, torch.bfloat16, tile=lib.TILE_128, **kw).float()
+        b = ops._conv_fwd(x, wp, bias, cout, cout, 3, flags, torch.bfloat16, tile=lib.TILE_HALO, **kw).float()
+        # same products, another summation order (chunk-of-32 outer, tap inner): fp32 rounding, then one bf16 rounding of the result
+        assert (a - b).abs().max().item() <= 2 ** -7 * a.abs().max().item(), (kw.keys(), (a - b).abs().max().item(), a.abs().max().item())
+        assert (a != b).float().mean().item() < 0.02
+    rows = lib.query("conv3d_fwd_stats_rows_ex", n, *grid, cin, cout, 3, lib.BF16, oh.ptr())
+    assert rows == 2 * n * -(-grid[0] // 4) * -(-grid[1] // 8) * -(-grid[2] // 8)
+    st = {}
+    y = ops._conv_fwd(x, wp, bias, cout, cout, 3, 0, torch.bfloat16, stats=st, tile=lib.TILE_HALO).float()
+    part = st["partials"]
+    assert tuple(part.shape) == (rows, 2, cout)
+    flat = y.reshape(-1, cout)
+    assert torch.allclose(part[:, 0].sum(0), flat.sum(0), rtol=1e-4, atol=1e-2 * flat.abs().max().item())
+    assert torch.allclose(part[:, 1].sum(0), (flat * flat).sum(0), rtol=1e-4, atol=1e-2 * (flat * flat).max().item())
+    if grid[0] * grid[1] * grid[2] * n <= 8000:
+        w = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
+        torch.manual_seed(cin + grid[0])
+        xx = torch.randn(n, *grid, cin, device=dev).bfloat16()
+        ww = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
+        wpp, _ = ops.PackedWeight().get([ww], torch.bfloat16, cout, False)
+        got = ops._conv_fwd(xx, wpp, None, cout, cout, 3, 0, torch.bfloat16, tile=lib.TILE_HALO).float().cpu()
+        ref = F.conv3d(cf(xx.float().cpu()), ww.bfloat16().float().cpu(), padding=1)
+        assert relerr(cf(got), ref) < 1e-2

@@ -39,7 +39,7 @@ for name in sys.argv[1:]:
             c = cb[sel][:, :3]
             dist = torch.minimum(c.abs(), (c - size).abs()).min(dim=1).values
             print(f'   level {l}: {int(sel.sum())} candidates; closest centre-to-face distance {dist.min().item():.3e}; outside: {int(((c < 0) | (c > size)).any(1).sum())}')
-    for b in bad[:12].tolist():
+    for b in bad[:40].tolist():
         lvl = int(rl[b])
         same = gl.long() == lvl
         boxok = same & ((gp - rp[b]).abs() <= tol[b, 0]).all(1)

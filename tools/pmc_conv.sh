@@ -18,7 +18,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
   f=$(ls /tmp/pmc_pass$i/*/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" "$out/pass$i.csv"
 done
-python - "$out" <<'PY'
+NRPN_ROOT="$root" python - "$out" <<'PY'
 import csv, json, sys, collections, glob, os
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -41,7 +41,12 @@ for k, cs in acc.items():
     if "TCC_HIT_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
     res[k] = d
-json.dump({"method": "rocprofv3 --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE in separate passes: 3 + 2 of the 4 TCC slots) on "
+import hashlib
+sha = hashlib.sha256()
+root = os.path.join(os.path.dirname(os.path.abspath(out)), "..") if False else os.environ.get("NRPN_ROOT", ".")
+for f in ("conv3d.hip", "conv_halo.hip", "conv_common.cuh", "common.h"):      # the same hash bench.py computes (conv_source_hash): counters are tied to the kernel source
+    sha.update(open(os.path.join(root, "nerf_rpn_amd", "csrc", f), "rb").read())
+json.dump({"conv_source_sha16": sha.hexdigest()[:16], "method": "rocprofv3 --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE in separate passes: 3 + 2 of the 4 TCC slots) on "
                      "tools/one_conv.py: 256->256 k3 @40^3 bf16, per-launch averages; bytes = FETCH_SIZE[KiB] x 1024 x 2 (gfx950 tallies the "
                      "128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE[KiB] x 1024 (uncalibrated)",
            "kernels": res}, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
