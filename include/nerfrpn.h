@@ -208,7 +208,9 @@ enum { NRPN_CONV_BIAS = 1, NRPN_CONV_RELU = 2, NRPN_CONV_OUT_F32 = 4,
         * centre voxel ("ideal memory"), resp. the per-K-step barrier + DMA drain is skipped ("free-running waves") */
        NRPN_CONV_DEBUG_ALIAS_TAPS = 256, NRPN_CONV_DEBUG_NO_SYNC = 512,
        /* experiment (results stay correct): waves 4-7 of the 256x256 kernel issue their LDS-DMA two sub-steps later than waves 0-3 */
-       NRPN_CONV_DEBUG_STAGGER = 1024 };
+       NRPN_CONV_DEBUG_STAGGER = 1024,
+       /* tools only (results stay correct): 2-bit A/B variant selector of the halo kernel (bits 12-13), see conv_halo.hip */
+       NRPN_CONV_DEBUG_VARIANT = 0x3000 };
 int nrpn_pack_conv_weight(const float *w_ref, int cout, int cin, int taps, int dtype, void *wp_fwd, void *wp_dgrad,
                           int rows_total, int row_offset, nrpn_stream_t stream);
 /* packed fp32 partial weight gradients [slices][taps][rows_total][Cin] (output of nrpn_conv3d_wgrad) -> sum over the

@@ -1151,7 +1151,7 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big4_kernel(const ConvArgs 
 
 // conv_halo.hip: the "halo" form of the 3x3x3 implicit GEMM (4 x 8 x 8 voxel blocks, input halo staged once per channel chunk)
 namespace hk { constexpr int TX = 4, TY = 8, TZ = 8; }
-int nrpn_launch_conv_halo(const ConvArgs &a, unsigned workgroups, hipStream_t st);
+int nrpn_launch_conv_halo(const ConvArgs &a, unsigned workgroups, hipStream_t st, int variant);
 
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
@@ -1186,14 +1186,14 @@ static std::atomic<int> g_conv_glds{1}, g_conv_bm{0}, g_conv_stagger{1}, g_conv_
 static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
   Knobs k{g_conv_glds.load(std::memory_order_relaxed), g_conv_bm.load(std::memory_order_relaxed), g_conv_stagger.load(std::memory_order_relaxed),
           g_conv_big_split.load(std::memory_order_relaxed), g_conv_kb.load(std::memory_order_relaxed),
-          flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER), g_conv_halo_auto.load(std::memory_order_relaxed)};
+          flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER | NRPN_CONV_DEBUG_VARIANT), g_conv_halo_auto.load(std::memory_order_relaxed)};
   if (o) {
     if (o->tile > 0) k.bm = o->tile;
     if (o->lds_dma >= 0) k.glds = o->lds_dma ? 1 : 0;
     if (o->kstep_bytes == 64 || o->kstep_bytes == 128) k.kb = o->kstep_bytes;
     if (o->stagger >= 0) k.stagger = o->stagger ? 1 : 0;
     if (o->big_split >= 0) k.big_split = o->big_split ? 1 : 0;
-    k.dbg |= o->debug & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER);
+    k.dbg |= o->debug & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER | NRPN_CONV_DEBUG_VARIANT);
   }
   return k;
 }
@@ -1415,7 +1415,7 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
     if (halo_ok(g, cin, cout, a.taps, es, out_f32, kn)) {
       const long long wgs = halo_tiles(g) * ((cout + 255) / 256);
       NRPN_REQUIRE(wgs < (1ll << 31), "conv3d_fwd: too many tiles");
-      return nrpn_launch_conv_halo(a, (unsigned)wgs, st);
+      return nrpn_launch_conv_halo(a, (unsigned)wgs, st, (kn.dbg >> 12) & 3);
     }
   }
   const int bs = workspace ? conv_big_split(a.M, cout, cin, a.taps, es, kn) : 0;

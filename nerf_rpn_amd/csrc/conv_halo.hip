@@ -39,6 +39,10 @@ __device__ __forceinline__ void block_voxel(int r, int &xl, int &yl, int &zl) {
 }
 }  // namespace hk
 
+// V (tools-only A/B variants, selected by the NRPN_CONV_DEBUG_VARIANT bits; the production instantiation is V = 0 -- set below to the measured
+// winner): bit 0 = static priority for the second-dispatched waves 4-7 (MI355X guide, "two waves per SIMD" item 4); bit 1 = waves 4-7 issue
+// their weight pieces one sub-step later than waves 0-3 (the two waves of a SIMD are then not both in their DMA-issue phase).
+template <int V>
 __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
   using namespace hk;
   typedef bf16s T;
@@ -155,12 +159,18 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
     const int subs = (2 * ks + 1 < 27) ? 4 : 2;
     const bool last = ks + 1 == KSTEPS;
     // the next weight tile (and, early in a chunk, the next chunk's halo) fly under this K-step's MFMAs
-    if (!last) issue_b(bbuf ^ 1, chunk, ks + 1);
-    else if (more_chunks) issue_b(bbuf ^ 1, chunk + 1, 0);
+    auto issue_next_b = [&]() {
+      if (!last) issue_b(bbuf ^ 1, chunk, ks + 1);
+      else if (more_chunks) issue_b(bbuf ^ 1, chunk + 1, 0);
+    };
+    const bool late = (V & 2) && wave_u >= 4;
+    if (!(V & 2)) issue_next_b();
+    else if (!late) issue_next_b();
     if (more_chunks && ks < A_PER_WAVE) issue_halo_piece(abuf ^ 1, chunk + 1, ks);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       if (s4 >= subs) break;
+      if ((V & 2) && s4 == 1 && late) issue_next_b();
       if (s4 + 1 < subs) {
         load(abuf, bbuf, ks, s4 + 1, af[(s4 + 1) & 1], bfv[(s4 + 1) & 1]);
       } else {
@@ -181,6 +191,7 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
     }
   };
   load(0, 0, 0, 0, af[0], bfv[0]);
+  if ((V & 1) && wave_u >= 4) __builtin_amdgcn_s_setprio(1);
   // chunks in pairs so that the halo buffer is a compile-time constant inside the unrolled K-steps (immediate ds offsets); 14 K-steps
   // per chunk flip the weight buffer an even number of times, so every chunk starts on weight buffer 0
 #pragma unroll 1
@@ -204,6 +215,7 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
   const T *maskp = reinterpret_cast<const T *>(p.mask);
   T *yp = reinterpret_cast<T *>(p.y);
   float ssum[TN] = {0.f, 0.f}, qsum[TN] = {0.f, 0.f};
+  const bool full_block = x0 + TX <= p.X && y0 + TY <= p.Y && z0 + TZ <= p.Z;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -222,9 +234,12 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
           const bf16s ob = f32_to_bf16_bits(o);
           *reinterpret_cast<bf16s *>(stage + (ii * 32 + rr) * PITCH + (j * 32 + efr) * 2) = ob;
           if (p.stats) {
-            int xl, yl, zl;
-            block_voxel(rr, xl, yl, zl);
-            const bool in = x0 + 2 * (blk >> 2) + xl < p.X && y0 + 2 * (blk & 3) + yl < p.Y && z0 + zl < p.Z;
+            bool in = true;
+            if (!full_block) {        // ragged block at the grid's edge: only voxels inside the grid count (wave-uniform branch)
+              int xl, yl, zl;
+              block_voxel(rr, xl, yl, zl);
+              in = x0 + 2 * (blk >> 2) + xl < p.X && y0 + 2 * (blk & 3) + yl < p.Y && z0 + zl < p.Z;
+            }
             const float of = in ? bf16_bits_to_f32(ob) : 0.f;
             ssum[j] += of;
             qsum[j] += of * of;
@@ -266,9 +281,19 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
 }
 
 
-int nrpn_launch_conv_halo(const ConvArgs &a, unsigned workgroups, hipStream_t st) {
-  NRPN_LDS(conv_halo_kernel, hk::LDS_BYTES);
-  hipLaunchKernelGGL(conv_halo_kernel, dim3(workgroups), dim3(512), hk::LDS_BYTES, st, a);
+int nrpn_launch_conv_halo(const ConvArgs &a, unsigned workgroups, hipStream_t st, int variant) {
+#define NRPN_HALO(V_)                                                                                       \
+  do {                                                                                                      \
+    NRPN_LDS(conv_halo_kernel<V_>, hk::LDS_BYTES);                                                          \
+    hipLaunchKernelGGL(conv_halo_kernel<V_>, dim3(workgroups), dim3(512), hk::LDS_BYTES, st, a);            \
+  } while (0)
+  switch (variant & 3) {
+    case 1: NRPN_HALO(1); break;
+    case 2: NRPN_HALO(2); break;
+    case 3: NRPN_HALO(3); break;
+    default: NRPN_HALO(0); break;
+  }
+#undef NRPN_HALO
   NRPN_LAUNCH_CHECK("conv_halo");
   return NRPN_OK;
 }

@@ -41,6 +41,18 @@ for grid, cin, cout, k in SHAPES:
         print(line, ' equal' if torch.equal(outs[lib.TILE_256X256], outs[lib.TILE_256X256_W4]) else ' DIFFERENT',
               ('halo maxdiff %.3g' % (outs[lib.TILE_256X256].float() - outs[lib.TILE_HALO].float()).abs().max().item()) if k == 3 else '', flush=True)
 
+# halo-kernel variants (nrpn_conv_opts.debug bits 12-13)
+x = torch.randn(1, 40, 40, 40, 256, device=dev).clamp_min(0).bfloat16()
+w = torch.randn(256, 256, 3, 3, 3, device=dev) * 0.05
+wp, _ = ops.PackedWeight().get([w], torch.bfloat16, 256, False)
+y = torch.empty(1, 40, 40, 40, 256, device=dev, dtype=torch.bfloat16)
+for rnd in range(2):
+    line = 'halo variants 256->256@40^3:'
+    for var in (0, 1, 2, 3):
+        o = lib.ConvOpts(tile=lib.TILE_HALO, debug=var << 12)
+        t = timeit(lambda: lib.call('conv3d_fwd_ex', x.data_ptr(), wp.data_ptr(), 0, y.data_ptr(), 1, 40, 40, 40, 256, 256, 256, 3, lib.BF16, 0, 0, o.ptr(), ops._s()), iters=40)
+        line += f'  V{var}: {t:.1f} us {2 * 64000 * 256 * 256 * 27 / t / 1e6:.0f} TF'
+    print(line, flush=True)
 if os.environ.get('SKIP_REST'):
     sys.exit(0)
 # stem
