@@ -8,10 +8,12 @@ root=$PWD
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
 python bench.py > $out/bench.log 2>$out/bench.err; grep '^{' $out/bench.log > $out/bench_n1.json; python tools/bench_line.py final < $out/bench_n1.json | cut -c1-200
 export TMPDIR=/tmp
-(cd /tmp && NRPN_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe > $root/$out/prof_bench.log 2>&1)
+(cd /tmp && NRPN_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe --no-extras > $root/$out/prof_bench.log 2>&1)
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $out/kernel_stats_single_stream.csv
 python tools/prof_summary.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) $out/kernel_summary_single_stream.json 7
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o p --output-format csv -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe > $root/$out/prof_bench2.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o p --output-format csv -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe --no-extras > $root/$out/prof_bench2.log 2>&1)
 cp $(find /tmp/prof2 -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 grep '^{' $out/prof_bench.log | python tools/bench_line.py profiled-single | cut -c1-120
 grep '^{' $out/prof_bench2.log | python tools/bench_line.py profiled-streams | cut -c1-120
+# PMC counters of the kernels that can serve the dominant shape (halo form, 256x256 tile on 8 / 4 waves) and the 256x256 wgrad kernel
+bash tools/pmc_conv.sh $out/pmc > $out/pmc.log 2>&1; tail -5 $out/pmc.log | cut -c1-200
