@@ -189,6 +189,9 @@ class RCNN(nn.Module):
         self.flatten_size = input_size[0] * input_size[1] * input_size[2]
         self.RCNN_bbox_pred = nn.Linear(width, self.reg_dim)
         self.RCNN_cls_score = nn.Linear(width, self.n_classes)
+        for m in (self.RCNN_bbox_pred, self.RCNN_cls_score):      # rows of ONE fused GEMM: a flat-arena trainer keeps them in the reference layout
+            m.__dict__["_nrpn_fused_gemm"] = True
+        self._pack = ops.PackedWeight()
 
     def forward(self, pooling_feature):
         x = pooling_feature
@@ -198,7 +201,15 @@ class RCNN(nn.Module):
             x = hip_nn.as_ncdhw(cl)
         x = x.reshape(x.size(0), -1) if self.is_flatten else x.mean(-1).mean(-1).mean(-1)
         x = x.float()
-        return F.linear(x, self.RCNN_bbox_pred.weight, self.RCNN_bbox_pred.bias), F.linear(x, self.RCNN_cls_score.weight, self.RCNN_cls_score.bias)
+        if x.shape[0] == 0 or (x.shape[1] * 4) % 64:
+            return F.linear(x, self.RCNN_bbox_pred.weight, self.RCNN_bbox_pred.bias), F.linear(x, self.RCNN_cls_score.weight, self.RCNN_cls_score.bias)
+        # both Linear heads as ONE one-tap GEMM on the MFMA kernels (rows = [bbox_pred | cls_score | zero padding to 64]), fp32 (exact
+        # fp32 MFMA chains): the same construction as the RPN head's fused cls / bbox GEMM
+        rows = ((self.reg_dim + self.n_classes + 63) // 64) * 64
+        y = ops.ConvFn.apply(x.reshape(x.shape[0], 1, 1, 1, x.shape[1]).contiguous(), self._pack, rows, False, True, 2,
+                             self.RCNN_bbox_pred.weight, self.RCNN_cls_score.weight, self.RCNN_bbox_pred.bias, self.RCNN_cls_score.bias)
+        y = y.reshape(x.shape[0], rows)
+        return y[:, :self.reg_dim], y[:, self.reg_dim:self.reg_dim + self.n_classes]
 
 
 class Classification_Model(nn.Module):

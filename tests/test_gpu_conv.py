@@ -331,7 +331,7 @@ def test_ragged_conv_equals_per_grid_convs(grids, cin, cout, dtype, dev):
         assert relerr(x.grad.float().cpu(), b.cpu()) < tol
     # bf16: where the two paths run different kernels, outputs that round to either side of zero flip their ReLU mask in the backward
     assert relerr(conv.weight.grad.cpu(), ref[2].cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
-    assert relerr(conv.bias.grad.cpu(), ref[3].cpu()) < 1e-5
+    assert relerr(conv.bias.grad.cpu(), ref[3].cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("cin,cout,grid,rows_expected", [
