@@ -7,14 +7,18 @@ What runs where:
   * RoI features: rotated 3D RoIAlign on channels-last pyramid levels (``csrc/roialign.hip``; reference op rotated_roi_3d);
   * the head's 3x3x3 convs: the MFMA implicit-GEMM conv kernels; the two Linear layers: the same GEMM with one tap.
 
-Divergences from the reference, on purpose:
-  * ``ROIPool`` always pools with the RoIAlign kernel.  The reference has three alternatives -- the CUDA op (``use_cuda``), a torch
-    re-implementation of the same sampling for rotated boxes, and an adaptive max-pool over integer crops for axis-aligned boxes; here
-    rotated RoIs go to the kernel directly and axis-aligned RoIs as theta = 0 boxes.
-  * The reference hands the box heading in RADIANS to an op that reads DEGREES and rotates sample points by -theta
-    (ROIAlignRotated3D_cuda.cu:103,146-147).  Here the angle is converted (degrees, negated), so the sampled region IS the box.
+``ROIPool`` modes:
+  * ``use_cuda=False`` (the reference CLI's default): the reference's torch paths restated on device tensors, bit-exact against outputs of
+    the reference itself (tests/golden/roipool.npz) -- integer crops + adaptive max-pool for AABBs, the rotated 8-corner gather + max-pool
+    / trilinear resize for OBBs, including its in-place enlargement of the caller's OBB RoIs and its AABB "enlargement" by (1 + e) / 2.
+  * ``use_cuda=True``: the rotated RoIAlign kernel; axis-aligned RoIs go through it as theta = 0 boxes.  Two behaviours of the reference's
+    op path are corrected by default and available verbatim with ``reference_op_quirks=True`` (or NRPN_ROIPOOL_REFERENCE_QUIRKS=1): it hands the box heading in RADIANS to an
+    op that reads DEGREES and rotates sample points by -theta (ROIAlignRotated3D_cuda.cu:103,146-147; here: converted, so the sampled
+    region IS the box), and it concatenates the pooled rows level by level (detector.py:250-259) while labels and RoIs stay in sample
+    order (here: rows are returned in the order of the RoIs).
 """
 import math
+import os
 from typing import List
 
 import numpy as np
@@ -103,7 +107,7 @@ class ROIPool(nn.Module):
     feature voxel at each level; RoI rows are (level index, box)."""
 
     def __init__(self, output_size=(1, 1, 1), spatial_scale=(1, 1, 1, 1), enlarge_scale=0.2, is_rotated_bbox=False,
-                 feature_extracting_type="pooling", max_res=200, remap=False, use_cuda=True):
+                 feature_extracting_type="pooling", max_res=200, remap=False, use_cuda=True, reference_op_quirks=None):
         super().__init__()
         self.output_size = [int(v) for v in output_size]
         self.spatial_scale = list(spatial_scale)
@@ -112,15 +116,16 @@ class ROIPool(nn.Module):
         self.feature_extracting_type = feature_extracting_type
         self.canonical_scale, self.canonical_level = max_res, len(spatial_scale)
         self.remap = remap
-        if not use_cuda:
-            # The reference's default (use_cuda=False) max-pools integer crops (AABB) or an 8-corner "interpolation" grid followed by
-            # max-pool / trilinear resize (OBB, ``feature_extracting_type``), detector.py:264-438.  Only the RoIAlign op path
-            # (``--use_cuda``) exists here: say so instead of silently producing different features for a reference-trained RCNN.
-            import warnings
-            warnings.warn("ROIPool: use_cuda=False / feature_extracting_type=%r are not implemented on the HIP path; the rotated RoIAlign "
-                          "kernel (the reference's --use_cuda path) is used instead -- RCNN checkpoints trained with the reference's "
-                          "default pooling will not reproduce their scores" % (feature_extracting_type,), stacklevel=2)
-        self.use_cuda = True
+        if feature_extracting_type not in ("pooling", "interpolation"):
+            raise NameError("Unkown feature_extracting_type")
+        # use_cuda=True: the rotated RoIAlign op (the reference's --use_cuda path, :247-261).  use_cuda=False (the reference CLI's DEFAULT):
+        # its torch paths -- integer crops + adaptive max-pool for AABBs (:397-438), a rotated 8-corner gather followed by max-pool or a
+        # trilinear resize for OBBs (:264-395) -- restated below on device tensors, so that an RCNN trained with the reference's default
+        # pooling reproduces its scores.  They are per-RoI torch loops exactly like the reference's (second-stage glue, not the hot path).
+        self.use_cuda = bool(use_cuda)
+        if reference_op_quirks is None:
+            reference_op_quirks = os.environ.get("NRPN_ROIPOOL_REFERENCE_QUIRKS", "0") == "1"
+        self.reference_op_quirks = bool(reference_op_quirks)
         self.align = ROIAlignRotated3D(self.output_size, sampling_ratio=0)
 
     def enlarge_roi(self, roi):
@@ -146,6 +151,8 @@ class ROIPool(nn.Module):
                 lv = mapper(geo).to(flat.dtype)
                 remapped.append(torch.cat([lv[..., None], boxes], -1).reshape(shape))
             rois = remapped
+        if not self.use_cuda:
+            return self._rotated_forward(feature, rois) if self.is_rotated_bbox else self._normal_forward(feature, rois)
         out = []
         for f, r in zip(feature, rois):
             r = r.reshape(-1, r.shape[-1])
@@ -159,8 +166,12 @@ class ROIPool(nn.Module):
                 rows = obb[sel]
                 # op rows: (batch index, centre, extent, angle in degrees); its sampling rotates by -angle, a box with heading theta
                 # is therefore sampled with angle = -theta (see the module docstring)
-                op_rois = torch.cat([torch.zeros_like(rows[:, :1]), rows[:, :6], -rows[:, 6:7] * (180.0 / math.pi)], dim=1)
+                angle = rows[:, 6:7] if self.reference_op_quirks else -rows[:, 6:7] * (180.0 / math.pi)
+                op_rois = torch.cat([torch.zeros_like(rows[:, :1]), rows[:, :6], angle], dim=1)
                 feat = self.align(f[l][None], op_rois, float(1 / self.spatial_scale[l]))
+                if self.reference_op_quirks:       # level-major rows, as the reference's torch.cat over levels leaves them
+                    pooled = feat if pooled is None else torch.cat([pooled, feat])
+                    continue
                 if pooled is None:
                     pooled = feat.new_zeros((r.shape[0],) + tuple(feat.shape[1:]))
                 pooled = pooled.index_copy(0, sel, feat)
@@ -168,6 +179,92 @@ class ROIPool(nn.Module):
                 c = f[0].shape[0]
                 pooled = f[0].new_zeros((0, c, *self.output_size))
             out.append(pooled)
+        return out
+
+
+    # ---------------------------------------------------------------------------------------------- reference torch paths (use_cuda=False)
+    def _adaptive_max_pool(self, feat):
+        """[C, a, b, c] -> [C, *output_size]: zero padding at the high side up to a multiple of the output size, then a max-pool whose kernel
+        = stride = ceil(extent / output) (reference :377-384, :425-432)."""
+        size = torch.tensor(feat.shape[1:], dtype=torch.float32)
+        out = torch.tensor(self.output_size, dtype=torch.float32)
+        kernel = torch.ceil(size / out).int()
+        pad = (kernel * out.int() - size.int()).int()
+        feat = F.pad(feat, (0, int(pad[2]), 0, int(pad[1]), 0, int(pad[0])))
+        k = [int(v) for v in kernel]
+        return F.max_pool3d(feat[None], kernel_size=k, stride=k)[0]
+
+    def _normal_forward(self, features, rois):
+        """AABB RoIs: the enlarged box in feature voxels, floor of both corners, the inclusive integer crop, adaptive max-pool (:397-438)."""
+        out = []
+        for f, r in zip(features, rois):
+            r = r.reshape(-1, r.shape[-1])
+            lv = r[..., 0].long()
+            scale = torch.tensor(self.spatial_scale, dtype=r.dtype, device=r.device)[lv][:, None]
+            roi = r[..., 1:]
+            # the reference's AABB "enlargement" places the corners at centre -+ 0.5 * (half extent * (1 + enlarge)): the pooled box is
+            # (1 + enlarge) / 2 of the RoI, not larger than it (:203-209).  Kept: it is what its RCNN weights were trained on.
+            ext = (roi[..., 3:] - roi[..., :3]) / 2 * (1 + self.enlarge_scale)
+            ctr = (roi[..., 3:] + roi[..., :3]) / 2
+            pos = torch.floor(torch.cat([ctr - 0.5 * ext, ctr + 0.5 * ext], dim=-1) / scale)
+            pos = pos.long().tolist()
+            feats = []
+            for j, p in enumerate(pos):
+                crop = f[int(lv[j])][..., p[0]:p[3] + 1, p[1]:p[4] + 1, p[2]:p[5] + 1]
+                feats.append(self._adaptive_max_pool(crop.float()))
+            out.append(torch.stack(feats) if feats else f[0].new_zeros((0, f[0].shape[0], *self.output_size)))
+        return out
+
+    def _rotated_forward(self, features, rois):
+        """OBB RoIs without the op (:264-395): a regular grid of ceil(extent / scale) points per RoI, rotated by theta about the box centre,
+        each point the reference's 8-corner blend  sum_corners feat[corner] * (1 - |dx| |dy| |dz|) / 8  (not a trilinear interpolation;
+        kept as it is), zero outside the map; then adaptive max-pool ('pooling') or a trilinear resize ('interpolation').  Like the
+        reference, the RoI extents are enlarged IN PLACE (its ``enlarge_roi`` writes through the view it is given), so the caller's
+        RoIs -- and the proposals decoded from them afterwards -- are the enlarged ones."""
+        out = []
+        fns = [(a, b, c) for a in (torch.floor, torch.ceil) for b in (torch.floor, torch.ceil) for c in (torch.floor, torch.ceil)]
+        for f, r in zip(features, rois):
+            flat = r.reshape(-1, r.shape[-1])              # a view: the in-place enlargement below reaches the caller's tensor
+            lv = flat[..., 0].long()
+            flat[..., 4:7] = flat[..., 4:7] * (1 + self.enlarge_scale)
+            boxes = flat[..., 1:]
+            pooled = [None] * flat.shape[0]
+            for level in range(len(f)):
+                sel = torch.nonzero(lv == level).view(-1)
+                if sel.numel() == 0:
+                    continue
+                fm = f[level].float()
+                dims = fm.shape
+                lr = boxes[sel].float()
+                sc = float(self.spatial_scale[level])
+                gsz = torch.ceil(lr[:, 3:6] / sc).long().clamp_min(1)
+                mx = [int(v) for v in gsz.max(dim=0).values]
+                grid = torch.stack(torch.meshgrid(*[torch.arange(m, device=lr.device) for m in mx], indexing="ij"), dim=0).reshape(3, -1).float()
+                pos = grid[None].repeat(lr.shape[0], 1, 1) - (gsz[..., None].float() - 1) / 2.0
+                th = lr[:, 6]
+                zero, one = torch.zeros_like(th), torch.ones_like(th)
+                rot = torch.stack([torch.stack([torch.cos(th), -torch.sin(th), zero], dim=1),
+                                   torch.stack([torch.sin(th), torch.cos(th), zero], dim=1),
+                                   torch.stack([zero, zero, one], dim=1)], dim=1)
+                pos = rot @ pos + lr[:, :3, None] / sc                                          # [n, 3, G]
+                p = pos.permute(1, 0, 2).reshape(3, -1)
+                inside = ((p[0] >= 0) & (p[0] <= dims[1] - 1) & (p[1] >= 0) & (p[1] <= dims[2] - 1) & (p[2] >= 0) & (p[2] <= dims[3] - 1))
+                acc = 0.
+                for fa, fb, fc in fns:
+                    q = [fa(p[0]), fb(p[1]), fc(p[2])]
+                    idx = [q[d].clamp(0, dims[d + 1] - 1).long() for d in range(3)]
+                    w = (p[0] - q[0]).abs() * (p[1] - q[1]).abs() * (p[2] - q[2]).abs()
+                    acc = acc + fm[:, idx[0], idx[1], idx[2]] * (1. - w[None])
+                acc = acc * inside[None] / 8
+                acc = acc.reshape(dims[0], lr.shape[0], *mx).permute(1, 0, 2, 3, 4)
+                for k, j in enumerate(sel.tolist()):
+                    g = [int(v) for v in gsz[k]]
+                    crop = acc[k][:, :g[0], :g[1], :g[2]]
+                    if self.feature_extracting_type == "pooling":
+                        pooled[j] = self._adaptive_max_pool(crop)
+                    else:
+                        pooled[j] = F.interpolate(crop[None], size=tuple(self.output_size), mode="trilinear", align_corners=True)[0]
+            out.append(torch.stack(pooled) if pooled else f[0].new_zeros((0, f[0].shape[0], *self.output_size)))
         return out
 
 

@@ -4,8 +4,8 @@ Command-line drop-in for the reference's ``nerf_rpn/run_rpn_detect.py`` (flags, 
 files ``<save_root>/<process_root>/<process_name>/{epoch_N.pt, model_best_ap25.pt, model_best_ap50.pt, eval.json, objectness/<thr>/*.npz}``;
 checkpoint keys ``epoch, backbone_state_dict, RCNN_dict, train_args, optimizer_state_dict, scheduler_state_dict``).  Underneath: HIP kernels
 for the backbone, the RoI <-> GT IoU matrices, rotated 3D RoIAlign and the head convolutions (``model/detector.py``).  torch.optim.AdamW +
-OneCycleLR are kept so optimizer / scheduler state dicts stay interchangeable with the reference's checkpoints.  ``--use_cuda`` is accepted
-and implied: RoI features always come from the RoIAlign kernel.
+OneCycleLR are kept so optimizer / scheduler state dicts stay interchangeable with the reference's checkpoints.  ``--use_cuda`` selects the
+RoIAlign kernel; without it ROIPool runs the reference's default torch pooling (bit-exact restatement, model/detector.py).
 """
 import argparse
 import glob
@@ -73,7 +73,7 @@ def build_parser():
     p.add_argument('--feature_input_dim', default=256, type=int, help='The input dimension of the classification network')
     p.add_argument('--obj_only', action='store_true', help='If true, only train the objectness score.')
     p.add_argument('--enlarge_scale', default=0.2, type=float, help='Control the enlarged ratio of roi')
-    p.add_argument('--use_cuda', action='store_true', help='(implied) RoI features always come from the RoIAlign kernel')
+    p.add_argument('--use_cuda', action='store_true', help='RoI features from the rotated RoIAlign kernel instead of the torch pooling paths')
     p.add_argument('--remap', action='store_true', help='re-map rois to different level')
     p.add_argument('--is_add_layer', action='store_true', help='Add an additional layer to the RCNN')
     p.add_argument('--feature_extracting_type', default='pooling', choices=['pooling', 'interpolation'])

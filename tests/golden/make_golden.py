@@ -439,6 +439,48 @@ def gen_detector():
          gt_rois_all0=gtr_all[0], labels_sampled=lab_s, rois_sampled=rois_s, gt_rois_sampled=gtr_s)
 
 
+def gen_roipool():
+    """ROIPool without the op (reference detector.py:264-438, the CLI default ``use_cuda=False``): AABB integer crops + adaptive max-pool,
+    OBB rotated 8-corner gather + max-pool / trilinear resize, and the in-place enlargement the OBB path leaves in the caller's RoIs."""
+    print("roipool (torch paths)")
+    from model import detector as R_det
+    g = torch.Generator().manual_seed(33)
+    C, scales = 6, [4, 8, 16]
+    feats = [[torch.randn(C, 80 // s, 64 // s, 48 // s, generator=g) for s in scales] for _ in range(2)]
+    orig_get_device = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: "cpu"
+    out = {}
+    try:
+        # OBB rows: (level, x, y, z, w, l, h, theta); some reach over the border (zero outside), some are smaller than one feature voxel
+        obb = []
+        for k in range(2):
+            r = rand_obb(24, g, 4, 60, 3, 40)
+            r[:, 1] = r[:, 1].clamp_max(60)
+            r[:, 2] = r[:, 2].clamp_max(44)
+            r[:4, 3:6] = torch.rand(4, 3, generator=g) * 3 + 0.5
+            obb.append(torch.cat([torch.randint(0, 3, (24, 1), generator=g).float(), r], dim=1))
+        for kind in ("pooling", "interpolation"):
+            pool = R_det.ROIPool([3, 3, 3], scales, enlarge_scale=0.2, is_rotated_bbox=True, feature_extracting_type=kind)
+            rois = torch.stack([r.clone() for r in obb])
+            res = pool(feats, rois)
+            out["obb_" + kind] = torch.stack(res)
+            out["obb_rois_after_" + kind] = rois
+        # AABB rows: (level, x0, y0, z0, x1, y1, z1) inside the grid (the reference slices with python semantics: keep the crops valid)
+        aabb = []
+        for k in range(2):
+            lo = torch.rand(20, 3, generator=g) * torch.tensor([40., 30., 20.]) + 2
+            hi = lo + torch.rand(20, 3, generator=g) * torch.tensor([36., 30., 24.]) + 1
+            aabb.append(torch.cat([torch.randint(0, 3, (20, 1), generator=g).float(), lo, hi], dim=1))
+        pool = R_det.ROIPool([2, 2, 2], scales, enlarge_scale=0.2, is_rotated_bbox=False)
+        out["aabb_pooling"] = torch.stack(pool(feats, [r.clone() for r in aabb]))
+    finally:
+        torch.Tensor.get_device = orig_get_device
+    for k in range(2):
+        for l in range(3):
+            out[f"feat{k}_{l}"] = feats[k][l]
+    save("roipool", obb_rois=torch.stack(obb), aabb_rois=torch.stack(aabb), scales=torch.tensor(scales), **out)
+
+
 def gen_ngp():
     """scripts/proposals2ngp.py: proposals -> instant-ngp bounding boxes (format-only consumer of the proposal files)."""
     print("ngp export")
@@ -802,6 +844,6 @@ def gen_fcos():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "detector", "ngp", "eval", "fullsize", "train", "fcos"]
+    which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "detector", "roipool", "ngp", "eval", "fullsize", "train", "fcos"]
     for w in which:
         globals()["gen_" + w]()

@@ -46,7 +46,46 @@ def test_roipool_samples_the_box_it_is_given(dev):
     assert good.shape == (1, 4, 3, 3, 3) and good.min().item() > 0.95 and bad.mean().item() < 0.8
 
 
-def test_classification_model_forward_backward(dev):
+def test_roipool_torch_paths_on_device(golden, dev):
+    """The reference's default pooling (use_cuda=False) on device tensors against the reference's CPU outputs: the same arithmetic, but the
+    device's sin / cos / division may round the last bit differently, which can move a sample point across an integer -- so not bit-exact
+    here (it is on the CPU: tests/test_harness_cpu.py): >= 99.9 % of the values within 1e-5, every value finite."""
+    from nerf_rpn_amd.model.detector import ROIPool
+    g = golden("roipool")
+    feats = [[T(g[f"feat{k}_{l}"], dev) for l in range(3)] for k in range(2)]
+    scales = [int(v) for v in g["scales"]]
+    for kind in ("pooling", "interpolation"):
+        rois = T(g["obb_rois"], dev).clone()
+        out = torch.stack(ROIPool([3, 3, 3], scales, 0.2, True, kind, use_cuda=False)(feats, rois)).cpu()
+        ref = T(g["obb_" + kind])
+        close = ((out - ref).abs() <= 1e-5 + 1e-5 * ref.abs()).float().mean().item()
+        assert close >= 0.999 and torch.isfinite(out).all(), (kind, close)
+        assert torch.allclose(rois.cpu(), T(g["obb_rois_after_" + kind]), rtol=1e-6)
+    out = torch.stack(ROIPool([2, 2, 2], scales, 0.2, False, use_cuda=False)(feats, [r for r in T(g["aabb_rois"], dev)])).cpu()
+    assert torch.equal(out, T(g["aabb_pooling"]))                # integer crops + max: exact
+
+
+def test_roipool_reference_op_quirks(dev):
+    """reference_op_quirks=True reproduces the two behaviours of the reference's --use_cuda path that the default corrects: rows come out
+    level by level (detector.py:250-259), and the heading is handed over in radians to an op that reads degrees.  With theta = 0 only the
+    order differs: the quirk rows are the default rows gathered level-major."""
+    from nerf_rpn_amd.model.detector import ROIPool
+    g = torch.Generator().manual_seed(5)
+    feats = [[torch.randn(16, s, s, s, generator=g).to(dev) for s in (16, 8, 4)]]
+    box = torch.cat([torch.rand(30, 3, generator=g) * 40 + 12, torch.rand(30, 3, generator=g) * 20 + 4, torch.zeros(30, 1)], dim=1)
+    rois = torch.cat([torch.randint(0, 3, (30, 1), generator=g).float(), box], dim=1).to(dev)
+    a = ROIPool([3, 3, 3], [4, 8, 16], 0.2, True, use_cuda=True, reference_op_quirks=False)([feats[0]], [rois])[0]
+    b = ROIPool([3, 3, 3], [4, 8, 16], 0.2, True, use_cuda=True, reference_op_quirks=True)([feats[0]], [rois])[0]
+    order = torch.cat([torch.nonzero(rois[:, 0] == l).view(-1) for l in range(3)])
+    assert torch.equal(b, a[order]) and not torch.equal(order, torch.arange(30, device=dev))
+    rois[:, 7] = 0.5                                              # 0.5 rad read as 0.5 degrees: almost the unrotated sampling, not the box's
+    c = ROIPool([3, 3, 3], [4, 8, 16], 0.2, True, use_cuda=True, reference_op_quirks=True)([feats[0]], [rois])[0]
+    d = ROIPool([3, 3, 3], [4, 8, 16], 0.2, True, use_cuda=True, reference_op_quirks=False)([feats[0]], [rois])[0]
+    assert (c - b).abs().mean().item() < 0.25 * (d[order] - b).abs().mean().item()
+
+
+@pytest.mark.parametrize("use_cuda", [True, False])
+def test_classification_model_forward_backward(dev, use_cuda):
     from nerf_rpn_amd.model.detector import Classification_Model, ProposalTargetLayer, RCNN, ROIPool
     from nerf_rpn_amd.model.feature_extractor import Bottleneck
     torch.manual_seed(0)
@@ -58,7 +97,7 @@ def test_classification_model_forward_backward(dev):
                       torch.rand(40, 7, generator=g).to(dev) * torch.tensor([70, 70, 70, 20, 20, 20, 1.], device=dev) + 4])
     rois = torch.cat([torch.randint(0, 4, (100, 1), generator=g).float().to(dev), rois], dim=1)
     model = Classification_Model(None, ProposalTargetLayer(2, batch_size=64, fg_threshold=0.35, bg_threshold=0.15, is_rotated_bbox=True),
-                                 ROIPool([3, 3, 3], [4, 8, 16, 32], 0.2, is_rotated_bbox=True),
+                                 ROIPool([3, 3, 3], [4, 8, 16, 32], 0.2, is_rotated_bbox=True, use_cuda=use_cuda),
                                  RCNN(256, Bottleneck, 2, [3, 3, 3], is_add_layer=True, is_rotated_bbox=True, is_flatten=True),
                                  is_rotated_bbox=True).to(dev).train()
     (boxes, labels), probs, losses = model([rois], [gt], [torch.ones(2, device=dev)], feats)

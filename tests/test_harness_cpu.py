@@ -5,6 +5,7 @@ import os
 import random
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -104,3 +105,24 @@ def test_ngp_box_export_matches_reference(tmp_path):
             "--proposals_path", str(tmp_path / "p"), "--output_dir", str(tmp_path / "o")])
     out = json.load(open(tmp_path / "o" / "s.json"))
     assert len(out["bounding_boxes"]) == 4 and out["bounding_boxes"][0]["score"] > out["bounding_boxes"][-1]["score"] > 0.5
+
+
+def test_roipool_torch_paths_match_reference(golden):
+    """ROIPool(use_cuda=False) -- the reference CLI's default pooling -- against outputs of the reference itself
+    (tests/golden/make_golden.py::gen_roipool): bit-exact features for OBB 'pooling' / 'interpolation' and AABB crops, and the caller's OBB
+    RoIs come back enlarged in place exactly as the reference leaves them (detector.py:195-201, 281)."""
+    from nerf_rpn_amd.model.detector import ROIPool
+    g = golden("roipool")
+    T = lambda k: torch.from_numpy(g[k])
+    feats = [[T(f"feat{k}_{l}") for l in range(3)] for k in range(2)]
+    scales = [int(v) for v in g["scales"]]
+    for kind in ("pooling", "interpolation"):
+        rois = T("obb_rois").clone()
+        out = torch.stack(ROIPool([3, 3, 3], scales, 0.2, True, kind, use_cuda=False)(feats, rois))
+        assert torch.equal(out, T("obb_" + kind)), kind
+        assert torch.equal(rois, T("obb_rois_after_" + kind)) and not torch.equal(rois, T("obb_rois"))
+    aabb = T("aabb_rois")
+    out = torch.stack(ROIPool([2, 2, 2], scales, 0.2, False, use_cuda=False)(feats, [r for r in aabb]))
+    assert torch.equal(out, T("aabb_pooling")) and torch.equal(aabb, T("aabb_rois"))
+    with pytest.raises(NameError):
+        ROIPool([2, 2, 2], scales, 0.2, True, "nearest", use_cuda=False)
