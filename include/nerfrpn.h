@@ -101,6 +101,12 @@ int nrpn_nms3d(const float *boxes, const int32_t *levels, const int32_t *d_count
  * ---------------------------------------------------------------------------------------------- */
 int nrpn_segmented_topk_f32(const float *scores, const int64_t *h_offsets, int nseg, int k,
                             int32_t *out_idx, float *out_val, nrpn_stream_t stream);
+/* Same contract and results; segments of >= 65536 scores are selected by up to 256 workgroups (histogram / collect / tie / sort
+ * launches, integer atomics only) instead of one.  `workspace`: nrpn_segmented_topk_workspace_bytes(nseg, k) bytes of device memory
+ * (contents irrelevant, overwritten). */
+size_t nrpn_segmented_topk_workspace_bytes(int nseg, int k);
+int nrpn_segmented_topk_f32_ws(const float *scores, const int64_t *h_offsets, int nseg, int k,
+                               int32_t *out_idx, float *out_val, void *workspace, size_t workspace_bytes, nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Anchors and box coders.  [a8, a10, a11, a12]

@@ -4,6 +4,7 @@
 // ballots/shuffles for reductions, LDS for the per-workgroup sort and the NMS row blocks.
 #include "geometry.cuh"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstring>
 #include <map>
@@ -161,15 +162,44 @@ extern "C" int nrpn_iou3d_matrix_f32(const float *a, const float *b, float *iou,
 constexpr int kMaxNms = 16384;
 constexpr int kNmsLevels = 64;
 
+// Rotated pairs are expensive (two sin/cos, 16 edge-edge tests, an 8-pick angular selection sort: ~2k instructions) and almost all pairs
+// of a tile are far apart, so a tile is worked in two phases: (1) lane = row: a cheap test per column that PROVES the full IoU would be
+// exactly 0 -- equal expression for the z overlap (zov == 0 => inter3 = iou2 * u2 * 0 = 0), or BEV circumcircles separated by a 1e-3
+// relative margin (no corner inside the other rectangle, no edge crossing => fewer than 3 vertices => area 0) -- on boxes whose numbers
+// are ordinary (finite, positive extents: anything else goes to the full computation, whose NaN / inf results suppress as before);
+// (2) the surviving (row, column) pairs are compacted into an LDS list and the 64 lanes take them round-robin, so every lane of the
+// wave runs the full IoU on a real candidate.  The decisions are those of the one-lane-per-row loop, bit for bit.
+__device__ __forceinline__ bool obb_ordinary(const float *b) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) ok = ok && (fabsf(b[k]) < 1e15f);      // also false for NaN / inf
+  return ok && b[3] > 1e-15f && b[4] > 1e-15f && b[5] > 1e-15f;
+}
+
+__device__ __forceinline__ bool obb_surely_disjoint(const float *p, const float *q) {
+  const float zt1 = p[2] + p[5] * 0.5f, zb1 = p[2] - p[5] * 0.5f;
+  const float zt2 = q[2] + q[5] * 0.5f, zb2 = q[2] - q[5] * 0.5f;
+  const float zov = fmaxf(fminf(zt1, zt2) - fmaxf(zb1, zb2), 0.f);   // the expression of iou3d_obb
+  if (zov == 0.f) return true;
+  const float dx = p[0] - q[0], dy = p[1] - q[1];
+  const float d = sqrtf(dx * dx + dy * dy);
+  const float r = 0.5f * (sqrtf(p[3] * p[3] + p[4] * p[4]) + sqrtf(q[3] * q[3] + q[4] * q[4]));
+  return d - r > 1e-3f * (r + fabsf(p[0]) + fabsf(p[1]) + fabsf(q[0]) + fabsf(q[1]) + 1.f);
+}
+
 template <int W>
-__global__ void nms_mask_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ levels,
+__global__ void __launch_bounds__(64)
+nms_mask_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ levels,
                                 const int32_t *__restrict__ d_count, int n_max, float thr, unsigned long long *__restrict__ mask,
                                 int words) {
   const int n = d_count ? min(*d_count, n_max) : n_max;
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
   __shared__ float cbox[64][W + 1];
+  __shared__ float rbox[64][W + 1];
   __shared__ int clev[64];
+  __shared__ unsigned long long bits_sh[64];
+  __shared__ unsigned short pairs[64 * 64];
   const int t = threadIdx.x;
   const int c = cb * 64 + t;
   if (c < n) {
@@ -177,26 +207,76 @@ __global__ void nms_mask_kernel(const float *__restrict__ boxes, const int32_t *
     for (int k = 0; k < W; ++k) cbox[t][k] = boxes[(int64_t)c * W + k];
     clev[t] = levels ? levels[c] : 0;
   }
-  __syncthreads();
   const int r = rb * 64 + t;
-  if (r >= n) return;
   float me[W];
 #pragma unroll
-  for (int k = 0; k < W; ++k) me[k] = boxes[(int64_t)r * W + k];
-  const int mylev = levels ? levels[r] : 0;
-  const int cend = min(64, n - cb * 64);
-  unsigned long long bits = 0ull;
-  for (int j = 0; j < cend; ++j) {
-    const int col = cb * 64 + j;
-    if (col > r && clev[j] == mylev) {
-      float other[W];
+  for (int k = 0; k < W; ++k) me[k] = (r < n) ? boxes[(int64_t)r * W + k] : 0.f;
 #pragma unroll
-      for (int k = 0; k < W; ++k) other[k] = cbox[j][k];
-      const float v = geo::iou3d<W>(me, other);
-      if (!(v <= thr)) bits |= (1ull << j);
+  for (int k = 0; k < W; ++k) rbox[t][k] = me[k];
+  bits_sh[t] = 0ull;
+  __syncthreads();
+  const int mylev = (levels && r < n) ? levels[r] : 0;
+  const int cend = min(64, n - cb * 64);
+  if (W == 6) {
+    if (r >= n) return;
+    unsigned long long bits = 0ull;
+    for (int j = 0; j < cend; ++j) {
+      const int col = cb * 64 + j;
+      if (col > r && clev[j] == mylev) {
+        float other[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) other[k] = cbox[j][k];
+        const float v = geo::iou3d<W>(me, other);
+        if (!(v <= thr)) bits |= (1ull << j);
+      }
+    }
+    mask[(int64_t)r * words + cb] = bits;
+    return;
+  }
+  // phase 1: candidate columns of my row
+  unsigned long long cand = 0ull;
+  if (r < n) {
+    const bool prefilter = (thr >= 0.f) && obb_ordinary(me);
+    for (int j = 0; j < cend; ++j) {
+      const int col = cb * 64 + j;
+      if (col > r && clev[j] == mylev) {
+        float other[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) other[k] = cbox[j][k];
+        const bool skip = prefilter && obb_ordinary(other) && obb_surely_disjoint(me, other);
+        if (!skip) cand |= (1ull << j);
+      }
     }
   }
-  mask[(int64_t)r * words + cb] = bits;
+  // phase 2: compaction (wave-wide inclusive scan of the per-row counts)
+  const int cnt = __popcll(cand);
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if (t >= off) incl += up;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int pos = incl - cnt;
+  unsigned long long rest = cand;
+  while (rest) {
+    const int j = __ffsll((long long)rest) - 1;
+    rest &= rest - 1;
+    pairs[pos++] = (unsigned short)((t << 6) | j);
+  }
+  __syncthreads();
+  // phase 3: the full IoU of the surviving pairs, one pair per lane per round
+  for (int q = t; q < total; q += 64) {
+    const int pr = pairs[q];
+    const int rl = pr >> 6, j = pr & 63;
+    float a[W], b[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { a[k] = rbox[rl][k]; b[k] = cbox[j][k]; }
+    const float v = geo::iou3d<W>(a, b);
+    if (!(v <= thr)) atomicOr(&bits_sh[rl], 1ull << j);
+  }
+  __syncthreads();
+  if (r < n) mask[(int64_t)r * words + cb] = bits_sh[t];
 }
 
 __global__ void __launch_bounds__(256)
@@ -434,6 +514,233 @@ extern "C" int nrpn_segmented_topk_f32(const float *scores, const int64_t *h_off
     NRPN_REQUIRE(h_offsets[s + 1] >= h_offsets[s] && h_offsets[s + 1] < (1ll << 31), "topk: bad segment %d", s);
     hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), lds, as_stream(stream), scores, (long long)h_offsets[s],
                        (long long)h_offsets[s + 1], k, P, out_idx + (int64_t)s * k, out_val + (int64_t)s * k);
+  }
+  NRPN_LAUNCH_CHECK("topk");
+  return NRPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Long segments (level 0 of a 200 x 200 x 130 scene holds ~1.07 M scores): the single workgroup above walks the segment five
+// times (2.2 ms).  Same selection, spread over G workgroups of 256 lanes, each on a contiguous slice:
+//   hist x3   LDS histogram of the slice for the current digit -> integer atomics into the segment's global histogram
+//             (the digits already fixed are re-derived by every workgroup from the finished histograms: no host round trip);
+//   collect   keys above the k-th key T go to the item list through one atomic counter (their order is irrelevant: the
+//             final sort orders (key, index)); the slice's count of keys == T is written per workgroup;
+//   ties      the `need` smallest indices among the keys == T: slice order = index order, ranks from the per-slice counts;
+//   sort      one workgroup: bitonic sort of the k items in LDS, outputs as above.
+// Integer atomics only: every run produces the same histogram, the same T, the same set and the same order.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTopkSliceThreads = 256;
+constexpr int kTopkMaxSlices = 256;
+constexpr int kTopkLongSegment = 65536;
+struct TopkWs {                 // per segment, in the caller's workspace (zeroed by the launcher)
+  int hist[3][2048];
+  int count_above;              // atomic slot counter of the collect pass
+  int pad[3];
+  int ties[kTopkMaxSlices];     // keys == T per slice
+};
+
+// digit of the need-th largest element of a histogram (bins descending) with 256 lanes; returns through shared memory
+__device__ __forceinline__ void topk_select_digit(const int *hist, int nb, int need, int *scratch, int *sh_out) {
+  const int t = threadIdx.x;
+  const int per = 2048 / kTopkSliceThreads;       // 8 bins per lane
+  int c[per], mine = 0;
+#pragma unroll
+  for (int i = 0; i < per; ++i) { const int b = t * per + i; c[i] = (b < nb) ? hist[b] : 0; mine += c[i]; }
+  scratch[t] = mine;
+  __syncthreads();
+  for (int off = 1; off < kTopkSliceThreads; off <<= 1) {
+    const int add = (t >= off) ? scratch[t - off] : 0;
+    __syncthreads();
+    scratch[t] += add;
+    __syncthreads();
+  }
+  const int total = scratch[kTopkSliceThreads - 1];
+  int above = total - scratch[t];               // elements in bins above my eight
+  __syncthreads();
+#pragma unroll
+  for (int i = per - 1; i >= 0; --i) {
+    if (above < need && need <= above + c[i]) { sh_out[0] = t * per + i; sh_out[1] = need - above; }
+    above += c[i];
+  }
+  __syncthreads();
+}
+
+// (prefix, pmask, need) after `passes` finished histograms
+__device__ __forceinline__ void topk_resolve(const TopkWs *ws, int k, int passes, int *scratch, int *sh_out, unsigned *prefix,
+                                             unsigned *pmask, int *need) {
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  *prefix = 0; *pmask = 0; *need = k;
+  for (int p = 0; p < passes; ++p) {
+    const int nb = 1 << bits[p];
+    topk_select_digit(ws->hist[p], nb, *need, scratch, sh_out);
+    *prefix |= ((unsigned)sh_out[0]) << shifts[p];
+    *pmask |= ((unsigned)(nb - 1)) << shifts[p];
+    *need = sh_out[1];
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(kTopkSliceThreads)
+topk_hist_kernel(const float *__restrict__ scores, long long seg_begin, long long seg_end, int k, int pass, TopkWs *__restrict__ ws) {
+  __shared__ int hist[2048];
+  __shared__ int scratch[kTopkSliceThreads];
+  __shared__ int sh_out[2];
+  const int t = threadIdx.x;
+  const long long n = seg_end - seg_begin;
+  const float *s = scores + seg_begin;
+  unsigned prefix, pmask;
+  int need;
+  topk_resolve(ws, k, pass, scratch, sh_out, &prefix, &pmask, &need);
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  const int nb = 1 << bits[pass], shift = shifts[pass];
+  for (int i = t; i < 2048; i += kTopkSliceThreads) hist[i] = 0;
+  __syncthreads();
+  const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+  const long long lo = min(n, (long long)blockIdx.x * chunk), hi = min(n, lo + chunk);
+  for (long long i = lo + t; i < hi; i += kTopkSliceThreads) {
+    const unsigned key = f2key(s[i]);
+    if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1);
+  }
+  __syncthreads();
+  for (int i = t; i < nb; i += kTopkSliceThreads)
+    if (hist[i]) atomicAdd(&ws->hist[pass][i], hist[i]);
+}
+
+__global__ void __launch_bounds__(kTopkSliceThreads)
+topk_collect_kernel(const float *__restrict__ scores, long long seg_begin, long long seg_end, int k, TopkWs *__restrict__ ws,
+                    unsigned long long *__restrict__ items) {
+  __shared__ int scratch[kTopkSliceThreads];
+  __shared__ int sh_out[2];
+  __shared__ int sh_ties;
+  const int t = threadIdx.x;
+  const long long n = seg_end - seg_begin;
+  const float *s = scores + seg_begin;
+  unsigned T, pmask;
+  int need;
+  topk_resolve(ws, k, 3, scratch, sh_out, &T, &pmask, &need);
+  if (t == 0) sh_ties = 0;
+  __syncthreads();
+  const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+  const long long lo = min(n, (long long)blockIdx.x * chunk), hi = min(n, lo + chunk);
+  int ties = 0;
+  for (long long i = lo + t; i < hi; i += kTopkSliceThreads) {
+    const unsigned key = f2key(s[i]);
+    if (key > T) {
+      const int slot = atomicAdd(&ws->count_above, 1);      // k - need of them in the whole segment
+      items[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+    ties += (key == T) ? 1 : 0;
+  }
+  if (ties) atomicAdd(&sh_ties, ties);
+  __syncthreads();
+  if (t == 0) ws->ties[blockIdx.x] = sh_ties;
+}
+
+__global__ void __launch_bounds__(kTopkSliceThreads)
+topk_ties_kernel(const float *__restrict__ scores, long long seg_begin, long long seg_end, int k, const TopkWs *__restrict__ ws,
+                 unsigned long long *__restrict__ items) {
+  __shared__ int scratch[kTopkSliceThreads];
+  __shared__ int sh_out[2];
+  const int t = threadIdx.x;
+  const long long n = seg_end - seg_begin;
+  const float *s = scores + seg_begin;
+  unsigned T, pmask;
+  int need;
+  topk_resolve(ws, k, 3, scratch, sh_out, &T, &pmask, &need);
+  int before = 0;                                            // ties in the slices in front of mine
+  for (int g = t; g < (int)blockIdx.x; g += kTopkSliceThreads) before += ws->ties[g];
+  scratch[t] = before;
+  __syncthreads();
+  for (int off = kTopkSliceThreads / 2; off > 0; off >>= 1) {
+    if (t < off) scratch[t] += scratch[t + off];
+    __syncthreads();
+  }
+  before = scratch[0];
+  __syncthreads();
+  if (before >= need) return;                                // uniform over the workgroup
+  const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+  const long long lo = min(n, (long long)blockIdx.x * chunk), hi = min(n, lo + chunk);
+  const long long sub = (hi - lo + kTopkSliceThreads - 1) / kTopkSliceThreads;
+  const long long a = min(hi, lo + (long long)t * sub), b = min(hi, a + sub);
+  int mine = 0;
+  for (long long i = a; i < b; ++i) mine += (f2key(s[i]) == T) ? 1 : 0;
+  scratch[t] = mine;
+  __syncthreads();
+  for (int off = 1; off < kTopkSliceThreads; off <<= 1) {
+    const int add = (t >= off) ? scratch[t - off] : 0;
+    __syncthreads();
+    scratch[t] += add;
+    __syncthreads();
+  }
+  int rank = before + scratch[t] - mine;
+  const int base = k - need;
+  for (long long i = a; i < b && rank < need; ++i) {
+    if (f2key(s[i]) == T) {
+      items[base + rank] = ((unsigned long long)T << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+      ++rank;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kTopkThreads)
+topk_sort_kernel(const unsigned long long *__restrict__ items_in, long long seg_begin, int k, int P, int32_t *__restrict__ out_idx,
+                 float *__restrict__ out_val) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+  const int t = threadIdx.x;
+  for (int i = t; i < P; i += kTopkThreads) lds64[i] = (i < k) ? items_in[i] : 0ull;
+  __syncthreads();
+  bitonic_sort_desc(lds64, P);
+  for (int i = t; i < k; i += kTopkThreads) {
+    const unsigned long long it = lds64[i];
+    out_idx[i] = (int32_t)(seg_begin + (long long)(0xFFFFFFFFu - (unsigned)(it & 0xFFFFFFFFull)));
+    out_val[i] = key2f((unsigned)(it >> 32));
+  }
+}
+
+extern "C" size_t nrpn_segmented_topk_workspace_bytes(int nseg, int k) {
+  if (nseg <= 0 || k <= 0) return 0;
+  return (size_t)nseg * (sizeof(TopkWs) + (size_t)next_pow2(k) * 8);
+}
+
+extern "C" int nrpn_segmented_topk_f32_ws(const float *scores, const int64_t *h_offsets, int nseg, int k, int32_t *out_idx,
+                                          float *out_val, void *workspace, size_t workspace_bytes, nrpn_stream_t stream) {
+  NRPN_REQUIRE(nseg >= 0 && k >= 1 && k <= 16384, "topk: bad nseg=%d k=%d", nseg, k);
+  if (nseg == 0) return NRPN_OK;
+  NRPN_REQUIRE(scores && h_offsets && out_idx && out_val, "topk: null pointer");
+  const int P = next_pow2(k);
+  bool any_long = false;
+  for (int s = 0; s < nseg; ++s) {
+    NRPN_REQUIRE(h_offsets[s + 1] >= h_offsets[s] && h_offsets[s + 1] < (1ll << 31), "topk: bad segment %d", s);
+    any_long = any_long || (h_offsets[s + 1] - h_offsets[s] >= kTopkLongSegment && h_offsets[s + 1] - h_offsets[s] > k);
+  }
+  hipStream_t st = as_stream(stream);
+  TopkWs *heads = reinterpret_cast<TopkWs *>(workspace);
+  unsigned long long *items = reinterpret_cast<unsigned long long *>(heads + nseg);
+  if (any_long) {
+    NRPN_REQUIRE(workspace && workspace_bytes >= nrpn_segmented_topk_workspace_bytes(nseg, k), "topk: workspace too small");
+    NRPN_HIP(hipMemsetAsync(heads, 0, sizeof(TopkWs) * (size_t)nseg, st));
+  }
+  const size_t lds = (size_t)P * 8 + 2048 * 4 + 1024 * 4;
+  NRPN_LDS(topk_kernel, 16384 * 8 + 2048 * 4 + 1024 * 4);
+  NRPN_LDS(topk_sort_kernel, 16384 * 8);
+  for (int s = 0; s < nseg; ++s) {
+    const long long b = h_offsets[s], e = h_offsets[s + 1], n = e - b;
+    if (n < kTopkLongSegment || n <= k) {
+      hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), lds, st, scores, b, e, k, P, out_idx + (int64_t)s * k,
+                         out_val + (int64_t)s * k);
+      continue;
+    }
+    const int G = (int)std::min<long long>(kTopkMaxSlices, (n + 4095) / 4096);
+    unsigned long long *it = items + (size_t)s * P;
+    for (int pass = 0; pass < 3; ++pass)
+      hipLaunchKernelGGL(topk_hist_kernel, dim3(G), dim3(kTopkSliceThreads), 0, st, scores, b, e, k, pass, heads + s);
+    hipLaunchKernelGGL(topk_collect_kernel, dim3(G), dim3(kTopkSliceThreads), 0, st, scores, b, e, k, heads + s, it);
+    hipLaunchKernelGGL(topk_ties_kernel, dim3(G), dim3(kTopkSliceThreads), 0, st, scores, b, e, k, heads + s, it);
+    hipLaunchKernelGGL(topk_sort_kernel, dim3(1), dim3(kTopkThreads), (size_t)P * 8, st, it, b, k, P, out_idx + (int64_t)s * k,
+                       out_val + (int64_t)s * k);
   }
   NRPN_LAUNCH_CHECK("topk");
   return NRPN_OK;

@@ -235,7 +235,9 @@ def segmented_topk(scores, offsets, k):
     idx = torch.empty((nseg, k), dtype=torch.int32, device=scores.device)
     val = torch.empty((nseg, k), dtype=torch.float32, device=scores.device)
     host = (ctypes.c_int64 * (nseg + 1))(*[int(o) for o in offsets])
-    call("segmented_topk_f32", _p(scores), ctypes.addressof(host), nseg, int(k), _p(idx), _p(val), _s())
+    nbytes = int(lib.query("segmented_topk_workspace_bytes", nseg, int(k)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=scores.device)
+    call("segmented_topk_f32_ws", _p(scores), ctypes.addressof(host), nseg, int(k), _p(idx), _p(val), _p(ws), nbytes, _s())
     return idx, val
 
 

@@ -125,6 +125,76 @@ def test_topk_order(dev):
     assert idx[0].tolist() == list(range(2500))
 
 
+def test_topk_long_segments_match_the_single_workgroup_kernel(dev):
+    """Segments of >= 65536 scores take the multi-workgroup selection (histograms with integer atomics, collect, ties, sort): the same
+    rows as the one-workgroup kernel behind the old entry point and as a stable descending sort, on quantised scores (thousands of ties
+    around the k-th key), -inf runs, NaNs, and a segment one element over the switch."""
+    import ctypes
+    from nerf_rpn_amd import lib, ops
+    gen = torch.Generator().manual_seed(11)
+    n0 = 200 * 200 * 130 // 64 * 13 + 7                      # ~1.06 M: level 0 of the 200 x 200 x 130 benchmark scene
+    x = torch.randn(n0 + 65537 + 300000 + 5000, generator=gen)
+    x[:n0] = (x[:n0] * 64).round() / 64                        # ~500 distinct values
+    x[n0 + 1000:n0 + 30000] = float("-inf")
+    x[n0 + 65537 + 5:n0 + 65537 + 300000:7] = 0.5
+    x[n0 + 65537 + 11] = float("nan")
+    offs = [0, n0, n0 + 65537, n0 + 65537 + 300000, x.numel()]
+    xd = x.to(dev)
+    for k in (2500, 16384, 1000):
+        idx, val = ops.segmented_topk(xd, offs, k)
+        old_idx = torch.empty_like(idx)
+        old_val = torch.empty_like(val)
+        host = (ctypes.c_int64 * len(offs))(*offs)
+        lib.call("segmented_topk_f32", xd.data_ptr(), ctypes.addressof(host), len(offs) - 1, k, old_idx.data_ptr(), old_val.data_ptr(),
+                 torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(idx, old_idx) and torch.equal(val.nan_to_num(7.0), old_val.nan_to_num(7.0)), k
+        for s_ in (0, 1, 3):                                   # segments without NaN: (score desc, index asc) = stable descending sort
+            seg = x[offs[s_]:offs[s_ + 1]]
+            kk = min(k, seg.numel())
+            order = torch.sort(seg, descending=True, stable=True).indices[:kk]
+            assert torch.equal(idx[s_, :kk].cpu().long(), order + offs[s_]), (k, s_)
+    again, _ = ops.segmented_topk(xd, offs, 2500)
+    first, _ = ops.segmented_topk(xd, offs, 2500)
+    assert torch.equal(again, first)                           # atomics on integers only: run-to-run identical
+
+
+def test_nms_prefilter_keeps_every_decision(dev):
+    """The rotated mask kernel skips pairs whose IoU is provably 0 and compacts the rest: keep masks must equal a greedy pass over the
+    full IoU matrix (same device IoU function, every pair) with the `not (iou <= thr)` rule -- on clustered boxes plus degenerate rows
+    (zero / negative extents, NaN, inf, huge) that must bypass the prefilter, and for a negative threshold (prefilter off)."""
+    from nerf_rpn_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    n = 1500
+    ctr = torch.rand(12, 3, generator=gen) * 120 + 20
+    c = ctr[torch.randint(0, 12, (n,), generator=gen)] + torch.randn(n, 3, generator=gen) * 6
+    sz = torch.rand(n, 3, generator=gen) * 24 + 3
+    th = (torch.rand(n, 1, generator=gen) - 0.5) * 3.1
+    b = torch.cat([c, sz, th], dim=1)
+    b[5, 3] = 0.0
+    b[17, 3:6] = 0.0
+    b[18] = b[17]
+    b[40, 4] = -3.0
+    b[77, 0] = float("nan")
+    b[90, 5] = float("inf")
+    b[130, 1] = 3e18
+    b[200] = b[199]
+    lv = torch.sort(torch.randint(0, 3, (n,), generator=gen)).values.to(torch.int32)
+    bd, ld = b.to(dev), lv.to(dev)
+    iou = ops.iou3d_matrix(bd, bd).cpu()
+    for thr in (0.3, 0.0, -0.5):
+        keep = ops.nms3d_sorted(bd, ld, thr).cpu().bool()
+        ref = torch.zeros(n, dtype=torch.bool)
+        dead = torch.zeros(n, dtype=torch.bool)
+        for i in range(n):
+            if dead[i]:
+                continue
+            ref[i] = True
+            sup = ~(iou[i] <= thr) & (lv == lv[i])
+            sup[:i + 1] = False
+            dead |= sup
+        assert torch.equal(keep, ref), thr
+
+
 def test_anchors_and_coders(golden, dev):
     from nerf_rpn_amd import ops
     from nerf_rpn_amd.model.coder import AABBCoder, MidpointOffsetCoder
