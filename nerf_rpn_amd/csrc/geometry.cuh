@@ -30,6 +30,24 @@ __device__ __forceinline__ bool vert_before(float x1, float y1, float x2, float 
   return false;  // y == 0 on either side: undefined in the reference, defined false
 }
 
+// The same predicate with the per-vertex term |x| x / (x^2 + y^2 + 1e-8) computed once per vertex (q1, q2) instead of inside every
+// comparison of the selection sort (8 picks x 24 candidates x 2 comparisons, each with two divisions and an fp64 round trip): the
+// operations and their order per term are those of vert_before, so d = q1 - q2 is the same float.
+__device__ __forceinline__ float vert_q(float x, float y) {
+  const float n = (float)((double)(x * x + y * y) + 1e-8);
+  return fabsf(x) * x / n;
+}
+// Branch-free (the early returns of vert_before are mutually exclusive cases): one lane per box pair runs this 8 x 24 x 2 times, and
+// as control flow it compiled to ~125 instructions and a dozen exec-mask branches per candidate.
+__device__ __forceinline__ bool vert_before_q(float x1, float y1, float q1, float x2, float y2, float q2) {
+  const float e = (float)1e-8;
+  const bool same = (fabsf(x1 - x2) <= e) & (fabsf(y2 - y1) <= e);
+  const bool up1 = y1 > 0.f, dn1 = y1 < 0.f, up2 = y2 > 0.f, dn2 = y2 < 0.f;
+  const float d = q1 - q2;
+  const bool r = (up1 & dn2) | (up1 & up2 & (d > e)) | (dn1 & dn2 & (d <= e));
+  return (!same) & r;
+}
+
 __device__ __forceinline__ void corners2d(float cx, float cy, float w, float h, float a, float *X, float *Y) {
   const float s = sinf(a), c = cosf(a);
   const float sx[4] = {0.5f, -0.5f, -0.5f, 0.5f};
@@ -97,35 +115,39 @@ __device__ __forceinline__ float rect_intersection_area(const float *AX, const f
   if (nv < 3) return 0.f;  // every slot is the zero pad vertex
   mx /= (float)nv;
   my /= (float)nv;
-  float nx[24], ny[24];
+  float nx[24], ny[24], nq[24];
 #pragma unroll
-  for (int k = 0; k < 24; ++k) { nx[k] = ox[k] - mx; ny[k] = oy[k] - my; }
+  for (int k = 0; k < 24; ++k) { nx[k] = ox[k] - mx; ny[k] = oy[k] - my; nq[k] = vert_q(nx[k], ny[k]); }
+  const float q_start = vert_q(1.0f, (float)(-1e-8));
   if (nv > 8) nv = 8;
   // Selection sort by angle (runtime loop over the <= 8 picks, the 24-candidate scan unrolled), with the shoelace sum
   // accumulated on the fly from the *original* coordinates of consecutive picks.
   float fx = 0.f, fy = 0.f;      // first pick (original coords)
   float qx = 0.f, qy = 0.f;      // previous pick (original coords)
-  float px = 0.f, py = 0.f;      // previous pick (normalised coords)
+  float px = 0.f, py = 0.f, pq = 0.f;      // previous pick (normalised coords, its vert_q)
   float total = 0.f, total4 = 0.f;
   int k0 = -1, k1 = -1, k2 = -1, k3 = -1, dup = 0;
 #pragma unroll 1
   for (int j = 0; j < nv; ++j) {
-    float bx = 1.0f, by = (float)(-1e-8);
-    float tx = ox[0], ty = oy[0], tnx = nx[0], tny = ny[0];
+    // (bx, by, bq) = best so far, starting from the reference's sentinel; until a candidate wins the pick is vertex 0
+    float bx = 1.0f, by = (float)(-1e-8), bq = q_start;
+    float tx = ox[0], ty = oy[0], tnx = nx[0], tny = ny[0], tq = nq[0];
     int take = 0;
+    const bool first = (j == 0);
 #pragma unroll
     for (int k = 0; k < 24; ++k) {
-      bool c = ok[k] && vert_before(nx[k], ny[k], bx, by);
-      if (j > 0) c = c && vert_before(px, py, nx[k], ny[k]);
-      if (c) { bx = nx[k]; by = ny[k]; tx = ox[k]; ty = oy[k]; tnx = nx[k]; tny = ny[k]; take = k; }
+      const bool c = ok[k] & vert_before_q(nx[k], ny[k], nq[k], bx, by, bq) & (first | vert_before_q(px, py, pq, nx[k], ny[k], nq[k]));
+      bx = c ? nx[k] : bx; by = c ? ny[k] : by; bq = c ? nq[k] : bq;
+      tx = c ? ox[k] : tx; ty = c ? oy[k] : ty; take = c ? k : take;
     }
+    if (take != 0) { tnx = bx; tny = by; tq = bq; }      // take == 0: nobody won, or vertex 0 won -- (tnx, tny) is vertex 0 either way
     if (j == 0) { fx = tx; fy = ty; k0 = take; }
     else total += qx * ty - qy * tx;
     if (j == 1) k1 = take;
     if (j == 2) k2 = take;
     if (j == 3) { k3 = take; total4 = total + (tx * fy - ty * fx); }
     if (j >= 4) dup += (take == k0) + (take == k1) + (take == k2) + (take == k3);
-    qx = tx; qy = ty; px = tnx; py = tny;
+    qx = tx; qy = ty; px = tnx; py = tny; pq = tq;
   }
   total += qx * fy - qy * fx;  // close the polygon
   // identical boxes: the 8 corners coincide pairwise and the first four picks already are the polygon

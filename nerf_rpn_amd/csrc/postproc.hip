@@ -109,7 +109,7 @@ extern "C" int nrpn_sort_vertices_f32(const float *vertices, const uint8_t *mask
 // =====================================================================================================================
 // IoU: paired and all-pairs
 // =====================================================================================================================
-__global__ void iou_pair_obb_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int64_t n) {
+__global__ void __launch_bounds__(64) iou_pair_obb_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float p[7], q[7];
@@ -119,7 +119,7 @@ __global__ void iou_pair_obb_kernel(const float *__restrict__ a, const float *__
 }
 
 template <int W>
-__global__ void iou_matrix_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int64_t n,
+__global__ void __launch_bounds__(64) iou_matrix_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int64_t n,
                                   int64_t m) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = blockIdx.y;
@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(256)
 nms_scan_kernel(const int32_t *__restrict__ levels, const int32_t *__restrict__ d_count, int n_max,
                 const unsigned long long *__restrict__ mask, int words, uint8_t *__restrict__ keep) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+  __shared__ unsigned long long sh_kept;
   const int n = d_count ? min(*d_count, n_max) : n_max;
   const int lev = blockIdx.x;
   // [s, e): rows whose level == lev (levels is non-decreasing); without levels block 0 owns everything
@@ -300,7 +301,7 @@ nms_scan_kernel(const int32_t *__restrict__ levels, const int32_t *__restrict__ 
   }
   if (s >= e) return;
   const int w0 = s >> 6, w1 = (e - 1) >> 6, nw = w1 - w0 + 1;
-  volatile unsigned long long *removed = lds64;  // [nw]
+  unsigned long long *removed = lds64;          // [nw]
   unsigned long long *rows = lds64 + nw;        // [64][nw]
   const int tid = threadIdx.x;
   for (int w = tid; w < nw; w += blockDim.x) removed[w] = 0ull;
@@ -316,17 +317,39 @@ nms_scan_kernel(const int32_t *__restrict__ levels, const int32_t *__restrict__ 
     }
     __syncthreads();
     if (tid < 64) {
+      // the 64 sequential decisions of the block on its diagonal word, in scalar registers: lane l holds row l's diagonal word,
+      // R = the suppression word of these 64 rows so far (uniform), row rr is kept iff its bit in R is still clear
+      const int row = b0 + tid;
+      const bool valid = row >= s && row < e;
+      const unsigned long long D = valid ? rows[tid * nw + (bw - w0)] : 0ull;
+      const unsigned long long V = __ballot(valid);
+      unsigned long long R = removed[bw - w0];
+      unsigned long long K = 0ull;
+      const int dlo = (int)(unsigned)D, dhi = (int)(unsigned)(D >> 32);
+#pragma unroll
       for (int rr = 0; rr < 64; ++rr) {
-        const int row = b0 + rr;
-        if (row < s || row >= e) continue;
-        const unsigned long long word = removed[(row >> 6) - w0];
-        const bool dead = (word >> (row & 63)) & 1ull;
-        if (!dead) {
-          if (tid == 0) keep[row] = 1;
-          for (int w = tid; w < nw; w += 64) removed[w] |= rows[rr * nw + w];
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(dlo, rr), hi = (unsigned)__builtin_amdgcn_readlane(dhi, rr);
+        const bool alive = ((V >> rr) & 1ull) && !((R >> rr) & 1ull);
+        if (alive) {
+          R |= ((unsigned long long)hi << 32) | lo;
+          K |= 1ull << rr;
         }
-        // the same wave wrote `removed`; LDS ops of one wave complete in order
       }
+      if ((K >> tid) & 1ull) keep[row] = 1;
+      if (tid == 0) sh_kept = K;
+    }
+    __syncthreads();
+    // the kept rows suppress in the words to the right of the diagonal: one lane per word, independent LDS reads
+    const unsigned long long K = sh_kept;
+    for (int w = tid; w < nw; w += blockDim.x) {
+      if (w0 + w <= bw) continue;
+      unsigned long long acc = removed[w], rest = K;
+      while (rest) {
+        const int rr = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        acc |= rows[rr * nw + w];
+      }
+      removed[w] = acc;
     }
     __syncthreads();
   }
@@ -1071,15 +1094,21 @@ select_kept_kernel(const float *__restrict__ boxes, const float *__restrict__ sc
   const int n = d_count ? min(*d_count, n_max) : n_max;
   if (threadIdx.x == 0) kept = 0;
   __syncthreads();
-  int mine = 0;
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    unsigned long long v = 0ull;
-    if (i < n && keep[i]) { v = ((unsigned long long)f2key(scores[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i); ++mine; }
-    lds64[i] = v;
+  // the survivors are packed to the front first (slot order is irrelevant: the sort orders (key, index)), so that the bitonic network
+  // runs on next_pow2(kept) items instead of next_pow2(candidates)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (keep[i]) {
+      const int slot = atomicAdd(&kept, 1);
+      lds64[slot] = ((unsigned long long)f2key(scores[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
   }
-  if (mine) atomicAdd(&kept, mine);
   __syncthreads();
-  bitonic_sort_desc(lds64, P);
+  int P2 = 2;
+  while (P2 < kept) P2 <<= 1;
+  if (P2 > P) P2 = P;
+  for (int i = kept + threadIdx.x; i < P2; i += blockDim.x) lds64[i] = 0ull;
+  __syncthreads();
+  bitonic_sort_desc(lds64, P2);
   const int m = min(kept, post);
   for (int i = threadIdx.x; i < post; i += blockDim.x) {
     if (i < m) {
