@@ -187,8 +187,11 @@ __device__ __forceinline__ bool obb_surely_disjoint(const float *p, const float 
   return d - r > 1e-3f * (r + fabsf(p[0]) + fabsf(p[1]) + fabsf(q[0]) + fabsf(q[1]) + 1.f);
 }
 
+constexpr int kNmsMaskThreads = 256;      // four waves per 64 x 64 tile: a dense tile (coarse level: most pairs overlap) is 64 rounds of
+                                          // the full IoU for ONE wave -- the critical path of the whole launch -- and 16 for four
+
 template <int W>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(kNmsMaskThreads)
 nms_mask_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ levels,
                                 const int32_t *__restrict__ d_count, int n_max, float thr, unsigned long long *__restrict__ mask,
                                 int words) {
@@ -197,86 +200,94 @@ nms_mask_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ lev
   if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
   __shared__ float cbox[64][W + 1];
   __shared__ float rbox[64][W + 1];
-  __shared__ int clev[64];
+  __shared__ int clev[64], rlev[64];
+  __shared__ unsigned char cord[64], rord[64];
   __shared__ unsigned long long bits_sh[64];
   __shared__ unsigned short pairs[64 * 64];
+  __shared__ int wave_tot[kNmsMaskThreads / 64];
   const int t = threadIdx.x;
-  const int c = cb * 64 + t;
-  if (c < n) {
+  if (t < 128) {
+    const bool is_col = t < 64;
+    const int l = t & 63;
+    const int g = (is_col ? cb : rb) * 64 + l;
+    float b[W];
 #pragma unroll
-    for (int k = 0; k < W; ++k) cbox[t][k] = boxes[(int64_t)c * W + k];
-    clev[t] = levels ? levels[c] : 0;
+    for (int k = 0; k < W; ++k) b[k] = (g < n) ? boxes[(int64_t)g * W + k] : 0.f;
+    const int lev = (levels && g < n) ? levels[g] : 0;
+    const unsigned char ord = (W == 7) ? (unsigned char)obb_ordinary(b) : 0;
+    if (is_col) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) cbox[l][k] = b[k];
+      clev[l] = lev; cord[l] = ord;
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) rbox[l][k] = b[k];
+      rlev[l] = lev; rord[l] = ord;
+      bits_sh[l] = 0ull;
+    }
   }
-  const int r = rb * 64 + t;
-  float me[W];
-#pragma unroll
-  for (int k = 0; k < W; ++k) me[k] = (r < n) ? boxes[(int64_t)r * W + k] : 0.f;
-#pragma unroll
-  for (int k = 0; k < W; ++k) rbox[t][k] = me[k];
-  bits_sh[t] = 0ull;
   __syncthreads();
-  const int mylev = (levels && r < n) ? levels[r] : 0;
   const int cend = min(64, n - cb * 64);
-  if (W == 6) {
-    if (r >= n) return;
-    unsigned long long bits = 0ull;
-    for (int j = 0; j < cend; ++j) {
-      const int col = cb * 64 + j;
-      if (col > r && clev[j] == mylev) {
-        float other[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) other[k] = cbox[j][k];
-        const float v = geo::iou3d<W>(me, other);
-        if (!(v <= thr)) bits |= (1ull << j);
-      }
-    }
-    mask[(int64_t)r * words + cb] = bits;
-    return;
-  }
-  // phase 1: candidate columns of my row
-  unsigned long long cand = 0ull;
+  // phase 1: lane = (row, quarter of the columns): candidate pairs = same level, column after row, not provably disjoint
+  const int rl = t & 63, part = t >> 6;
+  const int r = rb * 64 + rl;
+  unsigned cand = 0u;
   if (r < n) {
-    const bool prefilter = (thr >= 0.f) && obb_ordinary(me);
-    for (int j = 0; j < cend; ++j) {
+    float me[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) me[k] = rbox[rl][k];
+    const int mylev = rlev[rl];
+    const bool prefilter = (W == 7) && (thr >= 0.f) && rord[rl];
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = part * 16 + jj;
       const int col = cb * 64 + j;
-      if (col > r && clev[j] == mylev) {
+      if (j < cend && col > r && clev[j] == mylev) {
         float other[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) other[k] = cbox[j][k];
-        const bool skip = prefilter && obb_ordinary(other) && obb_surely_disjoint(me, other);
-        if (!skip) cand |= (1ull << j);
+        bool skip = false;
+        if (W == 7) skip = prefilter && cord[j] && obb_surely_disjoint(me, other);
+        if (!skip) cand |= (1u << jj);
       }
     }
   }
-  // phase 2: compaction (wave-wide inclusive scan of the per-row counts)
-  const int cnt = __popcll(cand);
+  // phase 2: compaction (inclusive scan inside each wave, wave totals through LDS)
+  const int cnt = __popc(cand);
   int incl = cnt;
+  const int lane = t & 63;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int up = __shfl_up(incl, off, 64);
-    if (t >= off) incl += up;
+    if (lane >= off) incl += up;
   }
-  const int total = __shfl(incl, 63, 64);
-  int pos = incl - cnt;
-  unsigned long long rest = cand;
+  if (lane == 63) wave_tot[t >> 6] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kNmsMaskThreads / 64; ++w) {
+    if (w < (t >> 6)) base += wave_tot[w];
+    total += wave_tot[w];
+  }
+  int pos = base + incl - cnt;
+  unsigned rest = cand;
   while (rest) {
-    const int j = __ffsll((long long)rest) - 1;
+    const int jj = __ffs((int)rest) - 1;
     rest &= rest - 1;
-    pairs[pos++] = (unsigned short)((t << 6) | j);
+    pairs[pos++] = (unsigned short)((rl << 6) | (part * 16 + jj));
   }
   __syncthreads();
   // phase 3: the full IoU of the surviving pairs, one pair per lane per round
-  for (int q = t; q < total; q += 64) {
+  for (int q = t; q < total; q += kNmsMaskThreads) {
     const int pr = pairs[q];
-    const int rl = pr >> 6, j = pr & 63;
+    const int a_ = pr >> 6, j = pr & 63;
     float a[W], b[W];
 #pragma unroll
-    for (int k = 0; k < W; ++k) { a[k] = rbox[rl][k]; b[k] = cbox[j][k]; }
+    for (int k = 0; k < W; ++k) { a[k] = rbox[a_][k]; b[k] = cbox[j][k]; }
     const float v = geo::iou3d<W>(a, b);
-    if (!(v <= thr)) atomicOr(&bits_sh[rl], 1ull << j);
+    if (!(v <= thr)) atomicOr(&bits_sh[a_], 1ull << j);
   }
   __syncthreads();
-  if (r < n) mask[(int64_t)r * words + cb] = bits_sh[t];
+  if (t < 64 && rb * 64 + t < n) mask[(int64_t)(rb * 64 + t) * words + cb] = bits_sh[t];
 }
 
 __global__ void __launch_bounds__(256)
@@ -373,9 +384,9 @@ extern "C" int nrpn_nms3d(const float *boxes, const int32_t *levels, const int32
   dim3 grid(words, words);
   auto *mask = reinterpret_cast<unsigned long long *>(workspace);
   if (box_dim == 6)
-    hipLaunchKernelGGL(nms_mask_kernel<6>, grid, dim3(64), 0, st, boxes, levels, d_count, (int)n_max, thr, mask, words);
+    hipLaunchKernelGGL(nms_mask_kernel<6>, grid, dim3(kNmsMaskThreads), 0, st, boxes, levels, d_count, (int)n_max, thr, mask, words);
   else
-    hipLaunchKernelGGL(nms_mask_kernel<7>, grid, dim3(64), 0, st, boxes, levels, d_count, (int)n_max, thr, mask, words);
+    hipLaunchKernelGGL(nms_mask_kernel<7>, grid, dim3(kNmsMaskThreads), 0, st, boxes, levels, d_count, (int)n_max, thr, mask, words);
   NRPN_LAUNCH_CHECK("nms_mask");
   const size_t lds = (size_t)words * 65 * 8;  // worst case: one level spans every word
   NRPN_LDS(nms_scan_kernel, (int)((kMaxNms / 64) * 65 * 8));

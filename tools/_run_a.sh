@@ -1,5 +1,5 @@
 set -u
-out=gpurun_out/r3m
+out=gpurun_out/r3n
 mkdir -p $out
 root=$PWD
 export TMPDIR=/tmp
@@ -9,7 +9,7 @@ timeout 300 python tools/eval_protocol.py 20 > $out/eval.log 2>&1; tail -4 $out/
 f=$(find /tmp/profe -name "*kernel_stats.csv" | head -1); cp $f $out/eval_kernel_stats.csv
 python - <<'PY'
 import csv
-rows=list(csv.DictReader(open('gpurun_out/r3m/eval_kernel_stats.csv')))
+rows=list(csv.DictReader(open('gpurun_out/r3n/eval_kernel_stats.csv')))
 for r in rows[:12]:
     print(f"{r['Name'][:70]:70s} {int(r['Calls'])/13:6.1f} {float(r['TotalDurationNs'])/13e3:9.1f} us/fwd  avg {float(r['AverageNs'])/1e3:8.1f}")
 PY
