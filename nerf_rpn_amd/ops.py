@@ -50,7 +50,10 @@ def _wgrad_side_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _WGRAD_SIDE["streams"].get(key)
     if st is None:
-        st = _WGRAD_SIDE["streams"][key] = torch.cuda.Stream(device=device)
+        # NRPN_WGRAD_PRIORITY: HIP stream priority of the weight-gradient stream (0 = default; positive = lower than the main stream's,
+        # so the critical chain of the backward gets free workgroup slots first -- measured)
+        prio = int(_os.environ.get("NRPN_WGRAD_PRIORITY", _WGRAD_SIDE.get("priority", 0)))
+        st = _WGRAD_SIDE["streams"][key] = torch.cuda.Stream(device=device, priority=prio) if prio else torch.cuda.Stream(device=device)
     return st
 
 
