@@ -153,7 +153,8 @@ class ConvProbe:
             if not (os.path.exists(pmc) and shape == (64000, 256, 256, 3)):
                 continue
             d = json.load(open(pmc))
-            k = d.get("kernels", {}).get(kernel.split(" ")[0])
+            base = kernel.split(" ")[0]          # the counter file keys carry template arguments ("conv_halo_kernel<0>")
+            k = next((v for name, v in d.get("kernels", {}).items() if name.split("<")[0] == base), None)
             if not (k and k.get("hbm_bytes") is not None):
                 continue
             # the counters describe the kernel SOURCE they were collected on: a newer conv3d.hip makes them stale, and stale is null
