@@ -1,4 +1,2 @@
-set -u
-mkdir -p gpurun_out/final
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > gpurun_out/final/pytest_gpu.log; cat gpurun_out/final/pytest_gpu.log
-bash tools/final_measure.sh 2>&1 | tail -12
+mkdir -p gpurun_out/r3p
+timeout 300 python tools/power_probe.py > gpurun_out/r3p/power.log 2>&1; cat gpurun_out/r3p/power.log | grep -v Warning | tail -40
