@@ -385,8 +385,18 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # NRPN_FORCE_EXCHANGE=1: a one-rank RCCL process group with the trainer's exchange machinery switched on -- the multi-GPU code path
+    # of this file and of engine.FlatTrainer (buckets, launch stream, collectives, the prints) on a single-GPU box (tests only)
+    dist_on = world > 1 or os.environ.get("NRPN_FORCE_EXCHANGE") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     from nerf_rpn_amd import lib
     from nerf_rpn_amd.engine import FlatTrainer
@@ -437,7 +447,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         trainer.exchange_events = []
     torch.cuda.synchronize()
@@ -450,7 +460,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -459,7 +469,7 @@ def main():
     packs_per_step = (_ops.PACK_COUNT["conv"] + _ops.PACK_COUNT["stem"] - packs0) / args.steps
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     per_rank_ms, exch = [round(1e3 * own_elapsed / args.steps, 3)], None
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ev = trainer.exchange_events
         wait_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
@@ -492,18 +502,18 @@ def main():
         step2 = make_step(model, trainer, [a for a, _ in sc2], [b.cpu() for _, b in sc2])
         for _ in range(3):
             step2()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         n2 = max(5, args.steps // 5)
         for _ in range(n2):
             step2()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
         extras["scenes_per_gpu_2"] = {"steps": n2, "ms_per_step": round(1e3 * t2.item() / n2, 3), "scenes_per_s": round(2 * world * n2 / t2.item(), 3)}
     if rank == 0 and not args.no_extras and args.model == "vgg_rpn" and world == 1 and spg == 1:
@@ -543,7 +553,7 @@ def main():
             "config": {"workload": f"configs[1]: {'one' if spg == 1 else spg} 160x160x160x4 rgb-sigma grid{'s' if spg > 1 else ''} per GPU, VGG19-EF 3D + FPN + "
                                    "anchor RPN (OBB, 16 GT boxes per scene), fwd+bwd+clip+AdamW, random-init weights", "scenes_per_gpu": spg,
                        "parallelism": f"dp{world}", "world_size_seen": world,
-                       "backend": (dist.get_backend() if world > 1 else "single process")},
+                       "backend": (dist.get_backend() if dist_on else "single process")},
             "per_rank_ms_per_step": per_rank_ms,
             **({"gradient_exchange": exch} if exch else {}),
             "weight_packs_per_step": packs_per_step, "wgrad_side_stream": side_stream, **({"tuning_knobs": knobs} if knobs else {}),
@@ -557,7 +567,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == "vgg_rpn":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -85,6 +85,9 @@ class FlatTrainer:
         dev = self.params[0].device
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.group = process_group
+        # the exchange machinery (buckets, launch stream, collectives) runs whenever there is more than one rank; NRPN_FORCE_EXCHANGE=1
+        # keeps it on for a one-rank process group, so that a single-GPU box exercises the real RCCL calls (tests / bench smoke)
+        self.exchanging = self.world > 1 or (os.environ.get("NRPN_FORCE_EXCHANGE") == "1" and dist.is_available() and dist.is_initialized())
         # Every slot starts on a 64-float (256-byte) boundary (16-byte vector kernels on single slots); the zero padding is inert in
         # AdamW (p = g = m = v = 0 stays 0) and in the norm.
         # Conv / linear weights that feed a single-weight GEMM are stored in the FORWARD GEMM LAYOUT [taps][Cout][Cin] ("packable",
@@ -140,7 +143,7 @@ class FlatTrainer:
         self.bucket_params = []
         self.bucket_of = {}
         self.handles = []
-        if self.world > 1:
+        if self.exchanging:
             dist.broadcast(self.p_arena, src=0, group=self.group)     # rank 0's weights everywhere (DDP init semantics)
             per = max(1, bucket_bytes // 4)
             end = total
@@ -163,11 +166,11 @@ class FlatTrainer:
     def _make_notify(self, i):
         def notify():
             self.seen[i] += 1
-            if self.world > 1 and self.g_arena.is_cuda:
+            if self.exchanging and self.g_arena.is_cuda:
                 h = ops._s()                 # raw handle of the stream this gradient was produced on (~0.3 us); the Stream object is
                 if h not in self._streams:   # only built the first time a handle shows up
                     self._streams[h] = torch.cuda.current_stream(self.g_arena.device)
-            if self.world > 1 and self.expected is not None:
+            if self.exchanging and self.expected is not None:
                 b = self.bucket_of[i]
                 if self.launched[b]:
                     # the bucket's all-reduce is already in flight: a late accumulation would race with it and mix un-reduced
@@ -252,7 +255,7 @@ class FlatTrainer:
 
     def sync_gradients(self):
         """Wait for the in-flight bucket exchanges; buckets not launched yet (first step, unused parameters) go now."""
-        if self.world > 1:
+        if self.exchanging:
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
                     self._launch(b)

@@ -203,3 +203,24 @@ def test_voxel_score_heatmaps(tmp_path, dev):
         assert z[str(lvl)].shape == (w, l, h)
         ref = logits[lvl][0].float().max(dim=0)[0][:w, :l, :h].cpu().numpy()
         assert np.allclose(z[str(lvl)], ref, atol=1e-5)
+
+
+def test_bench_distributed_path_on_one_rank(tmp_path):
+    """bench.py's multi-GPU code path (process group, exchange events, per-rank gathers, the gradient_exchange block of the JSON line)
+    on a one-rank RCCL group (NRPN_FORCE_EXCHANGE=1): the scaling run of the driver must not be the first time that code executes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NRPN_FORCE_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    for mode in ("allreduce", "rs_ag"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                              "--no-probe", "--no-extras", "--exchange", mode], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        ex = line["gradient_exchange"]
+        assert line["n_gpus"] == 1 and ex["mode"] == mode and ex["buckets"] >= 2 and len(line["per_rank_ms_per_step"]) == 1
+        assert line["value"] > 20 and line["config"]["parallelism"].startswith("dp1")

@@ -87,3 +87,67 @@ def test_two_rank_rccl_gradient_exchange(dev):
         alone.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu())
     mean = (alone[0] + alone[1]) / 2
     assert torch.allclose(ga[0], mean, rtol=1e-6, atol=1e-9 + 1e-6 * mean.abs().max().item())
+
+
+def _single_worker(port, q):
+    """One rank over RCCL on the one GPU of the box, the exchange machinery forced on (NRPN_FORCE_EXCHANGE=1): every exchange mode runs
+    its real collectives (all_reduce / reduce_scatter + all_gather / all_to_all + all_gather) on the launch stream behind the producer
+    events.  With one rank the reduced gradient IS the local gradient: exact for the fp32 modes, bf16-rounded for a2a_bf16."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from nerf_rpn_amd.engine import FlatTrainer
+    from test_gpu_e2e import build
+    x, gt = _scene(0)
+
+    def run(exchange):
+        torch.manual_seed(3)
+        model = build(True, 160, dev).train()
+        tr = FlatTrainer(model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, bucket_bytes=8 << 20, total_steps=10, exchange=exchange)
+        _grads(model, x, gt, dev)
+        tr.sync_gradients()
+        g0 = tr.flat_grads().cpu()
+        tr.step()
+        early = 0
+        for _ in range(2):
+            _grads(model, x, gt, dev)
+            early += sum(tr.launched)
+            tr.step()
+        torch.cuda.synchronize()
+        return g0, tr.flat_params().cpu(), len(tr.buckets), early
+
+    out = {"plain": run(None)}                      # no process group yet: the single-process trainer
+    os.environ["NRPN_FORCE_EXCHANGE"] = "1"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    for mode in ("allreduce", "rs_ag", "a2a_bf16"):
+        out[mode] = run(mode)
+    q.put({k: (v[0].numpy(), v[1].numpy(), v[2], v[3]) for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_exchange_modes(dev):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    g_plain, p_plain, nb_plain, _ = res["plain"]
+    assert nb_plain == 0
+    for mode in ("allreduce", "rs_ag"):
+        g, prm, nb, early = res[mode]
+        assert nb >= 2 and early >= 1, (mode, nb, early)          # buckets exist and went out during the backward of steps 1-2
+        assert (g == g_plain).all() and (prm == p_plain).all(), mode    # one rank: the exchange is the identity, bit for bit
+    g, prm, nb, early = res["a2a_bf16"]
+    assert nb >= 2 and early >= 1
+    scale = float(abs(g_plain).max())
+    assert abs(g - g_plain).max() <= 2.0 ** -8 * scale and torch.isfinite(torch.from_numpy(prm)).all()

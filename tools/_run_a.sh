@@ -1,2 +1,1 @@
-mkdir -p gpurun_out/final
-python bench.py > gpurun_out/final/bench.log 2>gpurun_out/final/bench.err; grep '^{' gpurun_out/final/bench.log > gpurun_out/final/bench_n1.json; python tools/bench_line.py final < gpurun_out/final/bench_n1.json | cut -c1-300
+timeout 900 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_harness.py::test_bench_distributed_path_on_one_rank -x -q 2>&1 | tail -25
