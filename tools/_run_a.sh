@@ -1,6 +1,9 @@
-mkdir -p gpurun_out/r3q
-for spg in 2 4; do
-  timeout 300 python bench.py --scenes-per-gpu $spg --steps 12 --warmup 3 --no-cpu-baseline --no-probe --no-extras > gpurun_out/r3q/spg$spg.log 2>&1
-  grep '^{' gpurun_out/r3q/spg$spg.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('scenes/gpu $spg', d['ms_per_step'], d['value'])"
-done
-timeout 200 python tools/eval_protocol.py 20 160 160 160 2>&1 | tail -4
+set -u
+mkdir -p gpurun_out/r3r
+root=$PWD
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_postproc.py tests/test_gpu_stages.py -x -q 2>&1 | tail -3
+timeout 300 python tools/eval_protocol.py 20 2>&1 | tail -4
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/profe -o p --output-format csv -- python $root/tools/eval_protocol.py 10 > $root/gpurun_out/r3r/prof.log 2>&1)
+f=$(find /tmp/profe -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/r3r/eval_kernel_stats.csv
+grep -E "nms_|topk|filter|select" gpurun_out/r3r/eval_kernel_stats.csv | cut -d, -f1-4 | cut -c1-150
