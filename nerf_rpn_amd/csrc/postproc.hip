@@ -319,12 +319,13 @@ nms_scan_kernel(const int32_t *__restrict__ levels, const int32_t *__restrict__ 
   __syncthreads();
   for (int b0 = s & ~63; b0 < e; b0 += 64) {
     const int bw = b0 >> 6;  // word index of this row block; only columns >= bw matter
-    for (int q = tid; q < 64 * nw; q += blockDim.x) {
-      const int rr = q / nw, w = q - rr * nw;
+    // 16 lanes per row (128-byte segments), 16 rows per pass; words left of the diagonal are never read again and are not staged
+    const int wlo = max(0, bw - w0);
+    for (int rr = tid >> 4; rr < 64; rr += (int)blockDim.x >> 4) {
       const int row = b0 + rr;
-      unsigned long long v = 0ull;
-      if (row >= s && row < e && (w0 + w) >= bw) v = mask[(int64_t)row * words + (w0 + w)];
-      rows[q] = v;
+      const bool live = row >= s && row < e;
+      for (int w = wlo + (tid & 15); w < nw; w += 16)
+        rows[rr * nw + w] = live ? mask[(int64_t)row * words + (w0 + w)] : 0ull;
     }
     __syncthreads();
     if (tid < 64) {
