@@ -25,6 +25,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.query("pool_out_size", 80, 3, 2, 1, 0) == 40
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/nerfrpn.h is the drop-in boundary: it must compile as C99 (no C++ or torch types in the signatures) and every prototype must
+    be bindable by the ctypes parser of lib.py (pointers, sizes, scalars only)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "nerfrpn.h"\nint main(void) { nrpn_conv_opts o; o.size = (int)sizeof o; return o.size > 0 ? 0 : 1; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    protos = lib._prototypes()
+    assert set(protos) == set(lib.declared_symbols())            # every declared entry point has a parsed prototype
+
+
 def test_argument_errors_are_reported_not_fatal():
     with pytest.raises(lib.NrpnError, match="box_dim"):
         lib.call("iou3d_matrix_f32", 0, 0, 0, 1, 1, 5, 0)
