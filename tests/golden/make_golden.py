@@ -669,7 +669,9 @@ def gen_fullsize2():
 
 def gen_train():
     print("end-to-end train")
-    cases = [("train_swin_obb", True, "smooth_l1", [(80, 56, 48)]),      # stochastic depth 0 (the draw is RNG-stream specific)
+    cases = [("train_obb_160_cfg1", True, "smooth_l1", [(160, 160, 160)]),   # BASELINE configs[1] at its full size: the bench workload
+             ("train_resnet_obb_iou_160x120x64", True, "iou", [(160, 120, 64)]),   # configs[4] family at a SURVEY 8d size
+             ("train_swin_obb", True, "smooth_l1", [(80, 56, 48)]),      # stochastic depth 0 (the draw is RNG-stream specific)
              ("train_resnet_aabb", False, "smooth_l1", [(64, 56, 48)]),
              ("train_resnet_obb_iou", True, "iou", [(64, 56, 48)]),        # BASELINE configs[4]: ResNet-50 + rotated-IoU loss
              ("train_aabb", False, "smooth_l1", [(48, 48, 48)]),
@@ -692,10 +694,11 @@ def gen_train():
         g = torch.Generator().manual_seed(77)
         gts = []
         for s in shapes:
+            nbox, smax = (16, 48) if min(s) >= 64 else (5, 20)      # full-size cases: the bench's 16 boxes of up to 48 voxels
             if rot:
-                gt = rand_obb(5, g, 8, min(s) - 8, 6, 20)
+                gt = rand_obb(nbox, g, 8, min(s) - 8, 6, smax)
             else:
-                gt = rand_aabb(5, g, 8, min(s) - 8, 6, 20)
+                gt = rand_aabb(nbox, g, 8, min(s) - 8, 6, smax)
             gts.append(gt)
         if "emptygt" in name:
             gts[-1] = gts[-1][:0]
