@@ -213,3 +213,43 @@ def test_fullsize_fcos_swin_matches_reference(name, golden, dev):
     tol = 3e-3 + 2e-4 * rp[:, 1:].abs()[:, None, :]
     ok = ((diff <= tol).all(dim=2) & near & (gp[None, :, 0] == rp[:, None, 0])).any(dim=1)
     assert (~ok).sum() <= allow, (name, int((~ok).sum()), rp.shape[0])
+
+
+@pytest.mark.parametrize("name,key,norm_band", [("train_obb_160_cfg1", "vgg_160x160x160", (0.95, 1.08)),
+                                                ("train_resnet_obb_iou_160x120x64", "resnet_160x120x64", (0.4, 2.8))])
+def test_bf16_training_deviates_like_bf16_storage_of_the_reference(name, key, norm_band, golden, dev):
+    """bf16 is the dtype the bench times.  In TRAIN mode (batch statistics, batch 1, random init) these networks amplify a 1e-6
+    relative perturbation of their activations 100-800 x (tests/golden/bf16_emulation.json, 'eps'), so bf16's 2^-9 rounding moves the
+    FPN outputs by 10-15 % (VGG19) / 30-57 % (ResNet-50) -- on the CPU, in plain torch, when the REFERENCE-equivalent oracle net merely
+    stores weights and activations in bf16 (tools/bf16_chaos_cpu.py).  The HIP bf16 path must sit in the same place: per FPN level, rms
+    deviation from the HIP fp32 run within 0.6-1.5 x the emulated figure (measured 0.91-1.05 x); losses within 4 % of the fp32 run
+    (measured 0.2-2.4 %); gradient norms of every GEMM weight within the stated band (VGG19 measured 0.993-1.034; ResNet-50 0.59-2.14:
+    with half of the feature signal replaced, gradient DIRECTIONS are not comparable -- cosine ~ 0 -- and are not asserted)."""
+    import json
+    import os
+    from test_gpu_e2e import build, scene
+    emu = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_emulation.json")))[key]["bf16"]
+    g = golden(name)
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)
+        m = build(bool(g["rotated"]), 160, dev, str(g["reg_loss_type"]), backbone=str(g.get("backbone", "vgg")), sd=0.0).train()
+        m.set_compute_dtype(dt)
+        xs = [scene(s, 200 + i).to(dev) for i, s in enumerate(g["shapes"])]
+        gts = [T(g[f"gt{i}"], dev) for i in range(len(xs))]
+        pos, neg = T(g["pos_idx"], dev), T(g["neg_idx"], dev)
+        m.rpn.sampler_hook = lambda labels: (pos, neg)
+        (feats, _, _), losses, _ = m(xs, gts)
+        (losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"]).backward()
+        params = dict(m.backbone.named_parameters())
+        params.update({"head." + k: v for k, v in m.rpn.head.named_parameters()})
+        out[dt] = ([f.detach().float() for f in feats], {k: v.item() for k, v in losses.items()},
+                   {k: p.grad.detach().float().norm().item() for k, p in params.items() if p.dim() > 1})
+    f32, b16 = out[torch.float32], out[torch.bfloat16]
+    for lvl, (a, b) in enumerate(zip(f32[0], b16[0])):
+        dev_rms = ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
+        assert 0.6 * emu[lvl] <= dev_rms <= 1.5 * emu[lvl], (name, lvl, dev_rms, emu[lvl])
+    for k in ("loss_objectness", "loss_rpn_box_reg"):
+        assert abs(b16[1][k] - f32[1][k]) <= 0.04 * abs(f32[1][k]), (name, k, b16[1][k], f32[1][k])
+    ratios = [b16[2][k] / f32[2][k] for k in f32[2] if f32[2][k] > 0]
+    assert norm_band[0] <= min(ratios) and max(ratios) <= norm_band[1], (name, min(ratios), max(ratios))

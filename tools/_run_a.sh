@@ -1,1 +1,1 @@
-timeout 900 python -m pytest "tests/test_gpu_e2e.py::test_train_matches_reference" -x -q -k "160" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k "bf16_training" 2>&1 | tail -6
