@@ -215,9 +215,12 @@ def test_fullsize_fcos_swin_matches_reference(name, golden, dev):
     assert (~ok).sum() <= allow, (name, int((~ok).sum()), rp.shape[0])
 
 
-@pytest.mark.parametrize("name,key,norm_band", [("train_obb_160_cfg1", "vgg_160x160x160", (0.95, 1.08)),
-                                                ("train_resnet_obb_iou_160x120x64", "resnet_160x120x64", (0.4, 2.8))])
-def test_bf16_training_deviates_like_bf16_storage_of_the_reference(name, key, norm_band, golden, dev):
+@pytest.mark.parametrize("name,key,norm_band,min_cos", [("train_obb_160_cfg1", "vgg_160x160x160", (0.95, 1.08), None),
+                                                        ("train_resnet_obb_iou_160x120x64", "resnet_160x120x64", (0.4, 2.8), None),
+                                                        # Swin-S: LayerNorm, no amplification -- features move by ~1 %, every gradient
+                                                        # keeps its direction (measured cosine 0.979-1.000, norms 0.982-1.011)
+                                                        ("train_swin_obb", "swin_80x56x48", (0.95, 1.05), 0.95)])
+def test_bf16_training_deviates_like_bf16_storage_of_the_reference(name, key, norm_band, min_cos, golden, dev):
     """bf16 is the dtype the bench times.  In TRAIN mode (batch statistics, batch 1, random init) these networks amplify a 1e-6
     relative perturbation of their activations 100-800 x (tests/golden/bf16_emulation.json, 'eps'), so bf16's 2^-9 rounding moves the
     FPN outputs by 10-15 % (VGG19) / 30-57 % (ResNet-50) -- on the CPU, in plain torch, when the REFERENCE-equivalent oracle net merely
@@ -244,7 +247,8 @@ def test_bf16_training_deviates_like_bf16_storage_of_the_reference(name, key, no
         params = dict(m.backbone.named_parameters())
         params.update({"head." + k: v for k, v in m.rpn.head.named_parameters()})
         out[dt] = ([f.detach().float() for f in feats], {k: v.item() for k, v in losses.items()},
-                   {k: p.grad.detach().float().norm().item() for k, p in params.items() if p.dim() > 1})
+                   {k: p.grad.detach().float().norm().item() for k, p in params.items() if p.dim() > 1},
+                   {k: p.grad.detach().float().reshape(-1).clone() for k, p in params.items() if p.dim() > 1} if min_cos else {})
     f32, b16 = out[torch.float32], out[torch.bfloat16]
     for lvl, (a, b) in enumerate(zip(f32[0], b16[0])):
         dev_rms = ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
@@ -253,3 +257,7 @@ def test_bf16_training_deviates_like_bf16_storage_of_the_reference(name, key, no
         assert abs(b16[1][k] - f32[1][k]) <= 0.04 * abs(f32[1][k]), (name, k, b16[1][k], f32[1][k])
     ratios = [b16[2][k] / f32[2][k] for k in f32[2] if f32[2][k] > 0]
     assert norm_band[0] <= min(ratios) and max(ratios) <= norm_band[1], (name, min(ratios), max(ratios))
+    for k, a in f32[3].items():
+        b = b16[3][k]
+        cos = (a.double() @ b.double() / (a.double().norm() * b.double().norm() + 1e-30)).item()
+        assert cos >= min_cos, (name, k, cos)
