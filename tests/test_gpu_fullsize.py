@@ -298,3 +298,30 @@ def test_bf16_eval_features_deviate_like_bf16_storage_of_the_reference(backbone,
         ratios.append(round(dev_rms / emu[lvl], 3))
         assert 0.7 * emu[lvl] <= dev_rms <= 1.4 * emu[lvl], (backbone, lvl, dev_rms, emu[lvl])
     print(f"[bf16 eval vs emulation] {backbone} {shape}: HIP / emulated rms deviation per level {ratios}")
+
+
+@pytest.mark.parametrize("name", FCOS_CASES2)
+def test_fullsize_fcos_swin_bf16_keeps_what_bf16_storage_keeps(name, golden, dev):
+    """config 4 in bf16 (Swin-S + FCOS head, OBB, full size): the oracle detector on the CPU with bf16 storage keeps 73-75 % / 89-92 % / 91-95 %
+    of the reference's 300 best detections at rotated IoU > 0.9 / 0.7 / 0.5 (tools/bf16_fcos_cpu.py -> bf16_emulation_proposals.json);
+    the HIP bf16 detector may not do worse than that by more than 10 points at any level, and returns finite scores."""
+    import json
+    import os
+    import test_gpu_fcos as TF
+    from oracle import boxes as OB
+    g = golden(name)
+    m = TF.build(True, "swin", dev).eval()
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        boxes, _, scores = m([_scene2(g).to(dev)])
+    rp, rs = T(g["boxes0"]), T(g["scores0"])
+    top = torch.argsort(rs, descending=True, stable=True)[:300]
+    gp = boxes[0].float().cpu()
+    assert gp.shape[0] > 0 and torch.isfinite(scores[0]).all()
+    best = OB.iou_matrix(rp[top][:, -7:], gp[:, -7:]).max(dim=1).values
+    emu = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_emulation_proposals.json")))[name]
+    fr = {lvl: (best > lvl).float().mean().item() for lvl in (0.9, 0.7, 0.5)}
+    print(f"[bf16 fcos] {name}: HIP bf16 keeps {fr[0.9]:.3f} / {fr[0.7]:.3f} / {fr[0.5]:.3f} of the top-300 at IoU > 0.9 / 0.7 / 0.5; emulation "
+          f"{emu['matched_0.9']} / {emu['matched_0.7']} / {emu['matched_0.5']}")
+    for lvl in (0.9, 0.7, 0.5):
+        assert fr[lvl] >= emu[f"matched_{lvl}"] - 0.10, (name, lvl, fr[lvl], emu[f"matched_{lvl}"])
