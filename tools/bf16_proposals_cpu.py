@@ -43,7 +43,15 @@ for name in names:
     bb, hd, det, rot = build(g)
     shape = [int(s) for s in (g["shape"] if "shape" in g else g["shapes"][0])]
     seed = int(g["seed"]) if "seed" in g else 100
-    x = torch.rand(4, *shape, generator=torch.Generator().manual_seed(seed))
+    if "normalize_density" in g:       # the VGG19 full-size fixtures: raw [W, L, H, 4] scene through the loader's ingest (density -> alpha)
+        gen = torch.Generator().manual_seed(seed)
+        raw = torch.rand(*shape, 4, generator=gen)
+        raw[..., 3] = raw[..., 3] * 10.0 - 5.0
+        if bool(g["normalize_density"]):
+            raw[..., 3] = torch.clamp(1.0 - torch.exp(-torch.exp(raw[..., 3]) / 100.0), 0.0, 1.0)
+        x = raw.permute(3, 0, 1, 2).contiguous()
+    else:
+        x = torch.rand(4, *shape, generator=torch.Generator().manual_seed(seed))
     with torch.no_grad():
         for p in list(bb.parameters()) + list(hd.parameters()):
             if p.dim() > 1:
@@ -64,5 +72,9 @@ for name in names:
                  "matched_0.5": round((best > 0.5).float().mean().item(), 4), "proposals": int(gp.shape[0]),
                  "scores": [round(float(scores[0].min()), 4), round(float(scores[0].max()), 4)]}
     print(name, res[name], flush=True)
-if not sys.argv[1:]:
-    json.dump(res, open(os.path.join(root, "tests", "golden", "bf16_emulation_proposals.json"), "w"), indent=1)
+path = os.path.join(root, "tests", "golden", "bf16_emulation_proposals.json")
+if os.path.exists(path):
+    old = json.load(open(path))
+    old.update(res)
+    res = old
+json.dump(res, open(path, "w"), indent=1)
