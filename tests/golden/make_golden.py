@@ -846,6 +846,54 @@ def gen_fcos():
         save(name, **arrs)
 
 
+def gen_convergence():
+    """40 optimiser steps of the REFERENCE's training loop (run_rpn.py:345-349, 373-395: AdamW lr 1e-4 / wd 0.01, OneCycleLR over the
+    run, clip_grad_norm 0.1, loss = objectness + 5 x box regression) on 4 fixed synthetic 160^3 scenes (VGG19-EF + FPN + RPN, OBB, 16 boxes
+    each; the bench workload), cycling through the scenes.  Stored: the three losses of every step and the anchors the reference's sampler
+    drew (labels depend on anchors and ground truth only, so the HIP run can be fed the same draws through ``sampler_hook``)."""
+    print("convergence: 40 reference training steps at 160^3")
+    import time
+    from torch.optim import AdamW
+    from torch.optim.lr_scheduler import OneCycleLR
+    steps, nscene = int(os.environ.get("GOLDEN_CONV_STEPS", 40)), 4
+    ref = build_ref(True, 160).train()
+    xs = [scene((160, 160, 160), 300 + i) for i in range(nscene)]
+    g = torch.Generator().manual_seed(78)
+    gts = [rand_obb(16, g, 8, 152, 6, 48) for _ in range(nscene)]
+    drawn = {}
+    orig = ref.rpn.fg_bg_sampler
+
+    class Rec:
+        def __call__(self, labels):
+            pos, neg = orig(labels)
+            drawn["pos"], drawn["neg"] = torch.where(torch.cat(pos, dim=0))[0], torch.where(torch.cat(neg, dim=0))[0]
+            return pos, neg
+
+    ref.rpn.fg_bg_sampler = Rec()
+    opt = AdamW(ref.parameters(), lr=1e-4, weight_decay=0.01)
+    sched = OneCycleLR(opt, max_lr=1e-4, total_steps=steps)
+    torch.manual_seed(4321)
+    losses, pos_all, neg_all, pos_off, neg_off, gnorm = [], [], [], [0], [0], []
+    for it in range(steps):
+        t0 = time.time()
+        k = it % nscene
+        _, ls, _ = ref([xs[k].clone()], [gts[k].clone()])
+        total = ls["loss_objectness"] + 5.0 * ls["loss_rpn_box_reg"] + 0.0 * ls["loss_rpn_box_reg_2d"]
+        total.backward()
+        gn = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
+        opt.step(); sched.step(); opt.zero_grad()
+        losses.append([ls["loss_objectness"].item(), ls["loss_rpn_box_reg"].item(), ls["loss_rpn_box_reg_2d"].item()])
+        gnorm.append(float(gn))
+        pos_all.append(drawn["pos"]); neg_all.append(drawn["neg"])
+        pos_off.append(pos_off[-1] + drawn["pos"].numel()); neg_off.append(neg_off[-1] + drawn["neg"].numel())
+        print(f"   step {it}: obj {losses[-1][0]:.6f} reg {losses[-1][1]:.6f} |g| {gnorm[-1]:.4f}  ({time.time() - t0:.1f} s)", flush=True)
+    arrs = {"steps": steps, "scenes": nscene, "losses": np.asarray(losses, dtype=np.float64), "grad_norm": np.asarray(gnorm),
+            "pos": torch.cat(pos_all), "neg": torch.cat(neg_all), "pos_off": np.asarray(pos_off), "neg_off": np.asarray(neg_off)}
+    for i, t in enumerate(gts):
+        arrs[f"gt{i}"] = t
+    save("convergence_obb_160", **arrs)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["geometry", "anchors", "coders", "matcher", "nms", "metrics", "cli", "detector", "roipool", "ngp", "eval", "fullsize", "train", "fcos"]
     for w in which:
