@@ -287,6 +287,31 @@ int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float *bias, voi
 int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw_packed, float *gbias, int nseg, const int32_t *dims,
                              int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
                              nrpn_stream_t stream);
+/* ---- Row-list ("sampled cone") forms.  In training the RPN loss reads the head at the sampled anchors only (reference model/rpn.py:389-420;
+ * "During training, boxes pred and scores are unused", rpn.py:506), so the head -- conv_depth x [Conv3d k3 + ReLU] + the 1x1x1 cls / bbox
+ * convs of reference model/anchor.py:RPNHead, shared by all pyramid levels -- is needed only on the receptive-field cones of those voxels,
+ * and its gradients are non-zero only there.  nrpn_cone_build turns the sampler's output into the sorted voxel lists S0 c S1 c ... c S_depth
+ * (S_k = 3x3x3 dilation of S_{k-1} inside each grid) over the ragged voxel space of `dims` (segment = level * n_scenes + scene, host int32
+ * [nlevels * n_scenes * 3]); the *_rows calls run a conv on exactly the listed rows.  List entry = two uint32 per row: { voxel id, in-bounds bits
+ * of the 27 taps | segment << 27 }.
+ *   pos / neg: device int64 [n_scenes][pos_stride | neg_stride] anchor indices in one scene's flat (level, x, y, z, a) order, as
+ *   nrpn_sample_pos_neg writes them; counts: device int32 [3 * n_scenes] = (kp, kn, err) per scene (its out_counts);
+ *   level_anchor_off: host int64 [nlevels + 1]; lists: device uint32 [depth + 1][cap][2], cap >= total voxels; counts_out: device int32
+ *   [depth + 2] = |S_0| .. |S_depth|, then an error flag (an anchor index outside the pyramid).  No host synchronisation. */
+size_t nrpn_cone_workspace_bytes(int64_t total_voxels);
+int nrpn_cone_build(const int64_t *pos, const int64_t *neg, const int32_t *counts, int n_scenes, int64_t pos_stride, int64_t neg_stride,
+                    int nlevels, const int64_t *level_anchor_off, int num_anchors, const int32_t *dims, int depth, uint32_t *lists,
+                    int64_t cap, int32_t *counts_out, void *workspace, nrpn_stream_t stream);
+/* forward / dgrad on the `nrows` listed output rows: x, y and relu_mask are [total voxels][C] tensors indexed by voxel id; rows outside the
+ * list are not written.  128-row tiles, no workspace.  Cin * elemsize must be a multiple of 128 bytes. */
+int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *bias, void *y, const uint32_t *rows, int64_t nrows, int nseg,
+                         const int32_t *dims, int cin, int cout, int wrows, int ksize, int dtype, int flags, const void *relu_mask,
+                         nrpn_stream_t stream);
+/* wgrad over the `nrows` listed voxels (the K extent): partial layout / slice count as nrpn_conv3d_wgrad with n = 1, gx = nrows, gy = gz = 1;
+ * workspace: >= max(256, slices * wrows * 4) bytes (bias partials; NRPN_WGRAD_* flags as above, MASK_READY is implied). */
+int nrpn_conv3d_wgrad_rows(const void *x, const void *dy, float *gw_packed, float *gbias, const uint32_t *rows, int64_t nrows, int nseg,
+                           const int32_t *dims, int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
+                           nrpn_stream_t stream);
 /* kernel selection of a forward / dgrad launch: 0 = 128-row tile, 1 = 256x256 tile (8 waves), 2 = 256x256 tile on K slices, 3 = 128-row
  * tile on K slices, 4 = wave-specialised 256x128, 5 = 256x256 tile on 4 waves, 6 = the same on K slices,
  * 7 = halo form of the 3x3x3 kernel;  of a wgrad launch: 1 = 256x256 tile, 0 = 128x128 (tests assert coverage with these) */

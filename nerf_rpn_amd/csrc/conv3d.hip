@@ -13,7 +13,9 @@
 // Replaces torch.nn.Conv3d (MIOpen/cuDNN) in reference feature_extractor.py:331-358, fpn.py:109-110, anchor.py:190-198.
 #include "conv_common.cuh"
 
-template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128>
+// ROWS (MODE 0): row-list form -- tile row v is voxel p.rows[2 v] of the ragged space with tap word p.rows[2 v + 1] (csrc/cone.hip); the
+// output (and the optional ReLU mask) row is that voxel.  The dense instantiations carry none of it.
+template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128, bool ROWS = false>
 __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(const ConvArgs p) {
   constexpr int WAVES_N = (BN == 128) ? 2 : 1;
   constexpr int TM = BM / (32 * (4 / WAVES_N));   // 32x32 tiles per wave along M: 1, 2 or (BM 256) 4
@@ -51,7 +53,16 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     const long long vv = a_ok[i] ? v : 0;
     int ox, oy, oz, gX = p.X, gY = p.Y, gZ = p.Z;
     long long n = 0;
-    if (MODE == 0) {
+    unsigned row_word = 0;
+    long long row_vox = vv;
+    if (MODE == 0 && ROWS) {
+      if (a_ok[i]) { row_vox = p.rows[2 * vv]; row_word = p.rows[2 * vv + 1]; }
+      const int seg = (int)(row_word >> 27);
+#pragma unroll
+      for (int q = 0; q < kMaxSeg; ++q)
+        if (q == seg && q < p.segs.n) { gY = p.segs.Y[q]; gZ = p.segs.Z[q]; }
+      ox = oy = oz = 0;
+    } else if (MODE == 0) {
       locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
     } else {
       oz = (int)(vv % p.OZ);
@@ -64,10 +75,12 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     a_x[i] = ox; a_y[i] = oy; a_z[i] = oz;
     a_yz[i] = gY * gZ * p.Cin * (int)sizeof(T);
     a_zs[i] = gZ * p.Cin * (int)sizeof(T);
-    a_off[i] = (MODE == 0) ? vv * p.Cin : 0;
+    a_off[i] = (MODE == 0) ? row_vox * p.Cin : 0;
     a_nbase[i] = (MODE == 0) ? 0 : n * (long long)p.X * p.Y * p.Z * 4;
     unsigned m = 0;
-    if (MODE == 0 && a_ok[i]) {
+    if (MODE == 0 && ROWS) {
+      m = p.taps == 27 ? (row_word & 0x7FFFFFFu) : (a_ok[i] ? 1u : 0u);
+    } else if (MODE == 0 && a_ok[i]) {
       if (p.taps == 27) {
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
@@ -329,9 +342,10 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     for (int q = 0; q < TM * 4; ++q) {
       const int pc = lane + 64 * q;                     // TM*32 rows x 8 pieces of 16 bytes
       const int row = pc >> 3, seg = pc & 7;
-      const long long v = m0 + wm * (TM * 32) + row;
+      const long long vt = m0 + wm * (TM * 32) + row;
       const int col = n0 + wn * 64 + seg * 8;
-      if (v < p.M && col < p.Cout) {
+      if (vt < p.M && col < p.Cout) {
+        const long long v = ROWS ? (long long)p.rows[2 * vt] : vt;
         f4 val = *reinterpret_cast<const f4 *>(stage + row * PITCH + seg * 16);
         if (maskp) {
           typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
@@ -356,8 +370,9 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, lane);
-        if (v < p.M) {
+        const long long vt = m0 + (wm * TM + i) * 32 + frag_row(r, lane);
+        if (vt < p.M) {
+          const long long v = ROWS ? (long long)p.rows[2 * vt] : vt;
           float o = acc[i][j][r] * sv + bv;
           if (relu) o = fmaxf(o, 0.f);
           if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
@@ -1506,6 +1521,42 @@ extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float
   return conv3d_fwd_impl(x, wp, bias, nullptr, y, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, flags, workspace, stream);
 }
 
+// Row-list form of the forward / dgrad launch: output rows = the `nrows` voxels of `rows` ([nrows][2] u32 = {voxel id in the ragged space of
+// `dims`, tap word}; csrc/cone.hip builds such lists) -- x, y and relu_mask are indexed by voxel id, rows outside the list are neither
+// read as outputs nor written.  128-row tiles of conv_igemm_kernel, no K slices (the lists are short: one launch, no workspace).
+extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *bias, void *y, const uint32_t *rows, int64_t nrows, int nseg,
+                                    const int32_t *dims, int cin, int cout, int wrows, int ksize, int dtype, int flags, const void *relu_mask,
+                                    nrpn_stream_t stream) {
+  NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_fwd_rows: ksize must be 1 or 3 (got %d)", ksize);
+  NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_fwd_rows: bad dtype %d", dtype);
+  NRPN_REQUIRE(x && wp && y && rows && nrows >= 0 && cin > 0 && cout > 0 && wrows >= cout, "conv3d_fwd_rows: bad arguments");
+  if (nrows == 0) return NRPN_OK;
+  const int es = dtype == NRPN_F32 ? 4 : 2;
+  NRPN_REQUIRE((cin * es) % 128 == 0, "conv3d_fwd_rows: Cin*elemsize must be a multiple of 128 bytes (Cin=%d)", cin);
+  const bool out_f32 = (flags & NRPN_CONV_OUT_F32) != 0 || dtype == NRPN_F32;
+  NRPN_REQUIRE(!relu_mask || !(flags & NRPN_CONV_OUT_F32) || dtype == NRPN_F32, "conv3d_fwd_rows: relu_mask needs outputs in the input dtype");
+  ConvArgs a{};
+  long long total = 0;
+  if (int rc = fill_segs(a.segs, nseg, dims, total)) return rc;
+  a.x = x; a.w = wp; a.bias = bias; a.mask = relu_mask; a.y = y; a.rows = rows;
+  a.M = nrows;
+  a.X = a.Y = a.Z = a.OX = a.OY = a.OZ = 1;
+  a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.flags = flags & 3; a.ksplit = 1;
+  NRPN_REQUIRE(total * cin * es < (1ll << 31) && total * cout * 4 < (1ll << 32) && (long long)a.taps * wrows * cin * es < (1ll << 31),
+               "conv3d_fwd_rows: activation / weight tensors must stay below 2 GiB (32-bit buffer offsets)");
+  a.x_bytes = (unsigned)(total * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)(cdiv64(nrows, 128) * ((cout + 127) / 128)));
+  const size_t lds_ = 2 * (size_t)(128 + 128) * 128;
+  int rc;
+  if (dtype == NRPN_F32) rc = launch_igemm(conv_igemm_kernel<float, 128, 0, true, 128, true, 128, true>, grid, lds_, st, a);
+  else if (out_f32) rc = launch_igemm(conv_igemm_kernel<bf16s, 128, 0, true, 128, true, 128, true>, grid, lds_, st, a);
+  else rc = launch_igemm(conv_igemm_kernel<bf16s, 128, 0, false, 128, true, 128, true>, grid, lds_, st, a);
+  if (rc) return rc;
+  NRPN_LAUNCH_CHECK("conv3d_fwd_rows");
+  return NRPN_OK;
+}
+
 static int stem_fwd_impl(const void *x, const void *wp, const float *bias, void *y, int n, int gx, int gy, int gz, int cout,
                          int stride, int dtype, int flags, const nrpn_conv_opts *opts, nrpn_stream_t stream) {
   NRPN_REQUIRE(stride == 1 || stride == 2, "stem: stride must be 1 or 2 (got %d)", stride);
@@ -1770,6 +1821,8 @@ struct WgradArgs {
                       // workgroups from their LDS A tiles; bias_finalize_kernel sums the slices in order (deterministic)
   long long slice_stride;   // elements between the partial gradients of consecutive voxel slices ([ksplit][...] layout of gw)
   Segs segs;          // MODE 0: ragged voxel list (n > 0); the tap-mask word then carries the segment id in bits 27-31
+  const unsigned *rows;   // ROWS kernels: K row k is voxel rows[2 k] of the ragged space with tap word rows[2 k + 1] (csrc/cone.hip); M = list
+                          // length; x / dy are indexed by voxel id.  Bit 13 of the word (centre tap) marks a valid row.
 };
 
 template <typename T> struct WgCfg;
@@ -1823,7 +1876,7 @@ __device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, i
   }
 }
 
-template <typename T, int MODE, bool TR>
+template <typename T, int MODE, bool TR, bool ROWS = false>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   constexpr int KV = WgCfg<T>::KV, RS = WgCfg<T>::RS;
   constexpr int TILE = KV * RS;
@@ -1861,7 +1914,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   // branches); border validity of a voxel for this workgroup's tap comes from a per-voxel 27-bit mask, fetched one chunk
   // ahead so the mask -> address dependency never stalls the data loads.
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
-  const __amdgpu_buffer_rsrc_t mr = make_rsrc(p.vmask, (unsigned)(p.M * 4));
+  const __amdgpu_buffer_rsrc_t mr = ROWS ? make_rsrc(p.rows, (unsigned)(p.M * 8)) : make_rsrc(p.vmask, (unsigned)(p.M * 4));
   // byte shift of this workgroup's tap inside each segment's own grid (classic layout: one entry); the mask word of a voxel
   // carries its segment id in bits 27..31
   __shared__ int seg_shift[kMaxSeg];
@@ -1874,6 +1927,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   }
   __syncthreads();
   unsigned a_voff[PIECES], b_voff[PIECES], m_voff[PIECES], m_next[PIECES];
+  unsigned r_vox[PIECES];        // ROWS: voxel id of the row this piece belongs to in the NEXT chunk (fetched with its tap word)
+  typedef __attribute__((ext_vector_type(2))) unsigned int rowpair;
   const bool use_mask = MODE == 0 && p.taps == 27;
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
@@ -1881,6 +1936,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     const int row = pc / PIECES_ROW, col = (pc % PIECES_ROW) ^ ((row & 3) << 2);   // logical column of physical slot pc % PIECES_ROW
     const long long v = c_begin * KV + row;
     const int ca = m0 + col * (16 / (int)sizeof(T)), cb = n0 + col * (16 / (int)sizeof(T));
+    r_vox[i] = 0;
+    if (MODE == 0 && ROWS) {     // only the column part is loop invariant; the row part comes from the list, chunk by chunk
+      a_voff[i] = ca < p.Cout ? (unsigned)(ca * (int)sizeof(T)) : kOOB;
+      b_voff[i] = cb < p.Cin ? (unsigned)(cb * (int)sizeof(T)) : kOOB;
+      m_voff[i] = (unsigned)(v * 8);
+      const rowpair rp = __builtin_amdgcn_raw_buffer_load_b64(mr, m_voff[i], 0, 0);      // beyond the list: zeros = invalid row
+      r_vox[i] = rp[0]; m_next[i] = rp[1];
+      continue;
+    }
     a_voff[i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * (long long)sizeof(T)) : kOOB;
     b_voff[i] = cb < p.Cin ? (unsigned)((v * p.Cin + cb) * (long long)sizeof(T)) : kOOB;       // the tap shift is added per chunk
     m_voff[i] = (unsigned)(v * 4);
@@ -1888,12 +1952,29 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     if (MODE == 0 && use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
   }
   const unsigned a_step = (unsigned)(KV * p.Cout * (int)sizeof(T)), b_step = (unsigned)(KV * p.Cin * (int)sizeof(T));
+  const unsigned a_rowb = (unsigned)(p.Cout * (int)sizeof(T)), b_rowb = (unsigned)(p.Cin * (int)sizeof(T));
+  // ROWS: addresses of piece i of the chunk whose list entries are in (r_vox, m_next); then fetch the next chunk's entries
+  auto rows_addr = [&](int i, unsigned &aa, unsigned &bb) {
+    const unsigned word = m_next[i];
+    const bool valid = (word >> 13) & 1u;
+    const bool in = p.taps == 27 ? ((word >> tap) & 1u) : valid;
+    aa = (valid && a_voff[i] != kOOB) ? r_vox[i] * a_rowb + a_voff[i] : kOOB;
+    bb = (in && b_voff[i] != kOOB) ? r_vox[i] * b_rowb + b_voff[i] + (unsigned)seg_shift[word >> 27] : kOOB;
+    m_voff[i] += KV * 8;
+    const rowpair rp = __builtin_amdgcn_raw_buffer_load_b64(mr, m_voff[i], 0, 0);
+    r_vox[i] = rp[0]; m_next[i] = rp[1];
+  };
 
   auto load_chunk = [&](long long ch) {
     const long long v0 = ch * KV;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      if (MODE == 0) {
+      if (MODE == 0 && ROWS) {
+        unsigned aa, bb;
+        rows_addr(i, aa, bb);
+        ra[i] = bufld16(dyr, aa);
+        rb[i] = bufld16(xr, bb);
+      } else if (MODE == 0) {
         ra[i] = bufld16(dyr, a_voff[i]);
         const bool in = (m_next[i] >> tap) & 1u;      // 0 beyond the tensor (the mask load itself was out of range)
         rb[i] = bufld16(xr, (in && b_voff[i] != kOOB) ? b_voff[i] + (unsigned)seg_shift[m_next[i] >> 27] : kOOB);
@@ -1950,6 +2031,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int dst = (64 * wave_u + 256 * i) * 16;
+      if (ROWS) {
+        unsigned aa, bb;
+        rows_addr(i, aa, bb);
+        lds_dma16(dyr, A + dst, aa);
+        lds_dma16(xr, B + dst, bb);
+        continue;
+      }
       lds_dma16(dyr, A + dst, a_voff[i]);
       const bool in = (m_next[i] >> tap) & 1u;
       lds_dma16(xr, B + dst, (in && b_voff[i] != kOOB) ? b_voff[i] + (unsigned)seg_shift[m_next[i] >> 27] : kOOB);
@@ -2063,6 +2151,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 // bytes pulled through the CU's vector-memory path per MFMA (the 128x128 tile moves 32 KB per 16 MFMAs per wave and saturates
 // it).  One workgroup = (cout tile, cin tile, tap, voxel slice); fp32 atomics into the packed gradient.
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool ROWS>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs p) {
   typedef bf16s T;
   constexpr int KV = 64, RS = 256, SUB = KV * RS;            // 16 KB sub-tile
@@ -2087,7 +2176,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   if (c_begin >= c_end) return;
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
-  const __amdgpu_buffer_rsrc_t mr = make_rsrc(p.vmask, (unsigned)(p.M * 4));
+  const __amdgpu_buffer_rsrc_t mr = ROWS ? make_rsrc(p.rows, (unsigned)(p.M * 8)) : make_rsrc(p.vmask, (unsigned)(p.M * 4));
   __shared__ int seg_shift[kMaxSeg];            // byte shift of this tap inside each segment's grid (see conv_wgrad_kernel)
   if (tid < kMaxSeg) {
     int Y = p.Y, Z = p.Z;
@@ -2100,6 +2189,8 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   const bool use_mask = p.taps == 27;
   // per thread: rows r_i = tid / 16 + 32 i (i = 0, 1) of every sub-tile, physical 16-byte slot tid % 16
   unsigned a_voff[2][2], b_voff[2][2], m_voff[2], m_next[2];
+  unsigned r_vox[2] = {0u, 0u};   // ROWS: voxel id of this thread's row in the next chunk (fetched with its tap word)
+  typedef __attribute__((ext_vector_type(2))) unsigned int rowpair;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = tid / PIECES_ROW + 32 * i;
@@ -2108,13 +2199,25 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int ca = m0 + 128 * t + col * 8, cb = n0 + 128 * t + col * 8;
-      a_voff[t][i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * 2) : kOOB;
-      b_voff[t][i] = cb < p.Cin ? (unsigned)((v * p.Cin + cb) * 2) : kOOB;                   // the tap shift is added per chunk
+      if (ROWS) {     // only the column part is loop invariant; the row part comes from the list, chunk by chunk
+        a_voff[t][i] = ca < p.Cout ? (unsigned)(ca * 2) : kOOB;
+        b_voff[t][i] = cb < p.Cin ? (unsigned)(cb * 2) : kOOB;
+      } else {
+        a_voff[t][i] = ca < p.Cout ? (unsigned)((v * p.Cout + ca) * 2) : kOOB;
+        b_voff[t][i] = cb < p.Cin ? (unsigned)((v * p.Cin + cb) * 2) : kOOB;                   // the tap shift is added per chunk
+      }
+    }
+    if (ROWS) {
+      m_voff[i] = (unsigned)(v * 8);
+      const rowpair rp = __builtin_amdgcn_raw_buffer_load_b64(mr, m_voff[i], 0, 0);           // beyond the list: zeros = invalid row
+      r_vox[i] = rp[0]; m_next[i] = rp[1];
+      continue;
     }
     m_voff[i] = (unsigned)(v * 4);
     m_next[i] = (v < p.M) ? 1u : 0u;
     if (use_mask) m_next[i] = __builtin_amdgcn_raw_buffer_load_b32(mr, m_voff[i], 0, 0);
   }
+  const unsigned a_rowb = (unsigned)(p.Cout * 2), b_rowb = (unsigned)(p.Cin * 2);
   const unsigned a_step = (unsigned)(KV * p.Cout * 2), b_step = (unsigned)(KV * p.Cin * 2);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto issue_dma = [&](int buf) {
@@ -2122,6 +2225,21 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int dst = (64 * wave_u + 512 * i) * 16;
+      if (ROWS) {
+        const unsigned word = m_next[i];
+        const bool valid = (word >> 13) & 1u;
+        const bool inr = p.taps == 27 ? ((word >> tap) & 1u) : valid;
+        const unsigned ra = r_vox[i] * a_rowb, rb = r_vox[i] * b_rowb + (unsigned)seg_shift[word >> 27];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          lds_dma16(dyr, base + t * SUB + dst, (valid && a_voff[t][i] != kOOB) ? ra + a_voff[t][i] : kOOB);
+          lds_dma16(xr, base + (2 + t) * SUB + dst, (inr && b_voff[t][i] != kOOB) ? rb + b_voff[t][i] : kOOB);
+        }
+        m_voff[i] += KV * 8;
+        const rowpair rp = __builtin_amdgcn_raw_buffer_load_b64(mr, m_voff[i], 0, 0);
+        r_vox[i] = rp[0]; m_next[i] = rp[1];
+        continue;
+      }
       const bool in = (m_next[i] >> tap) & 1u;
       const unsigned tsh = (unsigned)seg_shift[m_next[i] >> 27];
 #pragma unroll
@@ -2545,9 +2663,17 @@ static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
   a.ntiles_n = ntiles_n;
   const size_t lds = 4 * (size_t)WgCfg<T>::KV * WgCfg<T>::RS;
   const bool tr = g_wgrad_tr_mode != 0;
+  dim3 grid((unsigned)(((a.wrows + 127) / 128) * ntiles_n * (MODE == 0 ? a.taps : 1) * a.ksplit));
+  if constexpr (MODE == 0) {
+    if (a.rows) {      // row-list form (transpose-read fragments only)
+      NRPN_LDS((conv_wgrad_kernel<T, 0, true, true>), (int)lds);
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, 0, true, true>), grid, dim3(256), lds, st, a);
+      NRPN_LAUNCH_CHECK("conv_wgrad_rows");
+      return NRPN_OK;
+    }
+  }
   if (tr) NRPN_LDS((conv_wgrad_kernel<T, MODE, true>), (int)lds);
   else NRPN_LDS((conv_wgrad_kernel<T, MODE, false>), (int)lds);
-  dim3 grid((unsigned)(((a.wrows + 127) / 128) * ntiles_n * (MODE == 0 ? a.taps : 1) * a.ksplit));
   if (tr) hipLaunchKernelGGL((conv_wgrad_kernel<T, MODE, true>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<T, MODE, false>), grid, dim3(256), lds, st, a);
   NRPN_LAUNCH_CHECK("conv_wgrad");
@@ -2565,7 +2691,9 @@ extern "C" size_t nrpn_conv3d_wgrad_workspace_bytes(int n, int gx, int gy, int g
 
 static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, float *gbias, long long M, int gx, int gy, int gz,
                              const Segs *segs, int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias, void *workspace,
-                             nrpn_stream_t stream) {
+                             nrpn_stream_t stream, const unsigned *rows = nullptr, long long total_voxels = 0) {
+  // rows != nullptr: row-list form -- M = list length (the K extent), x / dy span `total_voxels` rows and are indexed through the list;
+  // the workspace then holds only the bias partials (the tap words ride in the list)
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_wgrad: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_wgrad: bad dtype %d", dtype);
   const int es = dtype == NRPN_F32 ? 4 : 2;
@@ -2579,16 +2707,18 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1; a.kpad = 0;
   hipStream_t st = as_stream(stream);
   NRPN_REQUIRE(workspace, "conv3d_wgrad: needs its workspace (nrpn_conv3d_wgrad_workspace_bytes)");
-  NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && a.M * cout * es < (1ll << 31), "conv3d_wgrad: tensors must stay below 2 GiB");
-  a.x_bytes = (unsigned)(a.M * cin * es); a.dy_bytes = (unsigned)(a.M * cout * es);
+  const long long span = rows ? total_voxels : a.M;
+  NRPN_REQUIRE(span * cin * es < (1ll << 31) && span * cout * es < (1ll << 31) && a.M * 8 < (1ll << 31), "conv3d_wgrad: tensors must stay below 2 GiB");
+  a.x_bytes = (unsigned)(span * cin * es); a.dy_bytes = (unsigned)(span * cout * es);
+  a.rows = rows;
   a.vmask = reinterpret_cast<const unsigned *>(workspace);
   const bool mask_ready = (accumulate_bias & NRPN_WGRAD_MASK_READY) != 0;     // the caller kept the workspace of an earlier call on this grid
   const bool defer_bias = (accumulate_bias & NRPN_WGRAD_DEFER_BIAS) != 0;     // nrpn_reduce_slices will sum the bias partials
   accumulate_bias &= NRPN_WGRAD_ACC_BIAS;
-  if (ksize == 3 && !mask_ready)
+  if (ksize == 3 && !mask_ready && !rows)
     hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)cdiv64(a.M, 256)), dim3(256), 0, st, reinterpret_cast<unsigned *>(workspace), a.M, gx, gy, gz,
                        a.segs);
-  float *bias_part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + wgrad_mask_bytes(a.M, ksize));
+  float *bias_part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (rows ? 0 : wgrad_mask_bytes(a.M, ksize)));
   a.gbias = gbias ? bias_part : nullptr;
   const WgPlan pl = wgrad_plan(a.M, wrows, cin, a.taps, es, 0, cout, cin);
   a.ksplit = pl.ksplit;
@@ -2600,8 +2730,13 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
     a.ntiles_n = (cin + 255) / 256;
     const int tiles = ((wrows + 255) / 256) * a.ntiles_n * a.taps;
     const size_t lds = 2 * 4 * (size_t)64 * 256;
-    NRPN_LDS(conv_wgrad_big_kernel, (int)lds);
-    hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
+    if (a.rows) {
+      NRPN_LDS(conv_wgrad_big_kernel<true>, (int)lds);
+      hipLaunchKernelGGL(conv_wgrad_big_kernel<true>, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
+    } else {
+      NRPN_LDS(conv_wgrad_big_kernel<false>, (int)lds);
+      hipLaunchKernelGGL(conv_wgrad_big_kernel<false>, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
+    }
     NRPN_LAUNCH_CHECK("conv_wgrad_big");
   }
   if (rc || !gbias || defer_bias) return rc;
@@ -2625,6 +2760,21 @@ extern "C" int nrpn_conv3d_wgrad_ragged(const void *x, const void *dy, float *gw
   long long M = 0;
   if (int rc = fill_segs(sg, nseg, dims, M)) return rc;
   return conv3d_wgrad_impl(x, dy, gw_packed, gbias, M, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, accumulate_bias, workspace, stream);
+}
+
+// Row-list form of the wgrad: dW[tap] = sum over the `nrows` listed voxels v of dY[v] (x) X[v + off(tap)] (list format: csrc/cone.hip; x / dy
+// indexed by voxel id over the ragged space of `dims`).  Slice count / partial layout as nrpn_conv3d_wgrad with n = 1, gx = nrows,
+// gy = gz = 1 (nrpn_conv3d_wgrad_slices); workspace >= slices * wrows floats when gbias is requested (bias partials), may be NULL otherwise.
+extern "C" int nrpn_conv3d_wgrad_rows(const void *x, const void *dy, float *gw_packed, float *gbias, const uint32_t *rows, int64_t nrows,
+                                      int nseg, const int32_t *dims, int cin, int cout, int wrows, int ksize, int dtype, int accumulate_bias,
+                                      void *workspace, nrpn_stream_t stream) {
+  NRPN_REQUIRE(rows && nrows > 0, "conv3d_wgrad_rows: empty row list (the caller zero-fills the gradient instead)");
+  Segs sg{};
+  long long total = 0;
+  if (int rc = fill_segs(sg, nseg, dims, total)) return rc;
+  NRPN_REQUIRE(workspace, "conv3d_wgrad_rows: needs a workspace (>= 256 bytes; slices * wrows floats with a bias gradient)");
+  return conv3d_wgrad_impl(x, dy, gw_packed, gbias, nrows, 1, 1, 1, &sg, cin, cout, wrows, ksize, dtype, accumulate_bias | NRPN_WGRAD_MASK_READY,
+                           workspace, stream, rows, total);
 }
 
 // 1 when a wgrad launch of this shape runs conv_wgrad_big_kernel (256x256 tile), 0 for the 128x128 kernel

@@ -98,9 +98,14 @@ def load():
     return lib
 
 
+KNOB_EPOCH = [0]      # bumped by every nrpn_set_* call: memoised size / plan queries (ops.query) are functions of (arguments, process knobs)
+
+
 def call(name, *args):
     """Call ``nrpn_<name>`` and raise NrpnError with the library's message on a non-zero status."""
     lib = load()
+    if name.startswith("set_"):
+        KNOB_EPOCH[0] += 1
     rc = getattr(lib, "nrpn_" + name)(*args)
     if rc != 0:
         raise NrpnError(f"nrpn_{name} failed ({rc}): {lib.nrpn_last_error().decode()}")

@@ -117,6 +117,26 @@ class RPNHead(nn.Module):
                                          self.bbox_pred.weight, self.cls_logits.bias, self.bbox_pred.bias))
         return outs
 
+    def cone_depth(self):
+        """Number of the lists S_0 .. S_depth a cone plan of this head needs (ops.ConePlan), or None when the head is not the plain
+        [Conv3d k3 + ReLU] x conv_depth chain the cone evaluation is written for."""
+        mods = list(self.conv)
+        if len(mods) % 2:
+            return None
+        for i in range(0, len(mods), 2):
+            cv = mods[i]
+            if not (isinstance(cv, nn.Conv3d) and cv.kernel_size == (3, 3, 3) and cv.stride == (1, 1, 1) and cv.padding == (1, 1, 1)
+                    and cv.in_channels == cv.out_channels and isinstance(mods[i + 1], nn.ReLU)):
+                return None
+        return max(len(mods) // 2 - 1, 0)
+
+    def forward_cone(self, feats_cl: List[Tensor], plan):
+        """Training only: logits [N,T] / deltas [N,T,dw] that are exact on the voxels of the sampled anchors and zero elsewhere
+        (ops.ConeHeadFn: the head evaluated on the sampled-anchor cones of ``plan``)."""
+        convs = [m for m in self.conv if isinstance(m, nn.Conv3d)]
+        return ops.ConeHeadFn.apply(plan, self, self.num_anchors, self.delta_width, *feats_cl, *[c.weight for c in convs], *[c.bias for c in convs],
+                                    self.cls_logits.weight, self.bbox_pred.weight, self.cls_logits.bias, self.bbox_pred.bias)
+
     def forward(self, x: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
         dt = x[0].dtype
         fused = self.forward_fused([hip_nn.as_ndhwc(f, dt) for f in x])

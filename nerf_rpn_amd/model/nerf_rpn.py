@@ -116,6 +116,8 @@ class NeRFRegionProposalNetwork(nn.Module):
                     prepared = self.rpn.prepare_targets(size, grids, targets, original_mesh_sizes, dev)
                 main.wait_stream(self._prep_stream)
                 for v in list(prepared.values()) + [targets]:       # produced on the side stream, consumed (and later freed) on the main one
+                    if isinstance(v, ops.ConePlan):
+                        v = v.tensors()
                     for t in (v if isinstance(v, (list, tuple)) else [v]):
                         if isinstance(t, torch.Tensor) and t.is_cuda:
                             t.record_stream(main)

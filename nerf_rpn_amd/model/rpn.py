@@ -120,6 +120,7 @@ class RegionProposalNetwork(nn.Module):
         self.fix_obb_clip = False            # True = drop scores/levels together with out-of-grid OBBs (quirk B3 fixed)
         self.loss_2d_requires_grad = True    # trainers set False when reg_loss_weight_2d == 0 (value is still reported)
         self.sampler_hook = None             # tests: callable(labels_list) -> (pos_idx, neg_idx) over the flat batch
+        self.use_cone = True                 # training: evaluate the head on the sampled-anchor cones only (ops.ConeHeadFn); False = dense head
         self.compute_dtype = torch.float32
         self.last_aux = {}
 
@@ -184,6 +185,20 @@ class RegionProposalNetwork(nn.Module):
             matched.append(m)
         return labels, matched
 
+    def _cone_depth(self, n, grids, device):
+        """Depth of the cone plan of a training step (ops.ConePlan), or None when the head runs densely: switched off, CPU tensors, a
+        head that is not the plain conv chain, more (level, scene) segments than the ragged conv kernels take, or a channel row that is
+        not a whole number of 128-byte K-steps."""
+        if not (ops.CONE_ENABLED[0] and self.use_cone) or torch.device(device).type != "cuda" or len(grids) * n > 16:
+            return None
+        depth = self.head.cone_depth() if hasattr(self.head, "cone_depth") else None
+        if depth is None:
+            return None
+        es = 2 if self.compute_dtype == torch.bfloat16 else 4
+        if (self.head.cls_logits.in_channels * es) % 128 or (self.head.head_rows * es) % 128:
+            return None
+        return depth
+
     def prepare_targets(self, mesh_size, grids, targets: List[Tensor], original_mesh_sizes, device, pending_flags=None):
         """Everything of the training loss that does not depend on the network output: anchor table, IoU + matcher labels, the
         sampled positives / negatives, their matched ground truth, regression targets and anchors.  The model calls this BEFORE the
@@ -196,10 +211,17 @@ class RegionProposalNetwork(nn.Module):
         labels, matched = self.assign_targets_to_anchors(table, targets, original_mesh_sizes if n > 1 else None, pad)
         T = table.total
         flags = None
+        # Sampled-anchor cones: the loss reads the head at the sampled anchors only, so the head runs on their receptive-field cones
+        # (ops.ConeHeadFn); the voxel lists are built right behind the sampler kernels and their sizes ride on the sampler's read-back.
+        depth = self._cone_depth(n, grids, device)
+        cone = ops.ConePlan(grids, n, depth, device) if depth is not None else None
         if self.sampler_hook is not None:
             pos, neg = self.sampler_hook(labels)
+            if cone is not None:
+                ops.cone_from_indices(cone, pos.to(device), neg.to(device), table)
         else:
-            pairs, flags = self.fg_bg_sampler.sample_batch(labels, pending_flags)     # the one host read-back of a training step
+            hook = None if cone is None else (lambda op_, on_, cnt_: (ops.cone_build(cone, op_, on_, cnt_, table), cone.finish))
+            pairs, flags = self.fg_bg_sampler.sample_batch(labels, pending_flags, hook)     # the one host read-back of a training step
             if n == 1:
                 pos, neg = pairs[0]
             else:
@@ -227,7 +249,7 @@ class RegionProposalNetwork(nn.Module):
         reg_targets = ops.encode_boxes(table, matched_gt, local, int(self.rotate))
         anchors_pos = ops.anchors(table, local)
         return dict(mesh_size=tuple(mesh_size), grids=[tuple(g) for g in grids], table=table, pad=pad, labels=labels, matched=matched,
-                    flags=flags, pos=pos, neg=neg, matched_gt=matched_gt, reg_targets=reg_targets, anchors_pos=anchors_pos)
+                    flags=flags, pos=pos, neg=neg, matched_gt=matched_gt, reg_targets=reg_targets, anchors_pos=anchors_pos, cone=cone)
 
     def compute_loss(self, prep, logits, deltas, max_mesh_dim):
         """reference rpn.py:372-456 on the sampled rows only."""
@@ -273,14 +295,20 @@ class RegionProposalNetwork(nn.Module):
                 objectness_output_paths=None, prepared=None):
         dt = features[0].dtype
         feats_cl = [hip_nn.as_ndhwc(f, dt) for f in features]
-        heads = self.head.forward_fused(feats_cl)
         n = meshes.shape[0]
         mesh_size = tuple(int(v) for v in meshes.shape[-3:])
         grids = [tuple(int(v) for v in f.shape[1:4]) for f in feats_cl]
         A, dw = self.head.num_anchors, self.num_delta_digits
-        if objectness_output_paths is not None:
-            self.output_objectness([hip_nn.as_ncdhw(h[..., :A]) for h in heads], original_mesh_sizes, objectness_output_paths)
-        logits, deltas = ops.FlattenHeadFn.apply(A, dw, dt, *[h.reshape(n, -1, h.shape[-1]) for h in heads])
+        cone = prepared.get("cone") if (self.training and prepared is not None and objectness_output_paths is None
+                                        and prepared["grids"] == grids and prepared["mesh_size"] == mesh_size) else None
+        if cone is not None:
+            # training: only the sampled anchors' logits / deltas are read below, so the head is evaluated on their cones (zeros elsewhere)
+            logits, deltas = self.head.forward_cone(feats_cl, cone)
+        else:
+            heads = self.head.forward_fused(feats_cl)
+            if objectness_output_paths is not None:
+                self.output_objectness([hip_nn.as_ncdhw(h[..., :A]) for h in heads], original_mesh_sizes, objectness_output_paths)
+            logits, deltas = ops.FlattenHeadFn.apply(A, dw, dt, *[h.reshape(n, -1, h.shape[-1]) for h in heads])
         boxes = scores = level_indexes = None
         losses = {}
         if not self.training:

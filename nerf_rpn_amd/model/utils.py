@@ -92,7 +92,7 @@ class BalancedPositiveNegativeSampler:
         q = neg[torch.randperm(neg.numel(), device=neg.device)[:n_neg]]
         return p.sort()[0], q.sort()[0]
 
-    def sample_batch(self, labels: List[Tensor], extra_flags=None):
+    def sample_batch(self, labels: List[Tensor], extra_flags=None, before_readback=None):
         """All scenes of a batch -> ([(pos_idx, neg_idx)], host values of ``extra_flags``).  On the device this is the fused sampler
         kernel (ops.sample_pos_neg: no torch.where / randperm, ONE host read-back for the whole batch, which also carries the caller's
         pending 0-dim flags); the draw is seeded from torch's CPU generator, so torch.manual_seed makes it reproducible."""
@@ -100,7 +100,7 @@ class BalancedPositiveNegativeSampler:
             from .. import ops
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             return ops.sample_pos_neg([lab.float() for lab in labels], self.batch_size_per_image,
-                                      int(self.batch_size_per_image * self.positive_fraction), seed, extra_flags)
+                                      int(self.batch_size_per_image * self.positive_fraction), seed, extra_flags, before_readback)
         return [self.sample_indices(lab) for lab in labels], [bool(f) for f in (extra_flags or [])]
 
     def __call__(self, matched_idxs: List[Tensor]):

@@ -10,7 +10,35 @@ import math
 import torch
 
 from . import lib
-from .lib import BF16, CONV_BIAS, CONV_OUT_F32, CONV_RELU, F32, call, query
+from .lib import BF16, CONV_BIAS, CONV_OUT_F32, CONV_RELU, F32, call
+
+# Size / plan queries of the C ABI are pure functions of (arguments, process-wide tool knobs): a training step asks the same ~40 of them
+# ~600 times, each a ctypes crossing with argument conversion (~3 us).  Memoised per (name, arguments) and dropped whenever a
+# nrpn_set_* knob is touched (lib.KNOB_EPOCH).  Queries that take an nrpn_conv_opts pointer are keyed on the descriptor's plan fields.
+_QCACHE = {"epoch": -1, "map": {}}
+
+
+def query(name, *args):
+    if _QCACHE["epoch"] != lib.KNOB_EPOCH[0]:
+        _QCACHE["epoch"], _QCACHE["map"] = lib.KNOB_EPOCH[0], {}
+    m = _QCACHE["map"]
+    key = (name, args)
+    v = m.get(key)
+    if v is None:
+        v = m[key] = lib.query(name, *args)
+    return v
+
+
+def _query_opts(name, opts, *args):
+    """``query`` for the *_ex entry points: the nrpn_conv_opts descriptor is the last argument; its plan fields (not its address) key the cache."""
+    if _QCACHE["epoch"] != lib.KNOB_EPOCH[0]:
+        _QCACHE["epoch"], _QCACHE["map"] = lib.KNOB_EPOCH[0], {}
+    m = _QCACHE["map"]
+    key = (name, args, opts.tile, opts.lds_dma, opts.kstep_bytes, opts.stagger, opts.big_split, opts.debug, bool(opts.scale), bool(opts.relu_mask))
+    v = m.get(key)
+    if v is None:
+        v = m[key] = lib.query(name, *args, opts.ptr())
+    return v
 
 
 import os as _os
@@ -154,18 +182,21 @@ def rotated_iou_loss(pred, target, mode):
 _SAMPLE_WS = {}
 
 
-def sample_pos_neg(labels, batch, max_pos, seed, extra_flags=None):
+def sample_pos_neg(labels, batch, max_pos, seed, extra_flags=None, before_readback=None):
     """Balanced sampler of every scene in ONE host read-back (reference BalancedPositiveNegativeSampler, model/utils.py:35-98).
     labels: list of [T] float32 device tensors; seed: python int (one draw per call; scene i uses seed + i).
     -> ([(pos_i, neg_i)], host list of ``extra_flags``): int64 ascending index tensors; ``extra_flags`` (a list of 0-dim device tensors)
-    ride on the same device->host copy so that callers with their own pending checks do not synchronise a second time."""
+    ride on the same device->host copy so that callers with their own pending checks do not synchronise a second time.
+    ``before_readback(out_pos, out_neg, counts)``: optional; enqueues more work on the sampler's raw output (device int64 [n, max_pos],
+    int64 [n, batch], int32 (kp, kn, err) per scene) and returns ``(int32 device vector, finish)``: the vector rides on the same copy and
+    ``finish(host values)`` is called after it (the cone lists of the RPN head are built this way, ``cone_build``)."""
     n = len(labels)
     dev = labels[0].device
     for lab in labels:
         if lab.dtype != torch.float32 or lab.dim() != 1:
             raise TypeError("sample_pos_neg: labels must be 1-D float32")
         _chk(lab.contiguous())
-    wsb = int(lib.query("sample_workspace_bytes"))
+    wsb = int(query("sample_workspace_bytes"))
     key = (str(dev), n, batch, max_pos, _s())
     if key not in _SAMPLE_WS:          # per-scene scratch of this stream, reused every step (stream-ordered)
         _SAMPLE_WS[key] = torch.empty((n, (wsb + 7) // 8), dtype=torch.int64, device=dev)
@@ -179,7 +210,14 @@ def sample_pos_neg(labels, batch, max_pos, seed, extra_flags=None):
              _p(out_pos[i]), _p(out_neg[i]), _p(counts[3 * i:]), _s())
     if nx:
         counts[3 * n:] = torch.stack([f.reshape(()) for f in extra_flags]).to(torch.int32)
-    host = counts.cpu().tolist()                      # the one synchronisation
+    finish = None
+    if before_readback is not None:
+        more, finish = before_readback(out_pos, out_neg, counts)
+        host = torch.cat([counts, more.to(torch.int32).reshape(-1)]).cpu().tolist()      # the one synchronisation
+        finish(host[3 * n + nx:])
+        host = host[:3 * n + nx]
+    else:
+        host = counts.cpu().tolist()                  # the one synchronisation
     res = []
     for i in range(n):
         kp, kn, err = host[3 * i:3 * i + 3]
@@ -238,7 +276,7 @@ def segmented_topk(scores, offsets, k):
     idx = torch.empty((nseg, k), dtype=torch.int32, device=scores.device)
     val = torch.empty((nseg, k), dtype=torch.float32, device=scores.device)
     host = (ctypes.c_int64 * (nseg + 1))(*[int(o) for o in offsets])
-    nbytes = int(lib.query("segmented_topk_workspace_bytes", nseg, int(k)))
+    nbytes = int(query("segmented_topk_workspace_bytes", nseg, int(k)))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=scores.device)
     call("segmented_topk_f32_ws", _p(scores), ctypes.addressof(host), nseg, int(k), _p(idx), _p(val), _p(ws), nbytes, _s())
     return idx, val
@@ -675,14 +713,14 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask
         return y
     opts = lib.ConvOpts(tile=tile or CONV_TILE[0], scale=_p(scale), relu_mask=_p(mask))
     if stats is not None and segs is None and mask is None and out_dtype == x.dtype and wrows == cout:
-        rows = query("conv3d_fwd_stats_rows_ex", n, gx, gy, gz, cin, cout, ksize, _dt(x), opts.ptr())
+        rows = _query_opts("conv3d_fwd_stats_rows_ex", opts, n, gx, gy, gz, cin, cout, ksize, _dt(x))
         if rows > 0:
             part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
             opts.stats = part.data_ptr()
             call("conv3d_fwd_ex", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, 0, opts.ptr(), _s())
             stats["partials"] = part
             return y
-    wsb = query("conv3d_fwd_workspace_bytes_ex", n, gx, gy, gz, cin, cout, ksize, _dt(x), opts.ptr())
+    wsb = _query_opts("conv3d_fwd_workspace_bytes_ex", opts, n, gx, gy, gz, cin, cout, ksize, _dt(x))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     call("conv3d_fwd_ex", _p(x), _p(wp), _p(bias), _p(y), n, gx, gy, gz, cin, cout, wrows, ksize, _dt(x), flags, _p(ws), opts.ptr(), _s())
     return y
@@ -839,38 +877,312 @@ class ConvFn(torch.autograd.Function):
             dims = _seg_dims(segs)
             call("conv3d_wgrad_ragged", _p(x), _p(dy), _p(gwp), _p(gb), len(segs), ctypes.addressof(dims), cin, rows_total, rows_total, ksize,
                  _dt(x), wflags, _p(ws), _s())
-        gws, gbs, row = [], [], 0
-        for i, w in enumerate(weights):
-            if wsinks[i] is not None and wsinks[i].flat is not None and nw == 1 and rows_total == w.shape[0]:
-                # the arena keeps this gradient in the partials' own layout: ordered sum of the slices, added in place
-                bias_part = ws.data_ptr() + query("conv3d_wgrad_bias_offset", n, gx, gy, gz, ksize) if defer_bias else 0
-                call("reduce_slices", _p(gwp), slices, gwp[0].numel(), _p(wsinks[i].flat), 1, bias_part, rows_total, rows_total,
-                     _p(gb) if defer_bias else 0, 1, _s())
-                wsinks[i].notify()
-                gws.append(None)
-            elif wsinks[i] is not None:
-                if not wsinks[i].slot.is_contiguous():
-                    raise lib.NrpnError("a GEMM-layout arena weight reached a fused multi-weight GEMM (mark the module _nrpn_fused_gemm)")
-                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(wsinks[i].slot), 1, slices, _s())
-                wsinks[i].notify()
-                gws.append(None)
+        bias_part = ws.data_ptr() + query("conv3d_wgrad_bias_offset", n, gx, gy, gz, ksize) if defer_bias else 0
+        return _deliver_wgrad(weights, wsinks, bsinks, gwp, gb, bias_part, slices, rows_total, cin, taps, has_bias, direct_bias, defer_bias)
+
+
+def _deliver_wgrad(weights, wsinks, bsinks, gwp, gb, bias_part, slices, rows_total, cin, taps, has_bias, direct_bias, defer_bias):
+    """Sum the per-slice partial gradients ``gwp`` [slices, taps, rows_total, cin] of a (possibly fused multi-weight) GEMM into their
+    destinations: the flat gradient arena (GradSink) or fresh tensors handed back to autograd.  -> (*weight grads, *bias grads), None where
+    a sink took the gradient."""
+    nw = len(weights)
+    gws, gbs, row = [], [], 0
+    for i, w in enumerate(weights):
+        if wsinks[i] is not None and wsinks[i].flat is not None and nw == 1 and rows_total == w.shape[0]:
+            # the arena keeps this gradient in the partials' own layout: ordered sum of the slices, added in place
+            call("reduce_slices", _p(gwp), slices, gwp[0].numel(), _p(wsinks[i].flat), 1, bias_part if defer_bias else 0, rows_total, rows_total,
+                 _p(gb) if defer_bias else 0, 1, _s())
+            wsinks[i].notify()
+            gws.append(None)
+        elif wsinks[i] is not None:
+            if not wsinks[i].slot.is_contiguous():
+                raise lib.NrpnError("a GEMM-layout arena weight reached a fused multi-weight GEMM (mark the module _nrpn_fused_gemm)")
+            call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(wsinks[i].slot), 1, slices, _s())
+            wsinks[i].notify()
+            gws.append(None)
+        else:
+            gw = torch.empty_like(w, dtype=torch.float32)
+            call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(gw), 0, slices, _s())
+            gws.append(gw)
+        if not has_bias:
+            gbs.append(None)
+        elif direct_bias:
+            bsinks[0].notify()
+            gbs.append(None)
+        elif bsinks[i] is not None:
+            bsinks[i].slot.add_(gb[row:row + w.shape[0]])
+            bsinks[i].notify()
+            gbs.append(None)
+        else:
+            gbs.append(gb[row:row + w.shape[0]].clone())
+        row += w.shape[0]
+    return (*gws, *gbs)
+
+
+def _on_wgrad_stream(device, tensors, sinks_complete, fn):
+    """Run ``fn()`` (a weight-gradient launch sequence whose results all go into GradSinks) on the weight-gradient side stream behind the
+    current stream, or inline when the side stream is off / a gradient has to be handed back to autograd."""
+    side = _wgrad_side_stream(device) if sinks_complete else None
+    if side is None:
+        return fn()
+    main = torch.cuda.current_stream(device)
+    side.wait_stream(main)
+    for t in tensors:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        res = fn()
+    if not _WGRAD_SIDE["dirty"]:
+        _WGRAD_SIDE["dirty"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(wgrad_stream_join)
+    return res
+
+
+# ======================================================================================================================
+# sampled-anchor cones of the RPN head (training)
+# ======================================================================================================================
+CONE_ENABLED = [_os.environ.get("NRPN_CONE", "1") != "0"]      # A/B switch: cone evaluation of the RPN head in training; default on
+
+
+class ConePlan:
+    """Sorted voxel lists S_0 c ... c S_depth of one training step (csrc/cone.hip) over the ragged (level-major, scene-major) voxel space
+    of the pyramid: ``lists`` int32 [depth + 1, total, 2] on the device, ``counts`` on the host once the sampler's read-back has happened."""
+
+    def __init__(self, grids, n_scenes, depth, device):
+        import ctypes
+        self.grids = [tuple(int(v) for v in g) for g in grids]
+        self.n, self.depth = int(n_scenes), int(depth)
+        self.segs = [g for g in self.grids for _ in range(self.n)]
+        self.nseg = len(self.segs)
+        self.dims = _seg_dims(self.segs)
+        self.dims_ptr = ctypes.addressof(self.dims)
+        self.cells = [g[0] * g[1] * g[2] for g in self.grids]
+        self.level_start = [0]
+        for c in self.cells:
+            self.level_start.append(self.level_start[-1] + c * self.n)
+        self.total = self.level_start[-1]
+        self.lists = torch.empty((self.depth + 1, self.total, 2), dtype=torch.int32, device=device)
+        self.counts_dev = torch.empty(self.depth + 2, dtype=torch.int32, device=device)
+        self.counts = None
+
+    def finish(self, host):
+        if host[self.depth + 1]:
+            raise RuntimeError("cone_build: a sampled anchor index lies outside the anchor pyramid")
+        self.counts = [int(v) for v in host[:self.depth + 1]]
+
+    def rows(self, k):
+        return self.lists[k].data_ptr(), self.counts[k]
+
+    def tensors(self):
+        return [self.lists, self.counts_dev]
+
+
+def cone_from_indices(plan, pos, neg, table):
+    """Build ``plan`` from flat batch indices (scene * T + anchor), e.g. a test's injected sample; synchronises (sizes of boolean selections)."""
+    T, n = table.total, plan.n
+    ps = [(pos[(pos >= i * T) & (pos < (i + 1) * T)] - i * T).long() for i in range(n)]
+    ns = [(neg[(neg >= i * T) & (neg < (i + 1) * T)] - i * T).long() for i in range(n)]
+    mp, mn = max(1, max(p.numel() for p in ps)), max(1, max(q.numel() for q in ns))
+    dev = plan.lists.device
+    out_pos = torch.zeros((n, mp), dtype=torch.int64, device=dev)
+    out_neg = torch.zeros((n, mn), dtype=torch.int64, device=dev)
+    cnt = []
+    for i in range(n):
+        out_pos[i, :ps[i].numel()] = ps[i]
+        out_neg[i, :ns[i].numel()] = ns[i]
+        cnt += [ps[i].numel(), ns[i].numel(), 0]
+    counts = torch.tensor(cnt, dtype=torch.int32, device=dev)
+    plan.finish(cone_build(plan, out_pos, out_neg, counts, table).cpu().tolist())
+    return plan
+
+
+def cone_build(plan, out_pos, out_neg, counts, table):
+    """Enqueue the list build of ``plan`` on the current stream from the sampler's raw output (see sample_pos_neg); no synchronisation."""
+    import ctypes
+    if table.A * sum(plan.cells) != table.total or len(table.counts) != len(plan.grids):
+        raise lib.NrpnError("cone_build: the anchor table and the feature grids disagree")
+    offs = (ctypes.c_int64 * (len(table.offsets)))(*[int(v) for v in table.offsets])
+    ws = torch.empty(query("cone_workspace_bytes", plan.total), dtype=torch.uint8, device=out_pos.device)
+    call("cone_build", _p(out_pos), _p(out_neg), _p(counts), plan.n, out_pos.shape[1], out_neg.shape[1], len(plan.grids), ctypes.addressof(offs),
+         table.A, plan.dims_ptr, plan.depth, _p(plan.lists), plan.total, _p(plan.counts_dev), _p(ws), _s())
+    return plan.counts_dev
+
+
+def conv_rows_fwd(x, wp, bias, y, plan, k, cin, cout, wrows, ksize, flags, mask=None):
+    """Forward / dgrad of a k1 / k3 conv on the rows of list S_k only: x [total, cin], y [total, cout] (rows outside the list untouched)."""
+    rows, nrows = plan.rows(k)
+    if nrows == 0:
+        return y
+    if y.dtype == torch.float32 and x.dtype == torch.bfloat16:
+        flags |= CONV_OUT_F32
+    if bias is not None:
+        flags |= CONV_BIAS
+    call("conv3d_fwd_rows", _p(x), _p(wp), _p(bias), _p(y), rows, nrows, plan.nseg, plan.dims_ptr, cin, cout, wrows, ksize, _dt(x), flags, _p(mask), _s())
+    return y
+
+
+def conv_rows_wgrad(x, dy, weights, biases, rows_total, ksize, plan, k):
+    """Weight (+ bias) gradient of a conv from the rows of S_k only (dy is zero elsewhere); delivery as ConvFn._wgrad."""
+    rows, nrows = plan.rows(k)
+    cin = x.shape[-1]
+    taps = ksize ** 3
+    nw = len(weights)
+    wsinks, bsinks = [_sink(w) for w in weights], [_sink(b) for b in biases]
+    has_bias = biases[0] is not None
+    if nrows == 0:      # nothing sampled: zero gradients (sinks are only told that this use of the parameter is done)
+        out = []
+        for t, sk in list(zip(weights, wsinks)) + list(zip(biases, bsinks)):
+            if t is None:
+                out.append(None)
+            elif sk is not None:
+                sk.notify()
+                out.append(None)
             else:
-                gw = torch.empty_like(w, dtype=torch.float32)
-                call("unpack_conv_wgrad", _p(gwp), w.shape[0], cin, taps, rows_total, row, _p(gw), 0, slices, _s())
-                gws.append(gw)
-            if not has_bias:
-                gbs.append(None)
-            elif direct_bias:
-                bsinks[0].notify()
-                gbs.append(None)
-            elif bsinks[i] is not None:
-                bsinks[i].slot.add_(gb[row:row + w.shape[0]])
-                bsinks[i].notify()
-                gbs.append(None)
-            else:
-                gbs.append(gb[row:row + w.shape[0]].clone())
-            row += w.shape[0]
-        return (*gws, *gbs)
+                out.append(torch.zeros_like(t, dtype=torch.float32))
+        return tuple(out)
+    slices = query("conv3d_wgrad_slices", 1, nrows, 1, 1, cin, rows_total, rows_total, ksize, _dt(x))
+    gwp = torch.empty((slices, taps, rows_total, cin), dtype=torch.float32, device=x.device)
+    direct_bias = has_bias and nw == 1 and bsinks[0] is not None
+    gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
+    ws = torch.empty(max(256, slices * rows_total * 4), dtype=torch.uint8, device=x.device)
+    fused_reduce = nw == 1 and wsinks[0] is not None and wsinks[0].flat is not None and rows_total == weights[0].shape[0]
+    defer_bias = fused_reduce and direct_bias
+    wflags = int(direct_bias) | (4 if defer_bias else 0)
+    call("conv3d_wgrad_rows", _p(x), _p(dy), _p(gwp), _p(gb), rows, nrows, plan.nseg, plan.dims_ptr, cin, rows_total, rows_total, ksize, _dt(x),
+         wflags, _p(ws), _s())
+    return _deliver_wgrad(weights, wsinks, bsinks, gwp, gb, ws.data_ptr(), slices, rows_total, cin, taps, has_bias, direct_bias, defer_bias)
+
+
+class ConeHeadFn(torch.autograd.Function):
+    """The whole RPN head in training -- conv_depth x [Conv3d k3 + ReLU] + the fused cls / bbox GEMM over all pyramid levels + the
+    reference's flatten (anchor.py:RPNHead, rpn.py:105-130) -- evaluated on the sampled-anchor cones of ``plan`` only: layer i (0-based,
+    D layers) is computed on S_{D-1-i}, the output GEMM on S_0; backward visits the same sets (weight gradients from the listed rows, input
+    gradients on the next larger set, the first layer's input gradient densely per level for the FPN).  One autograd node, ~25 launches,
+    instead of ~150 for the dense head at four levels.  logits / deltas are exact on the sampled anchors' voxels and ZERO elsewhere: only
+    the training loss, which reads the sampled rows, may consume them (RegionProposalNetwork.forward decides)."""
+
+    @staticmethod
+    def forward(ctx, plan, head, A, dw, *tensors):
+        L = len(plan.grids)
+        feats = tensors[:L]
+        convs = [m for m in head.conv if isinstance(m, torch.nn.Conv3d)]
+        D = len(convs)
+        cw, cb = tensors[L:L + D], tensors[L + D:L + 2 * D]
+        ow, ob = tensors[L + 2 * D:L + 2 * D + 2], tensors[L + 2 * D + 2:L + 2 * D + 4]
+        if plan.depth != max(D - 1, 0):
+            raise lib.NrpnError("ConeHeadFn: the plan must hold the lists S_0 .. S_{conv_depth - 1}")
+        n, C = feats[0].shape[0], feats[0].shape[-1]
+        dt = feats[0].dtype
+        dev = feats[0].device
+        V = plan.total
+        for f in feats:
+            _chk(f)
+        x0 = torch.cat([f.reshape(-1, C) for f in feats], dim=0)
+        if x0.shape[0] != V:
+            raise lib.NrpnError("ConeHeadFn: feature maps and cone plan disagree on the voxel count")
+        from .model.hip_nn import _pack_of
+        hs, ops_w = [x0], []
+        need_dgrad = any(f.requires_grad for f in feats)
+        for i, cv in enumerate(convs):
+            wp, wpd = _pack_of(cv).get([cw[i]], dt, C, True, C)
+            bias = cb[i].detach().float().contiguous() if cb[i] is not None else None
+            y = torch.empty((V, C), dtype=dt, device=dev)
+            conv_rows_fwd(hs[-1], wp, bias, y, plan, D - 1 - i, C, C, C, 3, CONV_RELU)
+            hs.append(y)
+            ops_w.append(wpd)
+        rows_total = head.head_rows
+        wpo, wpdo = head._pack.get(list(ow), dt, rows_total, True, C)
+        bias_o = None
+        if ob[0] is not None:
+            pack = head._pack
+            bkey = tuple((b.data_ptr(), b._version) for b in ob) + (rows_total, _weight_epoch)
+            if getattr(pack, "bias_key", None) != bkey:
+                parts = [b.detach().float().reshape(-1) for b in ob]
+                used = sum(p.numel() for p in parts)
+                if used < rows_total:
+                    parts.append(parts[0].new_zeros(rows_total - used))
+                pack.bias, pack.bias_key = torch.cat(parts), bkey
+            bias_o = pack.bias
+        out = torch.zeros((V, rows_total), dtype=torch.float32, device=dev)
+        conv_rows_fwd(hs[-1], wpo, bias_o, out, plan, 0, C, rows_total, rows_total, 1, 0)
+        T = sum(plan.cells) * A
+        logits = torch.empty((n, T), dtype=torch.float32, device=dev)
+        deltas = torch.empty((n, T, dw), dtype=torch.float32, device=dev)
+        off = 0
+        for l, c in enumerate(plan.cells):
+            for i in range(n):
+                r0 = plan.level_start[l] + i * c
+                call("head_flatten_f32", _p(out[r0:r0 + c]), c, rows_total, A, dw, _p(logits[i, off:]), _p(deltas[i, off:]), _s())
+            off += c * A
+        ctx.save_for_backward(*hs, *ops_w, wpdo, *cw, *[b for b in cb if b is not None], *ow, *[b for b in ob if b is not None])
+        ctx.meta = (plan, head, A, dw, L, D, n, C, dt, rows_total, [b is not None for b in cb], [b is not None for b in ob], need_dgrad)
+        return logits, deltas
+
+    @staticmethod
+    def backward(ctx, g_logits, g_deltas):
+        IN_BACKWARD[0] += 1
+        try:
+            return ConeHeadFn._backward(ctx, g_logits, g_deltas)
+        finally:
+            IN_BACKWARD[0] -= 1
+
+    @staticmethod
+    def _backward(ctx, g_logits, g_deltas):
+        plan, head, A, dw, L, D, n, C, dt, rows_total, has_cb, has_ob, need_dgrad = ctx.meta
+        saved = list(ctx.saved_tensors)
+        hs, saved = saved[:D + 1], saved[D + 1:]
+        wpds, saved = saved[:D], saved[D:]
+        wpdo, saved = saved[0], saved[1:]
+        cw, saved = saved[:D], saved[D:]
+        cb = []
+        for h in has_cb:
+            cb.append(saved.pop(0) if h else None)
+        ow, saved = saved[:2], saved[2:]
+        ob = [saved.pop(0) if h else None for h in has_ob]
+        dev = hs[0].device
+        V = plan.total
+        g_logits, g_deltas = g_logits.contiguous(), g_deltas.contiguous()
+        dout = torch.empty((V, rows_total), dtype=dt, device=dev)
+        off = 0
+        for l, c in enumerate(plan.cells):
+            for i in range(n):
+                r0 = plan.level_start[l] + i * c
+                call("head_unflatten", _p(g_logits[i, off:]), _p(g_deltas[i, off:]), c, rows_total, A, dw, 0, _p(dout[r0:r0 + c]), _dt(dout), _s())
+            off += c * A
+        _wait_dgrad_operands()
+
+        def sinks_ok(ws_, bs_):
+            return all(_sink(w) is not None for w in ws_) and all(_sink(b) is not None for b in bs_ if b is not None)
+
+        # output GEMM: weight / bias gradients from the rows of S_0; input gradient on S_0 with the last layer's ReLU mask
+        g_ow = _on_wgrad_stream(dev, [hs[D], dout, plan.lists], sinks_ok(ow, ob),
+                                lambda: conv_rows_wgrad(hs[D], dout, list(ow), list(ob), rows_total, 1, plan, 0))
+        dh = torch.zeros((V, C), dtype=dt, device=dev)
+        conv_rows_fwd(dout, wpdo, None, dh, plan, 0, rows_total, C, C, 1, 0, mask=hs[D] if D > 0 else None)
+        g_cw, g_cb = [None] * D, [None] * D
+        g_feats = [None] * L
+        if D == 0 and need_dgrad:       # no hidden layers: the output GEMM reads the FPN maps directly
+            for l in range(L):
+                g = plan.grids[l]
+                g_feats[l] = dh[plan.level_start[l]:plan.level_start[l + 1]].view(n, g[0], g[1], g[2], C)
+        for i in range(D - 1, -1, -1):
+            k = D - 1 - i
+            x_i, dy_i = hs[i], dh
+            res = _on_wgrad_stream(dev, [x_i, dy_i, plan.lists], sinks_ok([cw[i]], [cb[i]]),
+                                   lambda x_i=x_i, dy_i=dy_i, i=i, k=k: conv_rows_wgrad(x_i, dy_i, [cw[i]], [cb[i]], C, 3, plan, k))
+            g_cw[i] = res[0]
+            g_cb[i] = res[1] if len(res) > 1 else None
+            if i > 0:
+                dprev = torch.zeros((V, C), dtype=dt, device=dev)
+                conv_rows_fwd(dh, wpds[i], None, dprev, plan, k + 1, C, C, C, 3, 0, mask=hs[i])
+                dh = dprev
+            elif need_dgrad:
+                # first layer: its input gradient goes to the FPN output convs of every level -- dense, per level (halo kernel on the
+                # finest grid); dh is zero outside S_{D-1}
+                for l, c in enumerate(plan.cells):
+                    g = plan.grids[l]
+                    dyl = dh[plan.level_start[l]:plan.level_start[l + 1]].view(n, g[0], g[1], g[2], C)
+                    g_feats[l] = _conv_fwd(dyl, wpds[0], None, C, C, 3, 0, dt)
+        return (None, None, None, None, *g_feats, *g_cw, *g_cb, *g_ow)
 
 
 STEM_HALO = [_os.environ.get("NRPN_STEM_HALO", "1") != "0"]      # A/B switch: halo-form stem forward (bf16, stride 2, even Z, Cout 64); default on
