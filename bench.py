@@ -345,6 +345,21 @@ def eval_forward_protocol(dtype_name, dev, iters=20, warm=3):
             "note": "eval forward incl. decode / top-k / NMS at the reference's benchmark shape (run_rpn.py:594-617)"}
 
 
+def measured_ceiling():
+    """What the MFMA array sustains at the part's power cap on the operands the conv layers multiply (tools/mfma_peak_probe.py: a
+    register-only v_mfma_f32_32x32x16_bf16 loop, post-ReLU activations x small weights) -- profiles/r04_mfma_ceiling.json."""
+    path = os.path.join(ROOT, "profiles", "r04_mfma_ceiling.json")
+    if not os.path.exists(path):
+        return None
+    rows = json.load(open(path)).get("rows", [])
+    pick = [r for r in rows if r.get("operands") == "relu_randn_x_w0.05" and r.get("waves_per_simd") == 2]
+    if not pick:
+        return None
+    r = pick[0]
+    return {"tflops": r["tflops"], "power_w": r["power_w"], "sclk_mhz": r["sclk_mhz"], "source": "profiles/r04_mfma_ceiling.json",
+            "what": "register-only MFMA loop on post-ReLU randn activations x N(0, 0.05) weights, 2 waves per SIMD"}
+
+
 def conv_source_hash():
     import hashlib
     h = hashlib.sha256()
@@ -495,6 +510,31 @@ def main():
         probe.enabled = False
         probe.breakdown, probe.records = probe.records, timed_records
 
+    # host side of a step (never part of `value`): C-ABI crossings per step and the time the host needs to enqueue one step when the GPU is
+    # idle at its start (synchronise, then time until step() returns) -- the step is host-bound once this exceeds the GPU time
+    host = None
+    if rank == 0:
+        from nerf_rpn_amd import lib as _lib, ops as _opsh
+        cnt = [0]
+        orig_call = _opsh.call
+
+        def counting(name, *a):
+            cnt[0] += 1
+            return orig_call(name, *a)
+        _opsh.call = counting
+        enq = []
+        for _ in range(6):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            step()
+            enq.append(time.perf_counter() - th)
+        torch.cuda.synchronize()
+        _opsh.call = orig_call
+        enq.sort()
+        host = {"c_abi_calls_per_step": round(cnt[0] / 6, 1), "enqueue_ms_per_step": round(1e3 * enq[len(enq) // 2], 3),
+                "note": "median of 6 steps, each started on an idle GPU: time until step() has enqueued forward + backward + optimiser"}
+    cone = getattr(getattr(model, "rpn", None), "last_cone", None)
+
     extras = {}
     if not args.no_extras and args.model == "vgg_rpn" and spg == 1:
         # (a) two scenes per GPU, the reference's train.sh setting (batch_size 2 per rank): same trainer, batch of two grids
@@ -539,10 +579,25 @@ def main():
         if roof is not None:
             conv_ms = sum(v[1] for _, v in rows) / (BREAKDOWN_STEPS if probe.breakdown else args.steps)
             roof["timed_heavy_launches"]["ms_per_step"] = round(conv_ms, 3)
+            ceil = measured_ceiling()
+            if ceil is not None:
+                roof["measured_ceiling"] = ceil
+                roof["frac_of_measured_ceiling"] = round(roof["achieved"] / ceil["tflops"], 4)
             if args.model == "vgg_rpn":
-                step_tf = spg * STEP_GFLOP / (1e3 * elapsed / args.steps)
-                roof["step"] = {"gflop": spg * STEP_GFLOP, "tflops": round(step_tf, 1), "mfma_frac": round(step_tf / MFMA_PEAK_TFLOPS[args.dtype], 4),
-                                "note": "whole training step (fwd + dgrad + wgrad + everything else) against the dense MFMA peak"}
+                # FLOPs of the step: the reference's dense algorithm and what this engine executes -- in training the RPN head
+                # runs on the sampled-anchor cones only (ops.ConeHeadFn), so its convolutions cost rows x 2 * 256 * 256 * 27 instead of voxels x ...
+                executed = spg * STEP_GFLOP
+                if cone is not None:
+                    r, V = cone["rows"], cone["total_voxels"]
+                    per_row = 2.0 * 256 * 256 * 27 / 1e9
+                    dense_head = 4 * 3 * V * per_row
+                    done = sum((2 * r[3 - i] + (r[4 - i] if i > 0 else V)) * per_row for i in range(4)) if len(r) == 4 else dense_head
+                    executed = spg * STEP_GFLOP - dense_head + done
+                step_tf = executed / (1e3 * elapsed / args.steps)
+                roof["step"] = {"gflop": round(executed, 1), "gflop_dense_algorithm": spg * STEP_GFLOP, "tflops": round(step_tf, 1),
+                                "mfma_frac": round(step_tf / MFMA_PEAK_TFLOPS[args.dtype], 4),
+                                "note": "whole training step (fwd + dgrad + wgrad + everything else), EXECUTED FLOPs against the dense MFMA peak; "
+                                        "gflop_dense_algorithm = the same step with the head evaluated on every voxel, as the reference does"}
                 roof["forward_vgg19_fpn"] = forward_only(model, x, args.dtype)
                 roof["hbm_stages"] = hbm_stages(dtype, dev)
         out = {
@@ -558,6 +613,10 @@ def main():
             **({"gradient_exchange": exch} if exch else {}),
             "weight_packs_per_step": packs_per_step, "wgrad_side_stream": side_stream, **({"tuning_knobs": knobs} if knobs else {}),
             "final_loss": round(final_loss, 5),
+            **({"host": host} if host else {}),
+            **({"rpn_head_cone": {**cone, "note": "training: the RPN head is evaluated on the receptive-field cones of the sampled anchors only "
+                                                  "(rows = |S_0| .. |S_3| of the last step, of total_voxels over the four levels); NRPN_CONE=0 "
+                                                  "runs the dense head"}} if cone else {}),
             "roofline": roof,
             **extras,
         }

@@ -327,29 +327,11 @@ int nrpn_conv3d_fwd_stats(const void *x, const void *wp, const float *bias, void
 int nrpn_bn_stats_finalize(const float *partials, int nparts, int64_t rows, int c, float *mean, float *var, float *running_mean,
                            float *running_var, float momentum, nrpn_stream_t stream);
 int nrpn_conv3d_wgrad_plan(int n, int gx, int gy, int gz, int cin, int cout, int wrows, int ksize, int dtype);
-/* State: the library keeps NO per-call or per-stream state -- every buffer, workspace and stream comes from the caller.  What is process-wide:
- * (a) the nrpn_set_* switches below: TOOLS-ONLY process defaults for A/B measurements (atomics, read once per call; the product path never
- * calls them -- a caller that needs a non-default plan passes nrpn_conv_opts to the *_ex entry points instead); (b) a (kernel, device) cache of granted dynamic-LDS limits (mutex-protected, idempotent);
- * (c) the thread-local message behind nrpn_last_error(). */
-/* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
-int nrpn_set_conv_kstep_bytes(int kb);
-/* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */
-int nrpn_set_conv_lds_dma(int on);
-/* tuning knob: tile of the bf16 k1/k3 LDS-DMA kernel -- 0 = per shape, 128 = 128x128 (two workgroups per CU), 256 = wave-specialised
- * 256x128 (4 MFMA + 4 LDS-DMA waves), 512 = 256x256 with 8 waves (default for Cout >= 256 when it yields >= 200 workgroups),
- * 1024 = 256x256 with 4 waves (128x128 per wave) */
-int nrpn_set_conv_tile_m(int bm);
-/* tools-only default: 1 (default) = the halo form (NRPN_TILE_HALO) is chosen automatically where it applies (bf16 3x3x3, Cout >= 256, grids its
- * 4x8x8 blocks cover with <= 12 % waste and >= 200 workgroups), 0 = only on request */
-int nrpn_set_conv_halo_auto(int on);
-/* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
-int nrpn_set_conv_stagger(int on);
-/* tuning knob: 1 (default) = mid-size grids (16..199 tiles of 256x256) run the 256x256 kernel on K slices; 0 = 128-row kernel */
-int nrpn_set_conv_big_split(int on);
-/* tuning knob: 1 (default) = 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256; 0 = always the 128x128 kernel */
-int nrpn_set_wgrad_big_tile(int on);
-/* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
-int nrpn_set_wgrad_transpose_read(int on);
+/* State: the library keeps NO per-call or per-stream state -- every buffer, workspace and stream comes from the caller, and a caller that needs
+ * a non-default kernel plan passes nrpn_conv_opts to the *_ex entry points.  What is process-wide: (a) a (kernel, device) cache of granted
+ * dynamic-LDS limits (mutex-protected, idempotent); (b) the thread-local message behind nrpn_last_error(); (c) the measurement switches of
+ * include/nerfrpn_tools.h (process defaults for A/B timing runs: tools and tests only -- they are NOT part of this boundary and the product
+ * path never calls them). */
 /* Stem: Conv3d(4 -> Cout, k7, pad 3, stride 1|2) on [N,X,Y,Z,4] (feature_extractor.py:336,341) as an im2col GEMM
  * whose A operand is gathered tap by tap.  Packed stem weights: [Cout][Kpad], k = tap*4 + c, Kpad = nrpn_stem_kpad(dtype).
  * Output grid: (X - 1)/stride + 1 per axis. */
@@ -464,9 +446,8 @@ int nrpn_patch_merge(const void *src, void *dst, int n, int gx, int gy, int gz, 
  * through padded tokens; may be NULL).  Every (window, head) unit writes its partial bias-table gradient to `workspace`
  * (nrpn_window_attn_bwd_workspace_bytes) and a second kernel sums them: no same-address atomics, deterministic. */
 /* bf16 tensors run on MFMA kernels that compute the relative-position index as code(i) - code(j) + 171 (the reference's
- * define_relative_position_index for a 4x4x4 window) instead of reading rel_index; nrpn_set_window_attn_mfma(0) selects the
- * VALU kernels (always used for fp32). */
-int nrpn_set_window_attn_mfma(int on);
+ * define_relative_position_index for a 4x4x4 window) instead of reading rel_index (fp32 always runs the VALU kernels; tools can force them
+ * for bf16 through nerfrpn_tools.h). */
 int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, void *out,
                          int n, int gx, int gy, int gz, int c, int heads, int shift, int dtype, nrpn_stream_t stream);
 size_t nrpn_window_attn_bwd_workspace_bytes(int n, int gx, int gy, int gz, int heads);

@@ -1,0 +1,39 @@
+/* Tools-only switches of libnerfrpn_hip.so -- NOT part of the drop-in boundary (include/nerfrpn.h).
+ *
+ * Process-wide defaults for A/B measurements (tools/, a few kernel-variant tests): atomics, read once per call.  The product path never
+ * calls them; a caller that needs a non-default plan passes nrpn_conv_opts to the *_ex entry points of nerfrpn.h, which override these
+ * defaults per call.  Kept out of the public header so that "no global state" is what the boundary offers. */
+#ifndef NERFRPN_TOOLS_H
+#define NERFRPN_TOOLS_H
+#include "nerfrpn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tuning knob: K-step of the k1/k3 implicit-GEMM kernels in bytes per tile row (64 or 128, default 128) */
+int nrpn_set_conv_kstep_bytes(int kb);
+/* tuning knob: 1 (default) = operands go global -> LDS by LDS-DMA (buffer_load ... lds), 0 = register-staged */
+int nrpn_set_conv_lds_dma(int on);
+/* tuning knob: tile of the bf16 k1/k3 LDS-DMA kernel -- 0 = per shape, 128 = 128x128 (two workgroups per CU), 256 = wave-specialised
+ * 256x128 (4 MFMA + 4 LDS-DMA waves), 512 = 256x256 with 8 waves (default for Cout >= 256 when it yields >= 200 workgroups),
+ * 1024 = 256x256 with 4 waves (128x128 per wave) */
+int nrpn_set_conv_tile_m(int bm);
+/* tools-only default: 1 (default) = the halo form (NRPN_TILE_HALO) is chosen automatically where it applies (bf16 3x3x3, Cout >= 256, grids its
+ * 4x8x8 blocks cover with <= 12 % waste and >= 200 workgroups), 0 = only on request */
+int nrpn_set_conv_halo_auto(int on);
+/* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
+int nrpn_set_conv_stagger(int on);
+/* tuning knob: 1 (default) = mid-size grids (16..199 tiles of 256x256) run the 256x256 kernel on K slices; 0 = 128-row kernel */
+int nrpn_set_conv_big_split(int on);
+/* tuning knob: 1 (default) = 256x256 wgrad tiles for bf16 layers with Cout, Cin >= 256; 0 = always the 128x128 kernel */
+int nrpn_set_wgrad_big_tile(int on);
+/* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
+int nrpn_set_wgrad_transpose_read(int on);
+/* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
+int nrpn_set_window_attn_mfma(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

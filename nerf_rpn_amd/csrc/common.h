@@ -8,6 +8,7 @@
 #include <cstdio>
 
 #include "../../include/nerfrpn.h"
+#include "../../include/nerfrpn_tools.h"
 
 int nrpn_fail(int code, const char *fmt, ...);
 

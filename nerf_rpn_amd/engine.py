@@ -88,6 +88,11 @@ class FlatTrainer:
         # the exchange machinery (buckets, launch stream, collectives) runs whenever there is more than one rank; NRPN_FORCE_EXCHANGE=1
         # keeps it on for a one-rank process group, so that a single-GPU box exercises the real RCCL calls (tests / bench smoke)
         self.exchanging = self.world > 1 or (os.environ.get("NRPN_FORCE_EXCHANGE") == "1" and dist.is_available() and dist.is_initialized())
+        if self.exchange != "allreduce" and 64 % self.world != 0:
+            # bucket boundaries are multiples of 64 floats; the chunked modes hand every rank 1/world of a bucket (fail here with a
+            # clear message, not with a bare assertion in the middle of a collective sequence)
+            raise ValueError(f"exchange={self.exchange!r} splits every bucket into world-size chunks and needs a world size that divides 64 "
+                             f"(got {self.world}); use exchange='allreduce' for this node shape")
         # Every slot starts on a 64-float (256-byte) boundary (16-byte vector kernels on single slots); the zero padding is inert in
         # AdamW (p = g = m = v = 0 stays 0) and in the norm.
         # Conv / linear weights that feed a single-weight GEMM are stored in the FORWARD GEMM LAYOUT [taps][Cout][Cin] ("packable",

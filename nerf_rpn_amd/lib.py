@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRPN_LIBRARY: load another build of the same ABI (A/B timing of two kernel versions on one GPU box); default = the in-tree library
 SO_PATH = os.environ.get("NRPN_LIBRARY") or os.path.join(_HERE, "libnerfrpn_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "nerfrpn.h")
+TOOLS_HEADER = os.path.join(os.path.dirname(_HERE), "include", "nerfrpn_tools.h")     # measurement switches (nrpn_set_*): not the boundary
 
 F32, BF16 = 0, 1
 CONV_BIAS, CONV_RELU, CONV_OUT_F32 = 1, 2, 4
@@ -47,9 +48,9 @@ def build(force=False):
     return SO_PATH
 
 
-def declared_symbols():
-    """Every ``nrpn_*`` function declared in include/nerfrpn.h (used by the ABI test)."""
-    text = open(HEADER).read()
+def declared_symbols(tools=True):
+    """Every ``nrpn_*`` function declared in include/nerfrpn.h (+ include/nerfrpn_tools.h unless ``tools=False``); used by the ABI test."""
+    text = open(HEADER).read() + (open(TOOLS_HEADER).read() if tools else "")
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nrpn_[a-z0-9_]+)\s*\(", text)))
 
@@ -70,8 +71,8 @@ def _ctype(decl):
 
 
 def _prototypes():
-    """Parse include/nerfrpn.h into {name: (restype, [argtypes])} so ctypes converts and checks every argument."""
-    text = open(HEADER).read()
+    """Parse include/nerfrpn.h (+ the tools header) into {name: (restype, [argtypes])} so ctypes converts and checks every argument."""
+    text = open(HEADER).read() + open(TOOLS_HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
     for ret, name, args in re.findall(r"\b(int|size_t|int64_t|const char \*)\s*(nrpn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):

@@ -107,7 +107,7 @@ class ROIPool(nn.Module):
     feature voxel at each level; RoI rows are (level index, box)."""
 
     def __init__(self, output_size=(1, 1, 1), spatial_scale=(1, 1, 1, 1), enlarge_scale=0.2, is_rotated_bbox=False,
-                 feature_extracting_type="pooling", max_res=200, remap=False, use_cuda=True, reference_op_quirks=None):
+                 feature_extracting_type="pooling", max_res=200, remap=False, use_cuda=False, reference_op_quirks=None, aabb_use_kernel=False):
         super().__init__()
         self.output_size = [int(v) for v in output_size]
         self.spatial_scale = list(spatial_scale)
@@ -122,7 +122,12 @@ class ROIPool(nn.Module):
         # its torch paths -- integer crops + adaptive max-pool for AABBs (:397-438), a rotated 8-corner gather followed by max-pool or a
         # trilinear resize for OBBs (:264-395) -- restated below on device tensors, so that an RCNN trained with the reference's default
         # pooling reproduces its scores.  They are per-RoI torch loops exactly like the reference's (second-stage glue, not the hot path).
+        # Dispatch as the reference (:239-245): the op serves ROTATED RoIs when use_cuda is set; axis-aligned RoIs always take the integer
+        # crop + adaptive max-pool (normal_forward), whatever use_cuda says -- AABB RCNN weights trained with the reference expect that
+        # pooling.  ``aabb_use_kernel=True`` is an explicit opt-in (not in the reference) that sends AABBs through the RoIAlign kernel as
+        # theta = 0 boxes with a true (1 + e) enlargement.  The default of use_cuda is the reference's (False).
         self.use_cuda = bool(use_cuda)
+        self.aabb_use_kernel = bool(aabb_use_kernel)
         if reference_op_quirks is None:
             reference_op_quirks = os.environ.get("NRPN_ROIPOOL_REFERENCE_QUIRKS", "0") == "1"
         self.reference_op_quirks = bool(reference_op_quirks)
@@ -151,8 +156,10 @@ class ROIPool(nn.Module):
                 lv = mapper(geo).to(flat.dtype)
                 remapped.append(torch.cat([lv[..., None], boxes], -1).reshape(shape))
             rois = remapped
+        if not self.is_rotated_bbox and not (self.use_cuda and self.aabb_use_kernel):
+            return self._normal_forward(feature, rois)
         if not self.use_cuda:
-            return self._rotated_forward(feature, rois) if self.is_rotated_bbox else self._normal_forward(feature, rois)
+            return self._rotated_forward(feature, rois)
         out = []
         for f, r in zip(feature, rois):
             r = r.reshape(-1, r.shape[-1])

@@ -20,7 +20,11 @@ class FCOSPostProcessor(torch.nn.Module):
             raise NotImplementedError("bbox_aug_enabled is never set by run_fcos.py")
         n, L = geom.n, geom.levels
         D = 8 if self.use_obb else 6
-        k = min(int(self.pre_nms_top_n), max(geom.counts), 16384 // L)        # all levels of a scene are sorted together (<= 16384)
+        k = min(int(self.pre_nms_top_n), max(geom.counts))
+        if k * L > 16384:
+            # all levels of a scene are sorted and suppressed together in one workgroup's LDS (<= 16384 rows); the reference has no such
+            # limit, so refuse loudly instead of silently clamping (as RegionProposalNetwork.filter_proposals does)
+            raise ValueError(f"pre_nms_top_n ({self.pre_nms_top_n}) x pyramid levels ({L}) must stay <= 16384 on the HIP path")
         scores = ops.fcos_scores(geom, logits, ctr, pad_sizes, self.pre_nms_thresh)
         idx, val = ops.segmented_topk(scores, geom.segment_offsets, k)          # [(level, scene), k], score-descending
         seg_start = torch.tensor(geom.segment_offsets[:-1], dtype=torch.int32, device=idx.device)

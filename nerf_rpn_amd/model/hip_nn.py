@@ -107,7 +107,7 @@ def bn_fold(conv, bn):
     scale = gamma / sqrt(running_var + eps), shift = (conv bias - running_mean) * scale + beta.  Cached on the parameter / buffer
     versions and the raw-pointer weight epoch, so an eval forward costs no extra launches after the first."""
     ts = [conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts) + (bn.eps, ops._weight_epoch)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts) + (bn.eps, ops._weight_epoch, ops.BN_STATS_EPOCH[0])
     ent = bn.__dict__.get("_nrpn_fold")
     if ent is None or ent[0] != key:
         with torch.no_grad():

@@ -120,9 +120,11 @@ class RegionProposalNetwork(nn.Module):
         self.fix_obb_clip = False            # True = drop scores/levels together with out-of-grid OBBs (quirk B3 fixed)
         self.loss_2d_requires_grad = True    # trainers set False when reg_loss_weight_2d == 0 (value is still reported)
         self.sampler_hook = None             # tests: callable(labels_list) -> (pos_idx, neg_idx) over the flat batch
+        self.record_stages = False           # tests / diagnosis: keep references to the eval stage tensors of the last forward in last_aux
         self.use_cone = True                 # training: evaluate the head on the sampled-anchor cones only (ops.ConeHeadFn); False = dense head
         self.compute_dtype = torch.float32
         self.last_aux = {}
+        self.last_cone = None
 
     def pre_nms_top_n(self) -> int:
         return self._pre_nms_top_n["training" if self.training else "testing"]
@@ -157,8 +159,10 @@ class RegionProposalNetwork(nn.Module):
                                                     self.score_thresh, self.fix_obb_clip)
             keep = ops.nms3d_sorted(fb, fl, self.nms_thresh, cnt)
             pending.append(ops.select_kept(fb, fs, fl, keep, cnt, self.post_nms_top_n()))
-            stages.append(dict(cand_boxes=boxes, cand_valid=valid, cand_level=slot_level, nms_boxes=fb, nms_levels=fl, nms_count=cnt, nms_keep=keep))
-        self.last_aux = dict(stages=stages)       # references only (no copies): parity tests look at the decisions behind a proposal list
+            stages.append(dict(cand_boxes=boxes, cand_valid=valid, cand_level=slot_level, cand_logits=val.reshape(-1), nms_boxes=fb, nms_levels=fl, nms_count=cnt, nms_keep=keep))
+        # parity tests look at the decisions behind a proposal list (record_stages = True); production eval keeps no references to the
+        # per-scene candidate / NMS tensors beyond this call
+        self.last_aux = dict(stages=stages) if self.record_stages else {}
         for ob, os_, ol, oc in pending:
             m = int(oc.item())   # the one device->host read-back per scene
             boxes_out.append(ob[:m])
@@ -301,9 +305,11 @@ class RegionProposalNetwork(nn.Module):
         A, dw = self.head.num_anchors, self.num_delta_digits
         cone = prepared.get("cone") if (self.training and prepared is not None and objectness_output_paths is None
                                         and prepared["grids"] == grids and prepared["mesh_size"] == mesh_size) else None
+        self.last_cone = None
         if cone is not None:
             # training: only the sampled anchors' logits / deltas are read below, so the head is evaluated on their cones (zeros elsewhere)
             logits, deltas = self.head.forward_cone(feats_cl, cone)
+            self.last_cone = dict(rows=list(cone.counts), total_voxels=cone.total)       # sizes only (bench / logging)
         else:
             heads = self.head.forward_fused(feats_cl)
             if objectness_output_paths is not None:

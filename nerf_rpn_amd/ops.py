@@ -1020,13 +1020,14 @@ def conv_rows_fwd(x, wp, bias, y, plan, k, cin, cout, wrows, ksize, flags, mask=
     return y
 
 
-def conv_rows_wgrad(x, dy, weights, biases, rows_total, ksize, plan, k):
-    """Weight (+ bias) gradient of a conv from the rows of S_k only (dy is zero elsewhere); delivery as ConvFn._wgrad."""
+def conv_rows_wgrad(x, dy, weights, biases, rows_total, ksize, plan, k, sinks=None):
+    """Weight (+ bias) gradient of a conv from the rows of S_k only (dy is zero elsewhere); delivery as ConvFn._wgrad.
+    ``sinks``: (weight sinks, bias sinks) looked up by the caller on the original Parameter objects; default: on ``weights`` / ``biases``."""
     rows, nrows = plan.rows(k)
     cin = x.shape[-1]
     taps = ksize ** 3
     nw = len(weights)
-    wsinks, bsinks = [_sink(w) for w in weights], [_sink(b) for b in biases]
+    wsinks, bsinks = sinks if sinks is not None else ([_sink(w) for w in weights], [_sink(b) for b in biases])
     has_bias = biases[0] is not None
     if nrows == 0:      # nothing sampled: zero gradients (sinks are only told that this use of the parameter is done)
         out = []
@@ -1115,6 +1116,8 @@ class ConeHeadFn(torch.autograd.Function):
             off += c * A
         ctx.save_for_backward(*hs, *ops_w, wpdo, *cw, *[b for b in cb if b is not None], *ow, *[b for b in ob if b is not None])
         ctx.meta = (plan, head, A, dw, L, D, n, C, dt, rows_total, [b is not None for b in cb], [b is not None for b in ob], need_dgrad)
+        # gradient sinks are attributes of the Parameter objects: looked up here, on the objects the caller passed (as ConvFn does)
+        ctx.sinks = ([_sink(w) for w in cw], [_sink(b) for b in cb], [_sink(w) for w in ow], [_sink(b) for b in ob])
         return logits, deltas
 
     @staticmethod
@@ -1150,12 +1153,14 @@ class ConeHeadFn(torch.autograd.Function):
             off += c * A
         _wait_dgrad_operands()
 
-        def sinks_ok(ws_, bs_):
-            return all(_sink(w) is not None for w in ws_) and all(_sink(b) is not None for b in bs_ if b is not None)
+        cws, cbs, ows, obs = ctx.sinks
+
+        def sinks_ok(ws_, bs_, bt_):
+            return all(k_ is not None for k_ in ws_) and all(k_ is not None for k_, b in zip(bs_, bt_) if b is not None)
 
         # output GEMM: weight / bias gradients from the rows of S_0; input gradient on S_0 with the last layer's ReLU mask
-        g_ow = _on_wgrad_stream(dev, [hs[D], dout, plan.lists], sinks_ok(ow, ob),
-                                lambda: conv_rows_wgrad(hs[D], dout, list(ow), list(ob), rows_total, 1, plan, 0))
+        g_ow = _on_wgrad_stream(dev, [hs[D], dout, plan.lists], sinks_ok(ows, obs, ob),
+                                lambda: conv_rows_wgrad(hs[D], dout, list(ow), list(ob), rows_total, 1, plan, 0, (ows, obs)))
         dh = torch.zeros((V, C), dtype=dt, device=dev)
         conv_rows_fwd(dout, wpdo, None, dh, plan, 0, rows_total, C, C, 1, 0, mask=hs[D] if D > 0 else None)
         g_cw, g_cb = [None] * D, [None] * D
@@ -1167,8 +1172,8 @@ class ConeHeadFn(torch.autograd.Function):
         for i in range(D - 1, -1, -1):
             k = D - 1 - i
             x_i, dy_i = hs[i], dh
-            res = _on_wgrad_stream(dev, [x_i, dy_i, plan.lists], sinks_ok([cw[i]], [cb[i]]),
-                                   lambda x_i=x_i, dy_i=dy_i, i=i, k=k: conv_rows_wgrad(x_i, dy_i, [cw[i]], [cb[i]], C, 3, plan, k))
+            res = _on_wgrad_stream(dev, [x_i, dy_i, plan.lists], sinks_ok([cws[i]], [cbs[i]], [cb[i]]),
+                                   lambda x_i=x_i, dy_i=dy_i, i=i, k=k: conv_rows_wgrad(x_i, dy_i, [cw[i]], [cb[i]], C, 3, plan, k, ([cws[i]], [cbs[i]])))
             g_cw[i] = res[0]
             g_cb[i] = res[1] if len(res) > 1 else None
             if i > 0:
@@ -1261,6 +1266,9 @@ class StemFn(torch.autograd.Function):
         return None, gw, gb, None, None, None, None
 
 
+BN_STATS_EPOCH = [0]      # bumped by every training-mode BatchNorm forward (running statistics rewritten behind torch's back)
+
+
 class BatchNormFn(torch.autograd.Function):
     """BatchNorm3d (+ fused ReLU) on channels-last rows; training uses per-rank batch statistics (no SyncBN, as the reference)."""
 
@@ -1272,6 +1280,9 @@ class BatchNormFn(torch.autograd.Function):
         dev = x.device
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         if training:
+            # the statistics kernels update running_mean / running_var through raw pointers (no tensor._version bump): folded eval-mode
+            # (scale, shift) pairs cached on the buffer versions would go stale -- hip_nn.bn_fold keys on this epoch as well
+            BN_STATS_EPOCH[0] += 1
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             var = torch.empty(c, dtype=torch.float32, device=dev)
             if partials is not None:      # the producing conv left (sum, sum of squares) partials of x in its epilogue: only finish them

@@ -321,6 +321,9 @@ def gen_eval():
     cases = [("eval_aabb_s2", False, 160, [(48, 48, 48)], {}),
              ("eval_obb_s2", True, 160, [(48, 40, 32)], {}),
              ("eval_obb_s1_cfg0", True, 64, [(16, 16, 16)], {"pre": 600}),       # BASELINE config[0] at 16^3
+             # BASELINE config[0] at its stated size: one 64^3 grid with --resolution 64 (stride-1 stem, 64^3 / 32^3 / 16^3 / 8^3 maps,
+             # 3 893 760 anchors, a 3.4 M-element level-0 top-k segment)
+             ("eval_obb_64_cfg0", True, 64, [(64, 64, 64)], {}),
              ("eval_aabb_batch2", False, 160, [(48, 48, 32), (40, 32, 32)], {}),
              ("eval_resnet_obb", True, 160, [(64, 56, 48)], {"backbone": "resnet"}),
              # swin_s: token grids 20x14x12 -> 10x7x6 -> 5x4x3 -> 3x2x2: window padding on every stage, a stage whose

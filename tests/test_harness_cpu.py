@@ -126,3 +126,9 @@ def test_roipool_torch_paths_match_reference(golden):
     assert torch.equal(out, T("aabb_pooling")) and torch.equal(aabb, T("aabb_rois"))
     with pytest.raises(NameError):
         ROIPool([2, 2, 2], scales, 0.2, True, "nearest", use_cuda=False)
+    # dispatch as the reference (detector.py:239-245): axis-aligned RoIs take normal_forward whatever use_cuda says, and the
+    # constructor default is the reference's use_cuda=False; the theta = 0 kernel path for AABBs is an explicit opt-in
+    assert ROIPool([2, 2, 2], scales, 0.2, False).use_cuda is False and ROIPool([2, 2, 2], scales, 0.2, False).aabb_use_kernel is False
+    for kw in ({}, {"use_cuda": True}):
+        out = torch.stack(ROIPool([2, 2, 2], scales, 0.2, False, **kw)(feats, [r for r in aabb]))
+        assert torch.equal(out, T("aabb_pooling")), kw
