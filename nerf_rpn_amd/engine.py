@@ -170,6 +170,8 @@ class FlatTrainer:
 
     def _make_notify(self, i):
         def notify():
+            if self.g_arena.is_cuda and torch.cuda.is_current_stream_capturing():
+                return      # a backward pass being CAPTURED (graphs.GraphedBackbone) delivers nothing: no counts, no collective from inside a capture
             self.seen[i] += 1
             if self.exchanging and self.g_arena.is_cuda:
                 h = ops._s()                 # raw handle of the stream this gradient was produced on (~0.3 us); the Stream object is

@@ -1,0 +1,110 @@
+"""hipGraph capture of the backbone + FPN ("trunk") of a training step.
+
+A ResNet-50 / Swin-S training step is 500-800 C-ABI crossings and ~70-200 autograd nodes of ~20 us kernels: the host needs 15-24 ms to
+enqueue what the GPU runs in 11-17 ms (bench.py ``host``).  The trunk has static shapes and no host decisions -- target assignment and the
+sampler's read-back happen before it, the sampled-cone head and the loss (whose launch sizes depend on the draw) after it -- so its forward and
+its backward are captured once per input shape as two HIP graphs and replayed with one launch each:
+
+    step:   targets + sampler (eager, own stream)  ->  [graph: backbone + FPN forward]  ->  cone head + loss (eager)
+            ->  cone head backward (eager)  ->  [graph: FPN + backbone backward, weight gradients on the side stream inside the graph]
+            ->  clip + AdamW (eager)
+
+Capture does not execute anything, so it happens in the middle of ordinary training: the first ``warmup`` calls run eagerly (lazy one-time
+work: dynamic-LDS limits, workspaces, tap masks), the next call captures both graphs (the backward one through ``torch.autograd.backward``
+on the captured outputs, as ``torch.cuda.make_graphed_callables`` does) and then replays the forward one for real.  Everything a replay
+touches lives at fixed addresses: the static input copy, the graph's private memory pool, the trainer's arenas (parameters, gradients, bf16
+shadow, dgrad operands) and the BatchNorm buffers.  Once-per-update refreshes that the trunk performs itself (stem / non-arena weight packs)
+are forced into the graph by bumping the weight epoch before capture; those the trainer performs eagerly (AdamW's bf16 shadow, the dgrad
+operand transposition on the side stream) stay eager and are ordered before the replay by ordinary stream semantics.
+
+Results are bit-identical to the eager path (tests/test_gpu_graph.py).  Opt-in: ``model.use_graph = True`` or NRPN_GRAPH=1."""
+import os
+
+import torch
+
+from . import ops
+
+ENABLED = [os.environ.get("NRPN_GRAPH", "0") == "1"]
+
+
+class _Captured:
+    __slots__ = ("static_x", "outs", "gouts", "fwd", "bwd", "pool", "dummy")
+
+
+class _GraphedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cap, dummy):
+        cap.fwd.replay()
+        ctx.cap = cap
+        return tuple(o.detach() for o in cap.outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        cap = ctx.cap
+        for sg, g in zip(cap.gouts, gs):
+            if g is None:
+                sg.zero_()
+            else:
+                sg.copy_(g)
+        ops._wait_dgrad_operands()       # the side stream's operand refresh of the last optimiser step (an eager event) precedes the replay
+        cap.bwd.replay()
+        return None, None
+
+
+class GraphedBackbone:
+    """``backbone(x)`` through captured forward / backward graphs when training with gradients on a CUDA tensor; eager otherwise."""
+
+    def __init__(self, backbone, warmup=2):
+        self.backbone = backbone
+        self.warmup = int(warmup)
+        self.captured = {}
+        self.calls = {}
+
+    def __call__(self, x):
+        bb = self.backbone
+        if not (x.is_cuda and bb.training and torch.is_grad_enabled()) or torch.cuda.is_current_stream_capturing():
+            return bb(x)
+        if not self._sinks_everywhere():
+            return bb(x)
+        key = (tuple(x.shape), x.dtype, bb.compute_dtype)
+        n = self.calls.get(key, 0)
+        self.calls[key] = n + 1
+        if n < self.warmup:
+            return bb(x)
+        cap = self.captured.get(key)
+        if cap is None:
+            cap = self.captured[key] = self._capture(x)
+        if cap.static_x.data_ptr() != x.data_ptr():
+            cap.static_x.copy_(x)
+        return _GraphedFn.apply(cap, cap.dummy)
+
+    def _sinks_everywhere(self):
+        """A replayed backward delivers gradients only through the fixed addresses the capture saw: every trainable parameter of the trunk
+        must accumulate into a trainer's flat arena (ops.GradSink).  Without a FlatTrainer the trunk stays eager."""
+        ok = getattr(self, "_sinks_ok", None)
+        if ok is None:
+            ok = self._sinks_ok = all(getattr(p, "_nrpn_sink", None) is not None for p in self.backbone.parameters() if p.requires_grad)
+        return ok
+
+    def _capture(self, x):
+        bb = self.backbone
+        cap = _Captured()
+        cap.static_x = x.detach().clone()
+        cap.dummy = torch.zeros(1, device=x.device, requires_grad=True)
+        ops.wgrad_stream_join()
+        ops.weights_changed()            # once-per-update packs inside the trunk (stem, non-arena weights) become part of the graph
+        torch.cuda.synchronize()
+        cap.pool = torch.cuda.graph_pool_handle()
+        cap.fwd, cap.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap.fwd, pool=cap.pool):
+            with torch.enable_grad():
+                outs = tuple(bb(cap.static_x))
+        cap.outs = outs
+        cap.gouts = tuple(torch.zeros_like(o) for o in outs)
+        live = [o for o in outs if o.requires_grad]
+        if len(live) != len(outs):
+            raise RuntimeError("GraphedBackbone: every trunk output must require a gradient (is the backbone frozen?)")
+        with torch.cuda.graph(cap.bwd, pool=cap.pool):
+            torch.autograd.backward(outs, cap.gouts)
+        torch.cuda.synchronize()
+        return cap

@@ -44,6 +44,9 @@ class NeRFRegionProposalNetwork(nn.Module):
             dict(training=rpn_post_nms_top_n_train, testing=rpn_post_nms_top_n_test), rpn_nms_thresh,
             score_thresh=rpn_score_thresh, iou_batch_size=iou_batch_size, rotated_bbox=rotated_bbox, reg_loss_type=reg_loss_type)
         self._prep_stream = None          # side stream of the target preparation when the ground truth arrives as host tensors (forward)
+        from .. import graphs as _graphs
+        self.use_graph = _graphs.ENABLED[0]     # training: backbone + FPN forward / backward as two captured HIP graphs (needs an engine.FlatTrainer)
+        self._trunk = None
         self.set_compute_dtype(kwargs.get("compute_dtype", torch.float32))
 
     def set_compute_dtype(self, dtype):
@@ -126,7 +129,13 @@ class NeRFRegionProposalNetwork(nn.Module):
                 prepared = self.rpn.prepare_targets(size, grids, targets, original_mesh_sizes, dev, flags)
                 if prepared["flags"] is None or any(prepared["flags"]) or len(prepared["flags"]) != len(targets):
                     self.check_bbox_degeneration(targets)         # raises with the offending box (or covers what the flags did not)
-        features = list(self.backbone(mesh_tensors))
+        if self.use_graph and self.training and mesh_tensors.is_cuda and torch.is_grad_enabled():
+            if self._trunk is None:
+                from ..graphs import GraphedBackbone
+                self._trunk = GraphedBackbone(self.backbone)
+            features = list(self._trunk(mesh_tensors))       # backbone + FPN as captured HIP graphs (graphs.py); eager until captured
+        else:
+            features = list(self.backbone(mesh_tensors))
         proposals, level_index, proposal_losses, scores = self.rpn(mesh_tensors, features, original_mesh_sizes, targets,
                                                                    objectness_output_paths, prepared)
         return [features, proposals, level_index], proposal_losses, scores

@@ -625,6 +625,8 @@ _DGRAD_READY = {"event": None, "waited": set()}
 def _wait_dgrad_operands():
     """First dgrad of a stream after an optimiser step: wait for the operand refresh enqueued on the side stream."""
     ev = _DGRAD_READY["event"]
+    if ev is not None and torch.cuda.is_current_stream_capturing():
+        return      # graph capture (graphs.GraphedBackbone): the replay is ordered behind the refresh by an eager wait on the launching stream
     if ev is not None:
         sid = _s()
         if sid not in _DGRAD_READY["waited"]:

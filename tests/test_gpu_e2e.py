@@ -84,18 +84,28 @@ def _explain_unmatched(name, scene, rp, rs, rl, gp, gs, gl, bad, aux, mesh_size,
         st = aux["stages"][scene]
         cb, cv, cl = st["cand_boxes"].cpu(), st["cand_valid"].cpu().bool(), st["cand_level"].cpu().long()
     if rotated and has_b3:
+        # The reference clips the candidates of ALL levels as one concatenated list (rpn.py:347-351): a dropped box shifts every later box --
+        # of its own and of every coarser level -- one slot against the score / level lists.  So a level is exposed to the quirk when it or a
+        # finer level lost a candidate, and the number of slots a row may have moved is bounded by the candidates up to and including its
+        # level whose clip decision could fall either way (centre within the box tolerance of a face) + the adjacent ties of its own level.
         c = cb[:, :3]
         outside = ((c < 0) | (c > size)).any(dim=1) & cv
-        b3_levels = set(cl[outside].tolist())
         ctol = 2e-3 + 1e-4 * c.abs()
         at_face = ((c.abs() <= ctol) | ((c - size).abs() <= ctol)).any(dim=1) & cv         # the clip decision of these may fall either way
         sc_all = torch.sigmoid(st["cand_logits"].float().cpu())
-        for lv in b3_levels:
-            sel = (cl == lv) & cv
-            sc = sc_all[sel]                                # the level's top-k score list, in top-k order (what the i-th surviving box is paired with)
-            ties = int(((sc[:-1] - sc[1:]).abs() <= 2e-6).sum()) if sc.numel() > 1 else 0
-            slot_budget[lv] = int(at_face[cl == lv].sum()) + ties
-            level_scores[lv] = sc
+        sc_list, lv_list = sc_all[cv], cl[cv]              # the concatenated candidate list, in the order the reference holds it (level-major, top-k order)
+        levels_present = sorted(set(cl[cv].tolist()))
+        first = min(cl[outside].tolist()) if outside.any() else None
+        for lv in levels_present:
+            if first is None or lv < first:
+                continue
+            b3_levels.add(lv)
+            pos = torch.where(lv_list == lv)[0]
+            seg = sc_list[pos]
+            ties = int(((seg[:-1] - seg[1:]).abs() <= 2e-6).sum()) if seg.numel() > 1 else 0
+            slot_budget[lv] = int(at_face[cl <= lv].sum()) + ties
+            lo, hi = max(0, int(pos[0]) - slot_budget[lv] - 1), min(sc_list.numel(), int(pos[-1]) + slot_budget[lv] + 2)
+            level_scores[lv] = sc_list[lo:hi]              # the level's stretch of the list, widened by the slots a row may have moved
     tol = 2e-3 + 1e-4 * rp.abs()
     out, flipped = [], {}
     iou_fn = OB.iou_matrix if rotated else OB.aabb_iou_matrix

@@ -1,0 +1,47 @@
+"""graphs.GraphedBackbone: backbone + FPN forward / backward of a training step as captured HIP graphs.  The replayed step must be the eager
+step bit for bit: same losses, same gradient arena, same weights after the optimiser, over several steps that include the two eager warm-up
+steps, the capturing step and replays -- with scenes that change from step to step (the static input copy) and with the weight-gradient
+side stream inside the captured backward."""
+import pytest
+import torch
+
+from test_gpu_e2e import T, build, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, golden, use_graph, backbone, dtype, steps=6):
+    from nerf_rpn_amd.engine import FlatTrainer
+    g = golden("train_obb")
+    shape = tuple(int(v) for v in g["shapes"][0])
+    gts = [T(g["gt0"], dev)]
+    pos, neg = T(g["pos_idx"], dev), T(g["neg_idx"], dev)
+    m = build(True, 160, dev, backbone=backbone, sd=0.0).train()
+    m.set_compute_dtype(dtype)
+    m.use_graph = use_graph
+    m.rpn.sampler_hook = lambda labels: (pos, neg)
+    tr = FlatTrainer(m, lr=3e-4, weight_decay=0.01, clip_grad_norm=0.1)
+    losses, arenas = [], []
+    for it in range(steps):
+        x = scene(shape, 200 + (it % 3)).to(dev)          # three different grids in turn: the captured input buffer is refilled every step
+        _, l, _ = m([x], gts)
+        (l["loss_objectness"] + 5.0 * l["loss_rpn_box_reg"]).backward()
+        torch.cuda.synchronize()
+        arenas.append(tr.g_arena.clone())
+        tr.step()
+        losses.append((l["loss_objectness"].item(), l["loss_rpn_box_reg"].item()))
+    captured = len(m._trunk.captured) if m._trunk is not None else 0
+    return losses, arenas, tr.flat_params().clone(), {k: v.clone() for k, v in m.backbone.state_dict().items() if "running" in k or "tracked" in k}, captured
+
+
+@pytest.mark.parametrize("backbone,dtype", [("vgg", torch.float32), ("vgg", torch.bfloat16), ("resnet", torch.bfloat16)])
+def test_graphed_trunk_is_bit_identical_to_the_eager_step(backbone, dtype, golden, dev):
+    eager = _run(dev, golden, False, backbone, dtype)
+    graph = _run(dev, golden, True, backbone, dtype)
+    assert eager[4] == 0 and graph[4] == 1                    # one capture (one input shape), after the two eager warm-up calls
+    assert eager[0] == graph[0], (eager[0], graph[0])
+    for i, (a, b) in enumerate(zip(eager[1], graph[1])):
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+    assert torch.equal(eager[2], graph[2])
+    for k, v in eager[3].items():
+        assert torch.equal(v, graph[3][k]), k

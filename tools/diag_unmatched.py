@@ -48,6 +48,17 @@ for name in sys.argv[1:]:
         print(f'   row {b} lvl {lvl} score {rs[b]:.7f} box {[round(v, 4) for v in rp[b].tolist()]}')
         if j.numel():
             print(f'      same box at HIP row {int(j[0])} with score {gs[j[0]]:.7f} (diff {gs[j[0]] - rs[b]:+.2e})')
+            if 'cand_logits' in st:      # slot analysis of the B3 mechanism (tests/test_gpu_e2e.py::_explain_unmatched)
+                sel = (cl == lvl) & cv
+                sc = torch.sigmoid(st['cand_logits'].float().cpu())[sel]
+                c = cb[:, :3]
+                ctol = 2e-3 + 1e-4 * c.abs()
+                at_face = (((c.abs() <= ctol) | ((c - size).abs() <= ctol)).any(dim=1) & cv)[cl <= lvl].sum()      # cumulative: the clip shifts ALL later candidates
+                ties = int(((sc[:-1] - sc[1:]).abs() <= 2e-6).sum())
+                dr, dh = (sc - rs[b]).abs(), (sc - gs[j[0]]).abs()
+                print(f'      level list: {sc.numel()} candidates, {int(at_face)} at a face, {ties} adjacent ties; reference score sits at slot {int(dr.argmin())} '
+                      f'(|d| {dr.min().item():.1e}), HIP score at slot {int(dh.argmin())} (|d| {dh.min().item():.1e}); outside the grid: '
+                      f'{int((((c < 0) | (c > size)).any(dim=1) & cv)[cl == lvl].sum())}')
         else:
             top = torch.topk(iou, min(3, iou.numel()))
             print(f'      no HIP box within tolerance; best IoUs with HIP proposals of the level: {[round(v, 5) for v in top.values.tolist()]}; '
