@@ -379,6 +379,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 step, eval protocol, 2 scenes per GPU)")
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="per-rank batch of the TIMED region (1 = the BASELINE metric; 2 = the reference's train.sh setting)")
     ap.add_argument("--exchange", default=None, choices=["allreduce", "rs_ag", "a2a_bf16"], help="gradient exchange of the trainer (N > 1)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="backbone + FPN forward / backward as captured HIP graphs (nerf_rpn_amd/graphs.py): auto = for the ResNet-50 / Swin-S "
+                         "backbones, whose eager step is bound by the host's enqueue rate; the VGG19 step (the BASELINE metric) is GPU-bound and stays eager")
     ap.add_argument("--model", default="vgg_rpn", choices=["vgg_rpn", "resnet_rpn", "swin_rpn", "swin_fcos", "vgg_fcos"],
                     help="vgg_rpn = the BASELINE.json metric (default); the others are secondary workloads for profiling")
     args = ap.parse_args()
@@ -428,6 +431,10 @@ def main():
     backbone, head = args.model.split("_")
     fcos = head == "fcos"
     model = build_fcos(dtype, dev, "swin0" if backbone == "swin" else backbone) if fcos else build_model(dtype, dev, backbone)
+    use_graph = args.graph == "on" or (args.graph == "auto" and backbone in ("resnet", "swin"))
+    if os.environ.get("NRPN_GRAPH") in ("0", "1"):
+        use_graph = os.environ["NRPN_GRAPH"] == "1"
+    model.use_graph = use_graph
     trainer = FlatTrainer(model, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, total_steps=args.steps + args.warmup + 1 + 64,
                           exchange=args.exchange)
     spg = max(1, args.scenes_per_gpu)
@@ -611,7 +618,7 @@ def main():
                        "backend": (dist.get_backend() if dist_on else "single process")},
             "per_rank_ms_per_step": per_rank_ms,
             **({"gradient_exchange": exch} if exch else {}),
-            "weight_packs_per_step": packs_per_step, "wgrad_side_stream": side_stream, **({"tuning_knobs": knobs} if knobs else {}),
+            "weight_packs_per_step": packs_per_step, "wgrad_side_stream": side_stream, "trunk_hip_graph": bool(use_graph), **({"tuning_knobs": knobs} if knobs else {}),
             "final_loss": round(final_loss, 5),
             **({"host": host} if host else {}),
             **({"rpn_head_cone": {**cone, "note": "training: the RPN head is evaluated on the receptive-field cones of the sampled anchors only "

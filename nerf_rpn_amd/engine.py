@@ -26,6 +26,7 @@ import math
 import torch
 import torch.distributed as dist
 
+from . import graphs as _graphs
 from . import ops
 
 
@@ -170,7 +171,7 @@ class FlatTrainer:
 
     def _make_notify(self, i):
         def notify():
-            if self.g_arena.is_cuda and torch.cuda.is_current_stream_capturing():
+            if _graphs.CAPTURING[0]:
                 return      # a backward pass being CAPTURED (graphs.GraphedBackbone) delivers nothing: no counts, no collective from inside a capture
             self.seen[i] += 1
             if self.exchanging and self.g_arena.is_cuda:
@@ -194,7 +195,7 @@ class FlatTrainer:
     def _make_hook(self, i):
         notify = self._make_notify(i)
 
-        def hook(_):
+        def hook(_):       # (fires for every parameter of a backward pass, also when its Function handed None back because a sink took the gradient)
             notify()
         return hook
 

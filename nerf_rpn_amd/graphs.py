@@ -25,6 +25,10 @@ import torch
 from . import ops
 
 ENABLED = [os.environ.get("NRPN_GRAPH", "0") == "1"]
+CAPTURING = [False]       # True while a trunk is being captured (nothing executes): the trainer's gradient notifications are ignored meanwhile.
+# NOTE for new trunk ops: every parameter gradient must be ADDED INTO ITS GradSink by the backward kernel sequence itself.  A gradient handed
+# back to autograd is accumulated by an AccumulateGrad node on the stream that node was created on -- outside the captured backward -- and
+# replays would silently miss it (what ops.WindowAttnFn did before round 4; tests/test_gpu_graph.py holds every backbone to bit-identity).
 
 
 class _Captured:
@@ -54,9 +58,10 @@ class _GraphedFn(torch.autograd.Function):
 class GraphedBackbone:
     """``backbone(x)`` through captured forward / backward graphs when training with gradients on a CUDA tensor; eager otherwise."""
 
-    def __init__(self, backbone, warmup=2):
+    def __init__(self, backbone, warmup=2, max_shapes=4):
         self.backbone = backbone
         self.warmup = int(warmup)
+        self.max_shapes = int(max_shapes)     # every captured input shape pins its own activation pool: scenes of further shapes run eagerly
         self.captured = {}
         self.calls = {}
 
@@ -73,6 +78,8 @@ class GraphedBackbone:
             return bb(x)
         cap = self.captured.get(key)
         if cap is None:
+            if len(self.captured) >= self.max_shapes:
+                return bb(x)
             cap = self.captured[key] = self._capture(x)
         if cap.static_x.data_ptr() != x.data_ptr():
             cap.static_x.copy_(x)
@@ -96,15 +103,19 @@ class GraphedBackbone:
         torch.cuda.synchronize()
         cap.pool = torch.cuda.graph_pool_handle()
         cap.fwd, cap.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap.fwd, pool=cap.pool):
-            with torch.enable_grad():
-                outs = tuple(bb(cap.static_x))
-        cap.outs = outs
-        cap.gouts = tuple(torch.zeros_like(o) for o in outs)
-        live = [o for o in outs if o.requires_grad]
-        if len(live) != len(outs):
-            raise RuntimeError("GraphedBackbone: every trunk output must require a gradient (is the backbone frozen?)")
-        with torch.cuda.graph(cap.bwd, pool=cap.pool):
-            torch.autograd.backward(outs, cap.gouts)
+        CAPTURING[0] = True
+        try:
+            with torch.cuda.graph(cap.fwd, pool=cap.pool):
+                with torch.enable_grad():
+                    outs = tuple(bb(cap.static_x))
+            cap.outs = outs
+            cap.gouts = tuple(torch.zeros_like(o) for o in outs)
+            live = [o for o in outs if o.requires_grad]
+            if len(live) != len(outs):
+                raise RuntimeError("GraphedBackbone: every trunk output must require a gradient (is the backbone frozen?)")
+            with torch.cuda.graph(cap.bwd, pool=cap.pool):
+                torch.autograd.backward(outs, cap.gouts)
+        finally:
+            CAPTURING[0] = False
         torch.cuda.synchronize()
         return cap

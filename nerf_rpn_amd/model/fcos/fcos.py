@@ -161,6 +161,9 @@ class FCOSOverNeRF(nn.Module):
         self.args, self.world_size = args, world_size
         self.backbone = backbone
         self.fcos_module = FCOSModule(args, backbone.out_channels, fpn_strides, world_size=world_size)
+        from ... import graphs as _graphs
+        self.use_graph = _graphs.ENABLED[0]     # training: backbone + FPN forward / backward as two captured HIP graphs (needs an engine.FlatTrainer)
+        self._trunk = None
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dtype):
@@ -194,6 +197,13 @@ class FCOSOverNeRF(nn.Module):
         meshes = list(meshes)
         if len(meshes) > 1:
             meshes = self.transform(meshes)
-        features = list(self.backbone(ops.stack_scenes(meshes)))
+        stacked = ops.stack_scenes(meshes)
+        if self.use_graph and self.training and stacked.is_cuda and torch.is_grad_enabled():
+            if self._trunk is None:
+                from ...graphs import GraphedBackbone
+                self._trunk = GraphedBackbone(self.backbone)
+            features = list(self._trunk(stacked))       # backbone + FPN as captured HIP graphs (graphs.py); eager until captured
+        else:
+            features = list(self.backbone(stacked))
         boxes, scores, losses = self.fcos_module(sizes, features, targets, objectness_output_paths)
         return boxes, losses, scores

@@ -65,7 +65,12 @@ def _p(t):
 # instead of each draining the chip on its own.  Consumers of the arena (optimiser step, bucket all-reduce) call wgrad_stream_join().
 # On by default for arena training (every gradient of the layer has a GradSink); NRPN_WGRAD_STREAM=0 or set_wgrad_stream(False) keeps
 # everything on the current stream.  Measured on the 160^3 VGG19-FPN step: 12.8 -> 12.0 ms.
-_WGRAD_SIDE = {"enabled": _os.environ.get("NRPN_WGRAD_STREAM", "1") != "0", "streams": {}, "dirty": False, "prefetch": False}
+_WGRAD_SIDE = {"enabled": _os.environ.get("NRPN_WGRAD_STREAM", "1") != "0", "streams": {}, "dirty": False, "prefetch": False, "keep": []}
+# "keep": the tensors side-stream kernels of this backward pass read (dY, X), referenced until the main stream has joined the side stream.
+# record_stream only defers the REUSE of their memory; it does not stop autograd from WRITING into them: the engine accumulates gradients
+# in place when it holds the only reference (a residual join hands the same dY to both branches -- ScaleAddFn -- and the copy waiting in the
+# other branch's input buffer is then added into on the main stream while the weight-gradient kernel still reads it: Swin, found in round 4
+# by the graph-capture bit-identity tests).  A second reference makes the engine add out of place.
 
 
 def set_wgrad_stream(enabled):
@@ -97,6 +102,7 @@ def wgrad_stream_join():
                 cur.wait_stream(st)
         if joined:
             _WGRAD_SIDE["dirty"] = _WGRAD_SIDE["prefetch"] = False
+            _WGRAD_SIDE["keep"] = []        # every later write of the main stream is ordered behind the side stream's reads now
 
 
 def _chk(*ts):
@@ -848,6 +854,7 @@ class ConvFn(torch.autograd.Function):
         side.wait_stream(main)              # dy (after the ReLU mask) is ready; also orders this wgrad behind the arena's zero fill
         x.record_stream(side)
         dy.record_stream(side)
+        _WGRAD_SIDE["keep"].append((x, dy))
         with torch.cuda.stream(side):       # every gradient goes straight into the arena here: nothing is handed back to autograd
             res = ConvFn._wgrad(ctx, x, dy, weights)
         if not _WGRAD_SIDE["dirty"]:        # first side-stream wgrad of this backward pass: join when the pass ends
@@ -931,6 +938,7 @@ def _on_wgrad_stream(device, tensors, sinks_complete, fn):
     side.wait_stream(main)
     for t in tensors:
         t.record_stream(side)
+    _WGRAD_SIDE["keep"].append(tuple(tensors))
     with torch.cuda.stream(side):
         res = fn()
     if not _WGRAD_SIDE["dirty"]:
@@ -1558,6 +1566,7 @@ class WindowAttnFn(torch.autograd.Function):
         call("window_attn_fwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(out), n, gx, gy, gz, c, heads, int(shift), _dt(qkv), _s())
         ctx.save_for_backward(qkv, qb, t32, rel_index)
         ctx.meta = (heads, int(shift), any(g % 4 for g in (gx, gy, gz)))
+        ctx.sinks = (_sink(qkv_bias), _sink(table))
         return out
 
     @staticmethod
@@ -1573,6 +1582,19 @@ class WindowAttnFn(torch.autograd.Function):
         ws = torch.empty(query("window_attn_bwd_workspace_bytes", n, gx, gy, gz, heads), dtype=torch.uint8, device=qkv.device)
         call("window_attn_bwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(dout), _p(dqkv), _p(dtable), _p(dpad), n, gx, gy, gz, c, heads,
              shift, _dt(qkv), _p(ws), _s())
+        bsink, tsink = ctx.sinks
+        if tsink is not None and (dpad is None or bsink is not None):
+            # arena training: both parameter gradients are added to their slots here instead of travelling through autograd's AccumulateGrad
+            # (which runs on the stream it was created on and would fall out of a captured backward, graphs.py).  The qkv bias also receives
+            # the bias gradient of the qkv Linear on the weight-gradient stream: same stream, enqueue order = a fixed summation order.
+            def deliver():
+                tsink.slot.add_(dtable.view_as(tsink.slot))
+                tsink.notify()
+                if dpad is not None:
+                    bsink.slot.add_(dpad.view_as(bsink.slot))
+                    bsink.notify()
+            _on_wgrad_stream(qkv.device, [dtable] + ([dpad] if dpad is not None else []), True, deliver)
+            return dqkv, None, None, None, None, None
         return dqkv, dpad, dtable, None, None, None
 
 

@@ -34,7 +34,8 @@ def _run(dev, golden, use_graph, backbone, dtype, steps=6):
     return losses, arenas, tr.flat_params().clone(), {k: v.clone() for k, v in m.backbone.state_dict().items() if "running" in k or "tracked" in k}, captured
 
 
-@pytest.mark.parametrize("backbone,dtype", [("vgg", torch.float32), ("vgg", torch.bfloat16), ("resnet", torch.bfloat16)])
+@pytest.mark.parametrize("backbone,dtype", [("vgg", torch.float32), ("vgg", torch.bfloat16), ("resnet", torch.bfloat16), ("swin", torch.float32),
+                                            ("swin", torch.bfloat16)])
 def test_graphed_trunk_is_bit_identical_to_the_eager_step(backbone, dtype, golden, dev):
     eager = _run(dev, golden, False, backbone, dtype)
     graph = _run(dev, golden, True, backbone, dtype)
@@ -45,3 +46,44 @@ def test_graphed_trunk_is_bit_identical_to_the_eager_step(backbone, dtype, golde
     assert torch.equal(eager[2], graph[2])
     for k, v in eager[3].items():
         assert torch.equal(v, graph[3][k]), k
+
+
+@pytest.mark.parametrize("backbone", ["swin", "vgg"])
+def test_graphed_trunk_under_the_fcos_head(backbone, dev):
+    """FCOSOverNeRF shares the trunk: same check (losses, arena, weights) with the dense FCOS head behind the captured backbone."""
+    import test_gpu_fcos as TF
+    from nerf_rpn_amd.engine import FlatTrainer
+    shape = (64, 56, 48)
+    gt = torch.tensor([[20., 18., 16., 14., 12., 10., 0.3], [40., 30., 28., 16., 18., 12., -0.5], [30., 40., 20., 10., 10., 14., 0.9]], device=dev)
+    out = {}
+    for use_graph in (False, True):
+        m = TF.build(True, backbone, dev).train()
+        m.set_compute_dtype(torch.bfloat16)
+        m.use_graph = use_graph
+        tr = FlatTrainer(m, lr=3e-4, weight_decay=0.01, clip_grad_norm=0.1)
+        losses, arenas = [], []
+        for it in range(5):
+            x = TF.scene(shape, 500 + (it % 2)).to(dev)
+            _, l, _ = m([x], [gt])
+            (l["loss_cls"] + l["loss_reg"] + l["loss_centerness"]).backward()
+            torch.cuda.synchronize()
+            arenas.append(tr.g_arena.clone())
+            tr.step()
+            losses.append(tuple(v.item() for v in l.values()))
+        out[use_graph] = (losses, arenas, tr.flat_params().clone(), 0 if m._trunk is None else len(m._trunk.captured))
+    assert out[False][3] == 0 and out[True][3] == 1
+    assert out[False][0] == out[True][0], (out[False][0], out[True][0])
+    for i, (a, b) in enumerate(zip(out[False][1], out[True][1])):
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+    assert torch.equal(out[False][2], out[True][2])
+
+
+def test_swin_steps_are_bit_reproducible_with_the_weight_gradient_stream(golden, dev):
+    """Regression (round 4): a residual join hands the SAME gradient tensor to both branches; autograd then accumulates into it in place on the
+    main stream while a weight-gradient kernel on the side stream still reads it, unless something else holds a reference
+    (ops._WGRAD_SIDE['keep']).  Two eager runs of the Swin-S model must agree bit for bit -- they did not (gradient arena off by 5e-2)."""
+    a = _run(dev, golden, False, "swin", torch.float32, steps=3)
+    b = _run(dev, golden, False, "swin", torch.float32, steps=3)
+    assert a[0] == b[0]
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y), (x - y).abs().max().item()
