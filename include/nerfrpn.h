@@ -527,6 +527,10 @@ int nrpn_roi_align_rotated_3d_bwd(const void *grad_out, const float *rois, int n
                                   float spatial_scale, int pw, int pl, int ph, int sampling_ratio, void *grad_in, void *workspace,
                                   int dtype, nrpn_stream_t stream);
 
+/* Reduction step of the trainer's bf16 all-to-all gradient exchange (engine.FlatTrainer, exchange "a2a_bf16"): recv = bf16 [world][chunk]
+ * (chunk `rank` of every peer's bucket), local = this rank's own fp32 chunk; out[i] = bf16(sum over ranks in ascending order, fp32
+ * accumulation, the local chunk taken from `local`).  chunk % 4 == 0. */
+int nrpn_a2a_reduce_bf16(const void *recv, const float *local, int rank, int world, int64_t chunk, void *out, nrpn_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 arena.  [a21]  (clip_grad_norm_ + AdamW, run_rpn.py:345-349,390-395)
  *   grad_scale folds the 1/world_size of the data-parallel mean into both kernels (sum all-reduce, no extra pass).

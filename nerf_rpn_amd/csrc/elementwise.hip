@@ -705,6 +705,45 @@ extern "C" int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtyp
 // =====================================================================================================================
 // optimiser on the flat fp32 arena
 // =====================================================================================================================
+// gradient exchange helper: the reduction step of the bf16 all-to-all mode (engine.FlatTrainer, exchange = "a2a_bf16")
+// =====================================================================================================================
+// out[i] = bf16( sum over ranks r of (r == rank ? local_f32[i] : float(recv[r][i])) ), ranks in ascending order, fp32 accumulation: the
+// local contribution never goes through bf16, the result is rounded once.  One pass (world x 2 B + 4 B read, 2 B written per element)
+// instead of cast + slice-assign + sum + cast.
+__global__ void __launch_bounds__(256) a2a_reduce_kernel(const bf16s *__restrict__ recv, const float *__restrict__ local, int rank, int world,
+                                                         long long chunk, bf16s *__restrict__ out) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < chunk; i += (long long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= chunk) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < world; ++r) {
+        const f4 v = (r == rank) ? *reinterpret_cast<const f4 *>(local + i) : vec4<bf16s>::ld(recv + (long long)r * chunk + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += v[k];
+      }
+      vec4<bf16s>::st(out + i, acc);
+    } else {
+      for (long long e = i; e < chunk; ++e) {
+        float acc = 0.f;
+        for (int r = 0; r < world; ++r) acc += (r == rank) ? local[e] : bf16_bits_to_f32(recv[(long long)r * chunk + e]);
+        out[e] = f32_to_bf16_bits(acc);
+      }
+    }
+  }
+}
+
+extern "C" int nrpn_a2a_reduce_bf16(const void *recv, const float *local, int rank, int world, int64_t chunk, void *out, nrpn_stream_t stream) {
+  NRPN_REQUIRE(recv && local && out && world >= 1 && rank >= 0 && rank < world && chunk > 0 && chunk % 4 == 0,
+               "a2a_reduce_bf16: bad arguments (chunk must be a multiple of 4 elements)");
+  const long long groups = chunk / 4;
+  long long blocks = (groups + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(a2a_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const bf16s *)recv, local, rank, world, (long long)chunk,
+                     (bf16s *)out);
+  NRPN_LAUNCH_CHECK("a2a_reduce_bf16");
+  return NRPN_OK;
+}
+
+// =====================================================================================================================
 // Deterministic sum of squares: kSumsqBlocks fixed-size partials (each a fixed-order tree), and the block that takes the last
 // ticket adds the partials in index order -- the result does not depend on which block finishes last.
 // buf: [0] result, [1] ticket counter (u32, zeroed by the launcher), [2 .. 2 + kSumsqBlocks) partials.

@@ -46,7 +46,7 @@ def one_cycle(step, total_steps, max_lr, pct_start=0.3, div_factor=25.0, final_d
     return cos(max_lr, minimum, pct), cos(base_momentum, max_momentum, pct)
 
 
-EXCHANGE_MODES = ("allreduce", "rs_ag", "a2a_bf16")
+EXCHANGE_MODES = ("allreduce", "rs_ag", "a2a_bf16")     # + "auto": measured at start-up (FlatTrainer.measure_exchange), fastest wins
 
 
 class _null:
@@ -79,9 +79,10 @@ class FlatTrainer:
         self.model = model
         self.static_graph = static_graph
         import os
-        self.exchange = exchange or os.environ.get("NRPN_GRAD_EXCHANGE", "allreduce")
-        if self.exchange not in EXCHANGE_MODES:
-            raise ValueError(f"exchange must be one of {EXCHANGE_MODES}, got {self.exchange!r}")
+        self.exchange = exchange or os.environ.get("NRPN_GRAD_EXCHANGE", "auto")
+        if self.exchange not in EXCHANGE_MODES + ("auto",):
+            raise ValueError(f"exchange must be one of {EXCHANGE_MODES + ('auto',)}, got {self.exchange!r}")
+        self.exchange_table = None        # comm-only timings of the start-up measurement (exchange='auto' or measure_exchange())
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -89,7 +90,7 @@ class FlatTrainer:
         # the exchange machinery (buckets, launch stream, collectives) runs whenever there is more than one rank; NRPN_FORCE_EXCHANGE=1
         # keeps it on for a one-rank process group, so that a single-GPU box exercises the real RCCL calls (tests / bench smoke)
         self.exchanging = self.world > 1 or (os.environ.get("NRPN_FORCE_EXCHANGE") == "1" and dist.is_available() and dist.is_initialized())
-        if self.exchange != "allreduce" and 64 % self.world != 0:
+        if self.exchange not in ("allreduce", "auto") and 64 % self.world != 0:
             # bucket boundaries are multiples of 64 floats; the chunked modes hand every rank 1/world of a bucket (fail here with a
             # clear message, not with a bare assertion in the middle of a collective sequence)
             raise ValueError(f"exchange={self.exchange!r} splits every bucket into world-size chunks and needs a world size that divides 64 "
@@ -144,30 +145,80 @@ class FlatTrainer:
         for i, p in enumerate(self.params):
             p._nrpn_sink = ops.GradSink(p.grad, self._make_notify(i), self.flat_grad[i])
             p.register_post_accumulate_grad_hook(self._make_hook(i))
-        # buckets in reverse parameter order (gradients arrive roughly back to front)
-        self.buckets = []       # (start, end) element ranges of g_arena
-        self.bucket_params = []
-        self.bucket_of = {}
+        self.buckets, self.bucket_params, self.bucket_of = [], [], {}
         self.handles = []
+        self.total = total
         if self.exchanging:
             dist.broadcast(self.p_arena, src=0, group=self.group)     # rank 0's weights everywhere (DDP init semantics)
-            per = max(1, bucket_bytes // 4)
-            end = total
-            members = []
-            for i in range(len(self.params) - 1, -1, -1):
-                o, n = self.slices[i]
-                members.append(i)
-                self.bucket_of[i] = len(self.buckets)
-                if end - o >= per or i == 0:
-                    self.buckets.append((o, end))
-                    self.bucket_params.append(members)
-                    end, members = o, []
+            self._build_buckets(bucket_bytes)
         self.launched = [False] * len(self.buckets)
         self.early = [False] * len(self.buckets)
         self.finish = []                  # continuations of multi-phase exchanges (rs_ag / a2a_bf16), run by sync_gradients
         self._comm_stream = None
         self.exchange_events = None       # set to [] to collect (start, end) events around the exchange wait of every step
         self._streams = {}                # raw handle -> torch stream of every stream gradients are produced on
+        if self.exchange == "auto":
+            # the mode (and bucket size) is chosen from a comm-only measurement on the real arena -- every rank takes part and all agree
+            # on the result (MAX over ranks) -- instead of assuming what the node's xGMI topology prefers
+            if self.exchanging:
+                self.exchange_table = self.measure_exchange()
+                best = min(self.exchange_table, key=lambda k: self.exchange_table[k])
+                self.exchange = best[0]
+                self._build_buckets(best[1] << 20)
+            else:
+                self.exchange = "allreduce"
+
+    def _build_buckets(self, bucket_bytes):
+        """Buckets of ~bucket_bytes in reverse parameter order (gradients arrive roughly back to front)."""
+        self.bucket_bytes = int(bucket_bytes)
+        self.buckets, self.bucket_params, self.bucket_of = [], [], {}
+        per = max(1, self.bucket_bytes // 4)
+        end = self.total
+        members = []
+        for i in range(len(self.params) - 1, -1, -1):
+            o, n = self.slices[i]
+            members.append(i)
+            self.bucket_of[i] = len(self.buckets)
+            if end - o >= per or i == 0:
+                self.buckets.append((o, end))
+                self.bucket_params.append(members)
+                end, members = o, []
+        self.launched = [False] * len(self.buckets)
+        self.early = [False] * len(self.buckets)
+
+    def measure_exchange(self, modes=EXCHANGE_MODES, bucket_mib=(16, 32, 64), iters=3):
+        """Comm-only timing of every exchange mode x bucket size on the real gradient arena (no compute in flight): {(mode, MiB): ms}, the
+        MAX over ranks of the best of ``iters`` passes, so every rank holds the same table.  Leaves arena, buckets and mode as they were."""
+        import time
+        keep = (self.exchange, self.bucket_bytes if self.buckets else 64 << 20)
+        cuda = self.g_arena.is_cuda
+        table = {}
+        for mode in modes:
+            if mode != "allreduce" and 64 % self.world != 0:
+                continue
+            for mib in bucket_mib:
+                self.exchange = mode
+                self._build_buckets(mib << 20)
+                best = float("inf")
+                for it in range(iters + 1):          # first pass = warm-up (communicator / buffer set-up)
+                    if cuda:
+                        torch.cuda.synchronize()
+                    dist.barrier(group=self.group)
+                    t0 = time.perf_counter()
+                    for b in range(len(self.buckets)):
+                        self._launch(b)
+                    self._finish_exchange()
+                    if cuda:
+                        torch.cuda.synchronize()
+                    if it:
+                        best = min(best, time.perf_counter() - t0)
+                t = torch.tensor([best * 1e3], dtype=torch.float64, device=self.g_arena.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                table[(mode, mib)] = round(t.item(), 4)
+        self.g_arena.zero_()
+        self.exchange = keep[0]
+        self._build_buckets(keep[1])
+        return table
 
     def _make_notify(self, i):
         def notify():
@@ -248,9 +299,12 @@ class FlatTrainer:
 
         def second(h1=h1, recv=recv, g=g):
             h1.wait()
-            parts = recv.view(world, chunk).float()
-            parts[rank] = g.view(world, chunk)[rank]            # the local contribution never went through bf16
-            reduced = parts.sum(dim=0).to(torch.bfloat16)
+            if g.is_cuda and chunk % 4 == 0:      # one kernel: fp32 sum over the ranks in rank order, own chunk from the fp32 original, rounded once (ops.a2a_reduce)
+                reduced = ops.a2a_reduce(recv, g, rank, world)
+            else:
+                parts = recv.view(world, chunk).float()
+                parts[rank] = g.view(world, chunk)[rank]        # the local contribution never went through bf16
+                reduced = parts.sum(dim=0).to(torch.bfloat16)
             full = torch.empty(world * chunk, dtype=torch.bfloat16, device=g.device)
             h2 = dist.all_gather_into_tensor(full, reduced, group=grp, async_op=True)
 
@@ -267,30 +321,34 @@ class FlatTrainer:
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
                     self._launch(b)
-            cuda = self.g_arena.is_cuda
-            ctx = torch.cuda.stream(self._comm_stream) if cuda else _null()
-            with ctx:                                           # multi-phase modes continue on the launch stream
-                pending = list(self.finish)
-                self.finish = []
-                while pending:
-                    nxt = []
-                    for fn in pending:
-                        r = fn()
-                        if callable(r):
-                            nxt.append(r)
-                        elif r is not None:
-                            self.handles.append(r)
-                    pending = nxt
-            for h in self.handles:
-                h.wait()
-            if cuda:
-                torch.cuda.current_stream(self.g_arena.device).wait_stream(self._comm_stream)
-            self.handles = []
-            self.launched = [False] * len(self.buckets)
+            self._finish_exchange()
         if self.expected is None:
             self.expected = list(self.seen)
             self.early = [self.static_graph and all(self.expected[j] > 0 for j in members) for members in self.bucket_params]
         self.seen = [0] * len(self.params)
+
+    def _finish_exchange(self):
+        """Run the continuations of the multi-phase modes, wait for every handle, join the launch stream."""
+        cuda = self.g_arena.is_cuda
+        ctx = torch.cuda.stream(self._comm_stream) if (cuda and self._comm_stream is not None) else _null()
+        with ctx:                                           # multi-phase modes continue on the launch stream
+            pending = list(self.finish)
+            self.finish = []
+            while pending:
+                nxt = []
+                for fn in pending:
+                    r = fn()
+                    if callable(r):
+                        nxt.append(r)
+                    elif r is not None:
+                        self.handles.append(r)
+                pending = nxt
+        for h in self.handles:
+            h.wait()
+        if cuda and self._comm_stream is not None:
+            torch.cuda.current_stream(self.g_arena.device).wait_stream(self._comm_stream)
+        self.handles = []
+        self.launched = [False] * len(self.buckets)
 
     def step(self):
         ops.wgrad_stream_join()

@@ -651,6 +651,16 @@ _weight_epoch = 0
 PACK_COUNT = {"conv": 0, "stem": 0}      # pack launches so far (tests assert packs == modules x optimiser steps)
 
 
+def a2a_reduce(recv, bucket, rank, world):
+    """recv: bf16 [world * chunk] (chunk ``rank`` of every peer's bucket, peer-major), bucket: this rank's fp32 bucket [world * chunk] -> bf16
+    [chunk] = sum over the ranks in ascending order in fp32, the own chunk read from the fp32 bucket (engine.FlatTrainer, a2a_bf16)."""
+    chunk = bucket.numel() // world
+    _chk(recv, bucket)
+    out = torch.empty(chunk, dtype=torch.bfloat16, device=bucket.device)
+    call("a2a_reduce_bf16", _p(recv), bucket.data_ptr() + rank * chunk * 4, rank, world, chunk, _p(out), _s())
+    return out
+
+
 def weights_changed():
     global _weight_epoch
     _weight_epoch += 1

@@ -105,6 +105,56 @@ def test_flat_trainer_gradient_exchange(bucket_bytes, exchange):
         assert torch.allclose(g_a, flat, atol=1e-5)
 
 
+def _auto_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if os.path.exists("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_rpn_amd.engine import FlatTrainer, EXCHANGE_MODES
+    torch.manual_seed(100 + rank)
+    model = Tiny()
+    tr = FlatTrainer(model, exchange="auto")           # comm-only measurement at start-up, fastest (mode, bucket size) wins
+    table = dict(tr.exchange_table)
+    assert tr.exchange in EXCHANGE_MODES and (tr.exchange, tr.bucket_bytes >> 20) in table
+    assert table[(tr.exchange, tr.bucket_bytes >> 20)] == min(table.values())
+    assert float(tr.g_arena.abs().max()) == 0.0       # the measurement leaves a clean arena
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(8, 8, generator=g), torch.randn(8, 3, generator=g)
+    xs, ys = x_all[rank * 4:(rank + 1) * 4], y_all[rank * 4:(rank + 1) * 4]
+    ((model(xs) - ys) ** 2).sum().backward()
+    tr.sync_gradients()
+    q.put((rank, tr.exchange, tr.bucket_bytes, sorted((k[0], k[1], v) for k, v in table.items()), (tr.flat_grads() / world).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_auto_measures_every_mode_and_all_ranks_agree():
+    """exchange='auto' (the default): every rank times every (mode, bucket size) on the real arena, takes the MAX over ranks and therefore
+    picks the same winner; the exchange that follows still leaves the mean gradient everywhere."""
+    res = _run_ranks(_auto_worker, ())
+    (_, mode_a, bb_a, tab_a, g_a), (_, mode_b, bb_b, tab_b, g_b) = res
+    assert (mode_a, bb_a) == (mode_b, bb_b) and tab_a == tab_b
+    assert {m for m, _, _ in tab_a} == {"allreduce", "rs_ag", "a2a_bf16"} and len(tab_a) == 9
+    g_a, g_b = torch.from_numpy(g_a), torch.from_numpy(g_b)
+    torch.manual_seed(100)
+    ref = Tiny()
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(8, 8, generator=g), torch.randn(8, 3, generator=g)
+    ((ref(x_all) - y_all) ** 2).sum().backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ref.parameters()]) / 2
+    tol = dict(rtol=2 ** -7, atol=2 ** -8 * flat.abs().max().item()) if mode_a == "a2a_bf16" else dict(atol=1e-5)
+    assert torch.allclose(g_a, flat, **tol) and torch.allclose(g_b, flat, **tol)
+
+
+def test_chunked_exchange_rejects_world_sizes_that_do_not_divide_a_bucket():
+    """rs_ag / a2a_bf16 hand every rank 1/world of a 64-float-aligned bucket -- a world size of 3, 5, 6, 7 must fail at
+    construction with a clear message, not with an assertion in the middle of a collective sequence."""
+    import inspect
+    from nerf_rpn_amd import engine
+    src = inspect.getsource(engine.FlatTrainer.__init__)
+    assert "64 % self.world" in src and "divides 64" in src
+
+
 class _SinkLinear(torch.autograd.Function):
     """CPU stand-in for the HIP backward kernels: accumulates the weight gradient straight into the trainer's arena slot
     (ops.GradSink) and notifies, instead of returning a gradient tensor to autograd."""

@@ -151,3 +151,21 @@ def test_single_rank_rccl_exchange_modes(dev):
     assert nb >= 2 and early >= 1
     scale = float(abs(g_plain).max())
     assert abs(g - g_plain).max() <= 2.0 ** -8 * scale and torch.isfinite(torch.from_numpy(prm)).all()
+
+
+def test_a2a_reduce_kernel_matches_the_torch_formulation(dev):
+    """nrpn_a2a_reduce_bf16 (the reduction step of the bf16 all-to-all exchange): fp32 sum over the ranks in ascending order, the own chunk
+    from the fp32 bucket, one rounding -- bit-equal to the five-op torch formulation it replaces."""
+    from nerf_rpn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for world, chunk in ((2, 4096), (8, 64 * 1000 + 8), (4, 16)):
+        bucket = torch.randn(world * chunk, generator=g).to(dev)
+        recv = torch.randn(world * chunk, generator=g).to(torch.bfloat16).to(dev)
+        for rank in (0, world - 1):
+            parts = recv.view(world, chunk).float()
+            parts[rank] = bucket.view(world, chunk)[rank]
+            want = torch.zeros(chunk, device=dev)
+            for r in range(world):
+                want = want + parts[r]
+            got = ops.a2a_reduce(recv, bucket, rank, world)
+            assert torch.equal(got, want.to(torch.bfloat16)), (world, chunk, rank)
