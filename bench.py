@@ -148,7 +148,7 @@ class ConvProbe:
         es = 2 if dtype_name == "bf16" else 4
         algo_bytes = vox * cin_ * es + vox * cout_ * es + (_k ** 3) * cin_ * cout_ * es      # x + y + w, each once
         traffic, note = None, "no PMC collection for this kernel in profiles/ (null = not measured)"
-        for pmc_name in ("r03_pmc_conv_256x256_40c.json", "r02_pmc_conv_256x256_40c.json"):
+        for pmc_name in ("r04_pmc_conv_256x256_40c.json", "r03_pmc_conv_256x256_40c.json", "r02_pmc_conv_256x256_40c.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if not (os.path.exists(pmc) and shape == (64000, 256, 256, 3)):
                 continue

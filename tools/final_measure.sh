@@ -15,5 +15,15 @@ python tools/prof_summary.py $(find /tmp/prof -name "*kernel_trace.csv" | head -
 cp $(find /tmp/prof2 -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 grep '^{' $out/prof_bench.log | python tools/bench_line.py profiled-single | cut -c1-120
 grep '^{' $out/prof_bench2.log | python tools/bench_line.py profiled-streams | cut -c1-120
+# secondary workloads (not the BASELINE metric): eager and with the trunk as captured HIP graphs
+for m in resnet_rpn swin_rpn swin_fcos vgg_fcos; do
+  for g in off on; do
+    timeout 200 python bench.py --model $m --graph $g --steps 30 --no-cpu-baseline --no-extras --no-probe > $out/bench_${m}_graph_$g.json 2>/dev/null
+    python -c "import json; d=json.load(open('$out/bench_${m}_graph_$g.json')); print('$m graph=$g', d['ms_per_step'], d['value'], d.get('host'))" | cut -c1-200
+  done
+done
+timeout 200 python bench.py --graph on --steps 30 --no-cpu-baseline --no-extras --no-probe > $out/bench_vgg_rpn_graph_on.json 2>/dev/null
+NRPN_CONE=0 timeout 200 python bench.py --steps 30 --no-cpu-baseline --no-extras > $out/bench_vgg_rpn_dense_head.json 2>/dev/null
+python -c "import json; print('vgg graph=on', json.load(open('$out/bench_vgg_rpn_graph_on.json'))['ms_per_step'], 'dense head', json.load(open('$out/bench_vgg_rpn_dense_head.json'))['ms_per_step'])"
 # PMC counters of the kernels that can serve the dominant shape (halo form, 256x256 tile on 8 / 4 waves) and the 256x256 wgrad kernel
 bash tools/pmc_conv.sh $out/pmc > $out/pmc.log 2>&1; tail -5 $out/pmc.log | cut -c1-200
