@@ -303,10 +303,12 @@ int nrpn_cone_build(const int64_t *pos, const int64_t *neg, const int32_t *count
                     int nlevels, const int64_t *level_anchor_off, int num_anchors, const int32_t *dims, int depth, uint32_t *lists,
                     int64_t cap, int32_t *counts_out, void *workspace, nrpn_stream_t stream);
 /* forward / dgrad on the `nrows` listed output rows: x, y and relu_mask are [total voxels][C] tensors indexed by voxel id; rows outside the
- * list are not written.  128-row tiles, no workspace.  Cin * elemsize must be a multiple of 128 bytes. */
+ * list are not written.  128-row tiles; short lists run on K slices (fp32 partials in `workspace`, >= nrpn_conv3d_fwd_rows_workspace_bytes; NULL =
+ * one slice) summed in slice order by a scatter epilogue.  Cin * elemsize must be a multiple of 128 bytes. */
+size_t nrpn_conv3d_fwd_rows_workspace_bytes(int64_t nrows, int cin, int cout, int ksize, int dtype);
 int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *bias, void *y, const uint32_t *rows, int64_t nrows, int nseg,
                          const int32_t *dims, int cin, int cout, int wrows, int ksize, int dtype, int flags, const void *relu_mask,
-                         nrpn_stream_t stream);
+                         void *workspace, nrpn_stream_t stream);
 /* wgrad over the `nrows` listed voxels (the K extent): partial layout / slice count as nrpn_conv3d_wgrad with n = 1, gx = nrows, gy = gz = 1;
  * workspace: >= max(256, slices * wrows * 4) bytes (bias partials; NRPN_WGRAD_* flags as above, MASK_READY is implied). */
 int nrpn_conv3d_wgrad_rows(const void *x, const void *dy, float *gw_packed, float *gbias, const uint32_t *rows, int64_t nrows, int nseg,

@@ -1183,6 +1183,24 @@ __global__ void splitk_epilogue_kernel(const float *__restrict__ ws, const float
   }
 }
 
+// the same for the row-list form: partial row r belongs to voxel rows[2 r]; bias / ReLU / ReLU mask / store at that voxel's row of y
+template <typename T, bool OUTF32>
+__global__ void rows_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias, void *__restrict__ y, long long total,
+                                     int cout, int relu, int nslices, const T *__restrict__ mask, const unsigned *__restrict__ rows) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float o = ws[i];
+    for (int z = 1; z < nslices; ++z) o += ws[z * total + i];
+    const long long r = i / cout;
+    const int col = (int)(i - r * cout);
+    const long long dst = (long long)rows[2 * r] * cout + col;
+    o += bias ? bias[col] : 0.f;
+    if (relu) o = fmaxf(o, 0.f);
+    if (mask && !(elem<T>::ld(mask + dst) > 0.f)) o = 0.f;
+    if (OUTF32) reinterpret_cast<float *>(y)[dst] = o;
+    else elem<T>::st(reinterpret_cast<T *>(y) + dst, o);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Kernel selection.  Every decision below is a pure function of (shape, Knobs): a call resolves its Knobs from the process-wide
 // defaults (developer switches, tools only) overridden by the caller's nrpn_conv_opts, so two threads with different plans never
@@ -1524,9 +1542,28 @@ extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float
 // Row-list form of the forward / dgrad launch: output rows = the `nrows` voxels of `rows` ([nrows][2] u32 = {voxel id in the ragged space of
 // `dims`, tap word}; csrc/cone.hip builds such lists) -- x, y and relu_mask are indexed by voxel id, rows outside the list are neither
 // read as outputs nor written.  128-row tiles of conv_igemm_kernel, no K slices (the lists are short: one launch, no workspace).
+// Short lists (the S0 / S1 cones: 2-70 tiles) would leave the chip idle behind a 54-step K loop: they run on K slices whose fp32 partials
+// ([slices][nrows][Cout], plain stores) are summed in slice order and scattered by rows_epilogue_kernel.
+static int rows_ksplit(long long nrows, int cin, int cout, int taps, int es) {
+  const long long tiles = cdiv64(nrows, 128) * ((cout + 127) / 128);
+  const int nk = taps * (cin * es / 128);
+  if (tiles >= 128 || nk < 12) return 1;
+  long long s = (256 + tiles - 1) / tiles;
+  if (s > nk / 6) s = nk / 6;
+  if (s > 32) s = 32;
+  if (s < 2) return 1;
+  const long long per = (nk + s - 1) / s;
+  s = (nk + per - 1) / per;                  // no empty slice
+  return s < 2 ? 1 : (int)s;
+}
+extern "C" size_t nrpn_conv3d_fwd_rows_workspace_bytes(int64_t nrows, int cin, int cout, int ksize, int dtype) {
+  const int s = rows_ksplit(nrows, cin, cout, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
+  return s > 1 ? (size_t)s * nrows * cout * 4 : 0;
+}
+
 extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *bias, void *y, const uint32_t *rows, int64_t nrows, int nseg,
                                     const int32_t *dims, int cin, int cout, int wrows, int ksize, int dtype, int flags, const void *relu_mask,
-                                    nrpn_stream_t stream) {
+                                    void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(ksize == 1 || ksize == 3, "conv3d_fwd_rows: ksize must be 1 or 3 (got %d)", ksize);
   NRPN_REQUIRE(dtype == NRPN_F32 || dtype == NRPN_BF16, "conv3d_fwd_rows: bad dtype %d", dtype);
   NRPN_REQUIRE(x && wp && y && rows && nrows >= 0 && cin > 0 && cout > 0 && wrows >= cout, "conv3d_fwd_rows: bad arguments");
@@ -1546,7 +1583,9 @@ extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *
                "conv3d_fwd_rows: activation / weight tensors must stay below 2 GiB (32-bit buffer offsets)");
   a.x_bytes = (unsigned)(total * cin * es); a.w_bytes = (unsigned)((long long)a.taps * wrows * cin * es);
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)(cdiv64(nrows, 128) * ((cout + 127) / 128)));
+  const int ks = workspace ? rows_ksplit(nrows, cin, cout, a.taps, es) : 1;
+  if (ks > 1) { a.ksplit = ks; a.ws = reinterpret_cast<float *>(workspace); }
+  dim3 grid((unsigned)(cdiv64(nrows, 128) * ((cout + 127) / 128) * ks));
   const size_t lds_ = 2 * (size_t)(128 + 128) * 128;
   int rc;
   if (dtype == NRPN_F32) rc = launch_igemm(conv_igemm_kernel<float, 128, 0, true, 128, true, 128, true>, grid, lds_, st, a);
@@ -1554,6 +1593,16 @@ extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *
   else rc = launch_igemm(conv_igemm_kernel<bf16s, 128, 0, false, 128, true, 128, true>, grid, lds_, st, a);
   if (rc) return rc;
   NRPN_LAUNCH_CHECK("conv3d_fwd_rows");
+  if (ks > 1) {
+    const long long total = nrows * cout;
+    const int blocks = (int)min((long long)2048, (total + 255) / 256);
+    const float *b = (flags & NRPN_CONV_BIAS) ? bias : nullptr;
+    const int relu = (flags & NRPN_CONV_RELU) ? 1 : 0;
+    if (dtype == NRPN_F32) hipLaunchKernelGGL((rows_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, ks, (const float *)relu_mask, rows);
+    else if (out_f32) hipLaunchKernelGGL((rows_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, ks, (const bf16s *)relu_mask, rows);
+    else hipLaunchKernelGGL((rows_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, ks, (const bf16s *)relu_mask, rows);
+    NRPN_LAUNCH_CHECK("rows_epilogue");
+  }
   return NRPN_OK;
 }
 

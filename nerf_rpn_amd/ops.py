@@ -1036,7 +1036,10 @@ def conv_rows_fwd(x, wp, bias, y, plan, k, cin, cout, wrows, ksize, flags, mask=
         flags |= CONV_OUT_F32
     if bias is not None:
         flags |= CONV_BIAS
-    call("conv3d_fwd_rows", _p(x), _p(wp), _p(bias), _p(y), rows, nrows, plan.nseg, plan.dims_ptr, cin, cout, wrows, ksize, _dt(x), flags, _p(mask), _s())
+    wsb = lib.query("conv3d_fwd_rows_workspace_bytes", nrows, cin, cout, ksize, _dt(x))      # (not memoised: the list length changes every step)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    call("conv3d_fwd_rows", _p(x), _p(wp), _p(bias), _p(y), rows, nrows, plan.nseg, plan.dims_ptr, cin, cout, wrows, ksize, _dt(x), flags, _p(mask),
+         _p(ws), _s())
     return y
 
 
@@ -1060,7 +1063,7 @@ def conv_rows_wgrad(x, dy, weights, biases, rows_total, ksize, plan, k, sinks=No
             else:
                 out.append(torch.zeros_like(t, dtype=torch.float32))
         return tuple(out)
-    slices = query("conv3d_wgrad_slices", 1, nrows, 1, 1, cin, rows_total, rows_total, ksize, _dt(x))
+    slices = lib.query("conv3d_wgrad_slices", 1, nrows, 1, 1, cin, rows_total, rows_total, ksize, _dt(x))      # (not memoised: nrows changes every step)
     gwp = torch.empty((slices, taps, rows_total, cin), dtype=torch.float32, device=x.device)
     direct_bias = has_bias and nw == 1 and bsinks[0] is not None
     gb = bsinks[0].slot if direct_bias else (torch.empty(rows_total, dtype=torch.float32, device=x.device) if has_bias else None)
