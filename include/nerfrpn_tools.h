@@ -30,6 +30,8 @@ int nrpn_set_conv_big_split(int on);
 int nrpn_set_wgrad_big_tile(int on);
 /* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
 int nrpn_set_wgrad_transpose_read(int on);
+/* row-list conv (nrpn_conv3d_fwd_rows): 1 = lists of >= 96 tiles of 256 rows run the 256x256 tile (measured 0.4 % slower: kept for A/B), 0 (default) = 128-row tiles */
+int nrpn_set_rows_big_tile(int on);
 /* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
 int nrpn_set_window_attn_mfma(int on);
 

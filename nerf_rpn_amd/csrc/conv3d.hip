@@ -579,7 +579,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_ws_kernel(const ConvArgs p)
 // DBG (tools-only instantiations, selected by NRPN_CONV_DEBUG_* in the flag word; the production instantiation is DBG = 0 and carries
 // none of these branches): bit 0 = every tap reads the centre voxel ("ideal memory"), bit 1 = no per-K-step barrier / DMA drain.
 // RESULTS ARE WRONG with DBG != 0 (timing diagnosis, tools/diag_big_conv.py).
-template <bool OUTF32, bool STAG = false, int DBG = 0>
+// ROWS: row-list form (tile row v = voxel p.rows[2 v], tap word p.rows[2 v + 1]; outputs and the ReLU mask at that voxel), cf. conv_igemm_kernel.
+template <bool OUTF32, bool STAG = false, int DBG = 0, bool ROWS = false>
 __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p) {
   typedef bf16s T;
   constexpr int BM = 256, BN = 256, KB = 128, KE = 64, PPR = 8, RSTEP = 64, TM = 4, TN = 2;
@@ -612,13 +613,25 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     const int r = lr + RSTEP * i;
     const long long v = m0 + r;
     const bool ok = v < p.M;
-    const long long vv = ok ? v : 0;
-    int ox, oy, oz, gX, gY, gZ;
-    locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
+    long long vv = ok ? v : 0;
+    int ox, oy, oz, gX = p.X, gY = p.Y, gZ = p.Z;
+    unsigned row_word = 0;
+    if (ROWS) {
+      if (ok) { row_word = p.rows[2 * vv + 1]; vv = p.rows[2 * vv]; }
+      const int seg = (int)(row_word >> 27);
+#pragma unroll
+      for (int q = 0; q < kMaxSeg; ++q)
+        if (q == seg && q < p.segs.n) { gY = p.segs.Y[q]; gZ = p.segs.Z[q]; }
+      ox = oy = oz = 0;
+    } else {
+      locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
+    }
     a_yz[i] = gY * gZ * p.Cin * 2;
     a_zs[i] = gZ * p.Cin * 2;
     unsigned m = 0;
-    if (ok) {
+    if (ROWS) {
+      m = p.taps == 27 ? (row_word & 0x7FFFFFFu) : (ok ? 1u : 0u);
+    } else if (ok) {
       if (p.taps == 27) {
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
@@ -845,9 +858,10 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
       for (int q = 0; q < 8; ++q) {
         const int pc = elane + 64 * q;                  // 512 pieces: 64 rows x 8 pieces of 16 bytes
         const int row = pc >> 3, seg = pc & 7;
-        const long long v = m0 + wm * 128 + half * 64 + row;
+        const long long vt = m0 + wm * 128 + half * 64 + row;
         const int col = n0 + wn * 64 + seg * 8;
-        if (v < p.M && col < p.Cout) {
+        if (vt < p.M && col < p.Cout) {
+          const long long v = ROWS ? (long long)p.rows[2 * vt] : vt;
           f4 val = *reinterpret_cast<const f4 *>(stage + row * PITCH + seg * 16);
           if (maskp) {
             typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
@@ -879,8 +893,9 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
-        if (v < p.M) {
+        const long long vt = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
+        if (vt < p.M) {
+          const long long v = ROWS ? (long long)p.rows[2 * vt] : vt;
           float o = acc[i][j][r] * sv + bv;
           if (relu) o = fmaxf(o, 0.f);
           if (p.mask && !(elem<T>::ld(reinterpret_cast<const T *>(p.mask) + v * p.Cout + col) > 0.f)) o = 0.f;
@@ -1542,6 +1557,12 @@ extern "C" int nrpn_conv3d_fwd_ragged(const void *x, const void *wp, const float
 // Row-list form of the forward / dgrad launch: output rows = the `nrows` voxels of `rows` ([nrows][2] u32 = {voxel id in the ragged space of
 // `dims`, tap word}; csrc/cone.hip builds such lists) -- x, y and relu_mask are indexed by voxel id, rows outside the list are neither
 // read as outputs nor written.  128-row tiles of conv_igemm_kernel, no K slices (the lists are short: one launch, no workspace).
+// tools-only A/B switch (include/nerfrpn_tools.h): 256x256 tile for long row lists.  OFF by default -- measured on one box, bench step,
+// S3 = 33 k rows = 130 tiles: 9.47 ms with it against 9.43 ms on 128-row tiles (three alternating runs each): the 8-wave tile's
+// chunk-outer K order counts on an XCD's workgroups sweeping one contiguous voxel slab through its L2, which a gathered list is not.
+static std::atomic<int> g_rows_big{0};
+extern "C" int nrpn_set_rows_big_tile(int on) { g_rows_big = on ? 1 : 0; return NRPN_OK; }
+
 // Short lists (the S0 / S1 cones: 2-70 tiles) would leave the chip idle behind a 54-step K loop: they run on K slices whose fp32 partials
 // ([slices][nrows][Cout], plain stores) are summed in slice order and scattered by rows_epilogue_kernel.
 static int rows_ksplit(long long nrows, int cin, int cout, int taps, int es) {
@@ -1585,6 +1606,16 @@ extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *
   hipStream_t st = as_stream(stream);
   const int ks = workspace ? rows_ksplit(nrows, cin, cout, a.taps, es) : 1;
   if (ks > 1) { a.ksplit = ks; a.ws = reinterpret_cast<float *>(workspace); }
+  // opt-in (nrpn_set_rows_big_tile): long bf16 lists (>= 96 tiles of 256 rows) of wide layers on the 256x256 tile
+  if (g_rows_big.load(std::memory_order_relaxed) && dtype == NRPN_BF16 && !out_f32 && ks == 1 && cout >= 256 && (cout & 7) == 0 &&
+      cdiv64(nrows, 256) * ((cout + 255) / 256) >= 96) {
+    const size_t lds_big = 2 * (size_t)(256 + 256) * 128;
+    dim3 gbig((unsigned)(cdiv64(nrows, 256) * ((cout + 255) / 256)));
+    NRPN_LDS((conv_igemm_big_kernel<false, true, 0, true>), (int)lds_big);
+    hipLaunchKernelGGL((conv_igemm_big_kernel<false, true, 0, true>), gbig, dim3(512), lds_big, st, a);
+    NRPN_LAUNCH_CHECK("conv3d_fwd_rows (256x256 tile)");
+    return NRPN_OK;
+  }
   dim3 grid((unsigned)(cdiv64(nrows, 128) * ((cout + 127) / 128) * ks));
   const size_t lds_ = 2 * (size_t)(128 + 128) * 128;
   int rc;

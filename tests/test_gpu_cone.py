@@ -131,6 +131,42 @@ def test_conv_rows_forward_matches_torch_on_the_listed_rows(dtype, ksize, cin, c
             assert torch.all(got[rest] == 3.0)          # rows outside the list are not written
 
 
+def test_conv_rows_long_list_runs_the_256x256_tile(dev):
+    """The opt-in 256x256-tile form of the row-list conv (conv_igemm_big_kernel<ROWS>, tools switch nrpn_set_rows_big_tile; a measured
+    negative, kept for A/B) on a list of >= 96 tiles of 256 rows, and the default 128-row tiling of the same list: listed rows against torch
+    fp32 on the CPU, everything else untouched, with bias + ReLU and with a ReLU mask."""
+    from nerf_rpn_amd import lib, ops
+    grids = [(40, 40, 40)]
+    rng = np.random.default_rng(8)
+    pos, neg, _ = _sample(grids, 1, rng, 300, 300)
+    plan = _plan(grids, 1, 3, pos, neg, dev)
+    assert plan.counts[3] >= 96 * 256, plan.counts
+    V, cin, cout = plan.total, 256, 256
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(V, cin, generator=g) * 0.5).clamp_min(0).to(torch.bfloat16)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    wp, _ = ops.PackedWeight().get([w.to(dev)], torch.bfloat16, cout, True, cin)
+    mask = torch.randn(V, cout, generator=g).to(torch.bfloat16)
+    ref = _torch_conv(x, w.to(torch.bfloat16).float(), b, grids, 1, 3)
+    ids = plan.lists[3, :plan.counts[3], 0].long().cpu()
+    rest = torch.ones(V, dtype=torch.bool)
+    rest[ids] = False
+    try:
+        for big in (1, 0):
+            lib.call("set_rows_big_tile", big)
+            for relu, use_mask in ((True, False), (False, True)):
+                y = torch.full((V, cout), 3.0, dtype=torch.bfloat16, device=dev)
+                ops.conv_rows_fwd(x.to(dev), wp, b.to(dev), y, plan, 3, cin, cout, cout, 3, lib_flags(relu), mask.to(dev) if use_mask else None)
+                want = ref.clamp_min(0) if relu else torch.where(mask.float() > 0, ref, torch.zeros_like(ref))
+                got = y.float().cpu()
+                err = (got[ids] - want[ids]).abs().max().item() / want[ids].abs().max().item()
+                assert err < 1.2e-2, (big, relu, use_mask, err)
+                assert torch.all(got[rest] == 3.0)
+    finally:
+        lib.call("set_rows_big_tile", 0)
+
+
 def lib_flags(relu):
     from nerf_rpn_amd import lib
     return lib.CONV_RELU if relu else 0
