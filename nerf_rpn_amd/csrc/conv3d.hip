@@ -591,14 +591,33 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned ntiles = (p.Cout + BN - 1) / BN;
   const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * ntiles;
-  const unsigned zsplit = blockIdx.x / tiles;                      // K slice (0 unless ksplit > 1)
-  const unsigned tile = xcd_remap(blockIdx.x - zsplit * tiles, tiles);
+  // Three tilings of the launch: every tile whole (ksplit <= 1), every tile on `ksplit` K slices, or -- tail_ks > 1 -- the M tiles from
+  // tail_tile0 on (the last, partial round of a launch that needs a little more than a whole number of rounds of the chip) on tail_ks
+  // K slices while the full rounds run whole: a 323-tile launch (eval at 200 x 200 x 130) then costs 1 + 1/3 rounds instead of 2.
+  unsigned zsplit, tile;
+  int my_ks = p.ksplit > 1 ? p.ksplit : 1;
+  long long part_row0 = 0;                                         // first row of the partials' row range in ws
+  if (p.tail_ks > 1) {
+    const unsigned full = (unsigned)p.tail_tile0 * ntiles;
+    if (blockIdx.x < full) {
+      zsplit = 0; my_ks = 1;
+      tile = xcd_remap(blockIdx.x, full);
+    } else {
+      const unsigned t = blockIdx.x - full, ntail = tiles - full;
+      zsplit = t / ntail; my_ks = p.tail_ks;
+      tile = full + t % ntail;
+      part_row0 = (long long)p.tail_tile0 * BM;
+    }
+  } else {
+    zsplit = blockIdx.x / tiles;                                   // K slice (0 unless ksplit > 1)
+    tile = xcd_remap(blockIdx.x - zsplit * tiles, tiles);
+  }
   const long long m0 = (long long)(tile / ntiles) * BM;
   const int n0 = (int)(tile % ntiles) * BN;
   const int cpt = p.Cin / KE;
   int ks_begin = 0, nk = p.taps * cpt;
-  if (p.ksplit > 1) {
-    const int per = (nk + p.ksplit - 1) / p.ksplit;
+  if (my_ks > 1) {
+    const int per = (nk + my_ks - 1) / my_ks;
     ks_begin = zsplit * per;
     nk = min(nk, ks_begin + per);        // this workgroup runs K-steps [ks_begin, nk)
   }
@@ -801,8 +820,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
   int elane = lane;
   asm volatile("" : "+v"(elane));
   const int efr = elane & 31;
-  if (p.ksplit > 1) {     // fp32 partial of this K slice, plain stores; bias / ReLU / cast happen in splitk_epilogue_kernel
-    float *wsz = p.ws + (long long)zsplit * p.M * p.Cout;
+  if (my_ks > 1) {     // fp32 partial of this K slice, plain stores; bias / ReLU / cast happen in splitk_epilogue_kernel
+    float *wsz = p.ws + (long long)zsplit * (p.M - part_row0) * p.Cout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + efr;
@@ -812,7 +831,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, elane);
-          if (v < p.M) wsz[v * p.Cout + col] = acc[i][j][r];
+          if (v < p.M) wsz[(v - part_row0) * p.Cout + col] = acc[i][j][r];
         }
     }
     return;
@@ -1295,6 +1314,26 @@ static int conv_big_split(long long M, int cout, int cin, int taps, int elem_byt
   return s >= 2 ? s : 0;
 }
 
+// Tail split of a 256x256-tile launch: tiles = whole rounds of the 256 CUs + a short remainder (eval at 200 x 200 x 130: 323 = 256 + 67).  The
+// remainder's M tiles run on K slices so that the second round lasts 1 / ks of a round (+ a small epilogue over those rows) instead of a
+// whole one.  Only single-column tilings (Cout <= 256), bf16 in / bf16 out, no fused statistics.  -> {first tail M tile, ks}; ks 0 = none.
+struct TailSplit { int tile0, ks; };
+static TailSplit conv_tail_split(long long M, int cout, int cin, int taps, int elem_bytes, const Knobs &kn) {
+  TailSplit none{0, 0};
+  if (elem_bytes != 2 || !kn.glds || kn.kb != 128 || !kn.big_split || cout > 256 || cout < 256 || (cin * 2) % 128 != 0) return none;
+  const long long tiles = cdiv64(M, 256);
+  const long long rem = tiles % 256;
+  if (tiles <= 256 || rem == 0 || rem > 128) return none;
+  const int nk = taps * (cin / 64);
+  int ks = (int)(256 / rem);
+  if (ks > 8) ks = 8;
+  while (ks > 1 && nk / ks < 8) --ks;
+  if (ks < 2) return none;
+  const int per = (nk + ks - 1) / ks;
+  ks = (nk + per - 1) / per;                 // no empty slice
+  return ks >= 2 ? TailSplit{(int)(tiles - rem), ks} : none;
+}
+
 template <typename K>
 static int launch_igemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const ConvArgs &a) {
   if (lds > 64 * 1024) NRPN_LDS(kernel, (int)lds);
@@ -1341,6 +1380,11 @@ static int launch_conv(const ConvArgs &a, bool out_f32, hipStream_t st, const Kn
     if (!staged) return nrpn_fail(NRPN_ERR_ARG, "conv3d_fwd_stats: this shape does not run a kernel with fused statistics (ask nrpn_conv3d_fwd_stats_rows first)");
   }
   dim3 grid((unsigned)(cdiv64(a.M, bm) * ((a.Cout + (huge ? 256 : bn) - 1) / (huge ? 256 : bn)) * (a.ksplit > 1 ? a.ksplit : 1)));
+  if (a.tail_ks > 1) {
+    if (kind != 1) return nrpn_fail(NRPN_ERR_ARG, "conv3d_fwd: internal: tail split planned for a shape that does not run the 256x256 tile");
+    const long long mt = cdiv64(a.M, 256), nt = (a.Cout + 255) / 256;
+    grid = dim3((unsigned)(a.tail_tile0 * nt + (mt - a.tail_tile0) * nt * a.tail_ks));
+  }
   int rc = 0;
 #define NRPN_LC(BN_, OF_, KB_)                                                                                                    \
   do {                                                                                                                           \
@@ -1407,7 +1451,12 @@ static size_t fwd_workspace_bytes(long long M, int cin, int cout, int ksize, int
   const int bs = conv_big_split(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, kn);
   if (bs) return (size_t)bs * M * cout * 4;
   const int s = conv_ksplit(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, kn);
-  return s > 1 ? (size_t)s * M * cout * 4 : 0;
+  if (s > 1) return (size_t)s * M * cout * 4;
+  if (conv_tile_kind(M, cout, cin, dtype == NRPN_F32 ? 4 : 2, false, false, kn) == 1) {
+    const TailSplit t = conv_tail_split(M, cout, cin, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2, kn);
+    if (t.ks > 1) return (size_t)t.ks * (M - (long long)t.tile0 * 256) * cout * 4;
+  }
+  return 0;
 }
 extern "C" size_t nrpn_conv3d_fwd_workspace_bytes(int n, int gx, int gy, int gz, int cin, int cout, int ksize, int dtype) {
   return fwd_workspace_bytes((long long)n * gx * gy * gz, cin, cout, ksize, dtype, resolve_knobs(nullptr), Grid{n, gx, gy, gz});
@@ -1474,7 +1523,21 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
     if (a.ksplit > 1) a.ws = reinterpret_cast<float *>(workspace);
   }
   const int nsl = a.ksplit;
+  if (a.ksplit <= 1 && workspace && !segs && !stats && !out_f32 && dtype == NRPN_BF16 && conv_tile_kind(a.M, cout, cin, es, false, false, kn) == 1) {
+    const TailSplit t = conv_tail_split(a.M, cout, cin, a.taps, es, kn);
+    if (t.ks > 1) { a.tail_tile0 = t.tile0; a.tail_ks = t.ks; a.ws = reinterpret_cast<float *>(workspace); }
+  }
   int rc = (dtype == NRPN_F32) ? launch_conv<float, 0>(a, true, st, kn) : launch_conv<bf16s, 0>(a, out_f32, st, kn);
+  if (!rc && a.tail_ks > 1) {      // bias / scale / ReLU / mask / cast of the tail rows, from their K-slice partials
+    const long long row0 = (long long)a.tail_tile0 * 256, total = (a.M - row0) * cout;
+    const int blocks = (int)min((long long)2048, (total + 255) / 256);
+    const float *b = (flags & NRPN_CONV_BIAS) ? bias : nullptr;
+    const bf16s *mk = a.mask ? reinterpret_cast<const bf16s *>(a.mask) + row0 * cout : nullptr;
+    hipLaunchKernelGGL((splitk_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, reinterpret_cast<bf16s *>(y) + row0 * cout, total, cout,
+                       (flags & NRPN_CONV_RELU) ? 1 : 0, a.tail_ks, mk, a.scale);
+    NRPN_LAUNCH_CHECK("splitk_epilogue (tail)");
+    return NRPN_OK;
+  }
   if (rc || a.ksplit <= 1) return rc;
   const long long total = a.M * cout;
   const int blocks = (int)min((long long)4096, (total + 255) / 256);

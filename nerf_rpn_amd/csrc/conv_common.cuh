@@ -128,6 +128,8 @@ struct ConvArgs {
   float *ws;          // [ksplit][M][Cout] fp32 partials (plain stores, summed in slice order by splitk_epilogue_kernel: deterministic)
   int slices;         // 1: the K slices run on the 256x256 kernel (mid-size grids, conv_big_split); 0: on the 128-row kernel
   Segs segs;          // MODE 0 only: ragged voxel list (n > 0) instead of N copies of X*Y*Z
+  int tail_tile0, tail_ks;   // conv_igemm_big_kernel: tail_ks > 1 = the M tiles from tail_tile0 on run on tail_ks K slices (partials for rows >=
+                             // tail_tile0 * 256 in ws), the tiles before them whole; 0 = off
   const unsigned *rows;   // row-list form (conv_igemm_kernel<..., ROWS = true> only): [M][2] u32 = {voxel id, tap word}, see csrc/cone.hip
   float *stats;       // optional (bf16 staged epilogues only): per row-group partial BatchNorm statistics [P][2][Cout] = (sum, sum of squares)
                       // of the STORED (bf16-rounded) outputs; row group = the rows one wave row covers (see nrpn_conv3d_fwd_stats_rows)

@@ -215,7 +215,10 @@ def test_layout_roundtrip_and_adamw(dev):
 # (case, forward plan, dgrad plan, wgrad plan): nrpn_conv3d_fwd_plan codes 1 = 256x256 tile, 2 = 256x256 tile on K slices, 0 = 128-row tile, 7 = halo form
 BIG_CASES = [((1, (40, 40, 40), 256, 256, 3), 7, 7, 1),      # the dominant launch of the bench step itself: halo form (plan 7) for forward AND dgrad, against
                                                            # torch fp32 on the CPU (it used to meet an independent reference only on <= 8000 voxels)
-             ((1, (40, 40, 33), 256, 256, 3), 1, 1, 1), ((1, (20, 20, 20), 512, 512, 3), 2, 2, 1), ((1, (20, 20, 20), 256, 512, 3), 2, 3, 1),
+             ((1, (40, 40, 33), 256, 256, 3), 1, 1, 1),
+             # 323 tiles of 256 rows = one round of the chip + 67: the last 67 M tiles run on 3 K slices (conv_tail_split), the first 256 whole --
+             # the level-0 maps of the reference's eval benchmark shape (200 x 200 x 130), forward and dgrad
+             ((1, (50, 50, 33), 256, 256, 3), 1, 1, 1), ((1, (20, 20, 20), 512, 512, 3), 2, 2, 1), ((1, (20, 20, 20), 256, 512, 3), 2, 3, 1),
              ((1, (24, 20, 18), 320, 256, 3), 0, 2, 1), ((2, (40, 30, 30), 128, 256, 1), 1, 0, 0)]
 
 
