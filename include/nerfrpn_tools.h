@@ -32,6 +32,8 @@ int nrpn_set_wgrad_big_tile(int on);
 int nrpn_set_wgrad_transpose_read(int on);
 /* row-list conv (nrpn_conv3d_fwd_rows): 1 = lists of >= 96 tiles of 256 rows run the 256x256 tile (measured 0.4 % slower: kept for A/B), 0 (default) = 128-row tiles */
 int nrpn_set_rows_big_tile(int on);
+/* row-list conv: 1 (default) = the M tiles of a short last round (tiles = k x 512 slots + a remainder <= 256) run on K slices, 0 = whole */
+int nrpn_set_rows_tail_split(int on);
 /* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
 int nrpn_set_window_attn_mfma(int on);
 

@@ -33,8 +33,26 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const unsigned ntiles = (p.Cout + BN - 1) / BN;
   const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * ntiles;
-  const unsigned zsplit = blockIdx.x / tiles;                      // split-K slice (0 when ksplit == 1)
-  const unsigned tile = xcd_remap(blockIdx.x - zsplit * tiles, tiles);
+  // whole tiles, every tile on `ksplit` K slices, or (tail_ks > 1) only the M tiles from tail_tile0 on -- the short last round of a launch
+  // that needs a little more than a whole number of rounds of the chip -- on tail_ks slices (see conv_igemm_big_kernel)
+  unsigned zsplit, tile;
+  int my_ks = p.ksplit > 1 ? p.ksplit : 1;
+  long long part_row0 = 0;
+  if (p.tail_ks > 1) {
+    const unsigned full = (unsigned)p.tail_tile0 * ntiles;
+    if (blockIdx.x < full) {
+      zsplit = 0; my_ks = 1;
+      tile = xcd_remap(blockIdx.x, full);
+    } else {
+      const unsigned t = blockIdx.x - full, ntail = tiles - full;
+      zsplit = t / ntail; my_ks = p.tail_ks;
+      tile = full + t % ntail;
+      part_row0 = (long long)p.tail_tile0 * BM;
+    }
+  } else {
+    zsplit = blockIdx.x / tiles;                                   // split-K slice (0 when ksplit == 1)
+    tile = xcd_remap(blockIdx.x - zsplit * tiles, tiles);
+  }
   const long long m0 = (long long)(tile / ntiles) * BM;
   const int n0 = (int)(tile % ntiles) * BN;
   const int lr = tid / PPR, ls = tid % PPR;
@@ -103,8 +121,8 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
 
   // split-K: this workgroup runs K-steps [ks_begin, ks_end)
   int ks_begin = 0, ks_end = nk;
-  if (p.ksplit > 1) {   // the launcher trims ksplit so that no slice is empty (every partial is fully written)
-    const int per = (nk + p.ksplit - 1) / p.ksplit;
+  if (my_ks > 1) {   // the launcher trims the slice count so that no slice is empty (every partial is fully written)
+    const int per = (nk + my_ks - 1) / my_ks;
     ks_begin = zsplit * per;
     ks_end = min(nk, ks_begin + per);
   }
@@ -286,9 +304,9 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     }
   }
 
-  if (p.ksplit > 1) {   // fp32 partial of this K slice, plain stores (deterministic); the slices are summed in order, then bias /
-                        // ReLU / cast, by splitk_epilogue_kernel
-    float *wsz = p.ws + (long long)zsplit * p.M * p.Cout;
+  if (my_ks > 1) {   // fp32 partial of this K slice, plain stores (deterministic); the slices are summed in order, then bias /
+                     // ReLU / cast, by splitk_epilogue_kernel / rows_epilogue_kernel
+    float *wsz = p.ws + (long long)zsplit * (p.M - part_row0) * p.Cout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + fr;
@@ -298,7 +316,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long long v = m0 + (wm * TM + i) * 32 + frag_row(r, lane);
-          if (v < p.M) wsz[v * p.Cout + col] = acc[i][j][r];
+          if (v < p.M) wsz[(v - part_row0) * p.Cout + col] = acc[i][j][r];
         }
     }
     return;
@@ -1640,9 +1658,32 @@ static int rows_ksplit(long long nrows, int cin, int cout, int taps, int es) {
   s = (nk + per - 1) / per;                  // no empty slice
   return s < 2 ? 1 : (int)s;
 }
+// Long lists: the 128-row tiling of the S3 cone is a little more than one round of the chip's 512 workgroup slots (33-35 k rows x 2 column
+// tiles = 518-552 workgroups), i.e. two rounds in time.  The M tiles of the short last round run on K slices (cf. conv_tail_split).
+static std::atomic<int> g_rows_tail{1};     // tools-only A/B switch
+extern "C" int nrpn_set_rows_tail_split(int on) { g_rows_tail = on ? 1 : 0; return NRPN_OK; }
+static TailSplit rows_tail_split(long long nrows, int cin, int cout, int taps, int es) {
+  TailSplit none{0, 0};
+  if (!g_rows_tail.load(std::memory_order_relaxed)) return none;
+  const long long mt = cdiv64(nrows, 128), nt = (cout + 127) / 128, tiles = mt * nt;
+  const long long rem = tiles % 512;
+  if (tiles <= 512 || rem == 0 || rem > 256) return none;
+  const long long tail_mt = (rem + nt - 1) / nt;
+  const int nk = taps * (cin * es / 128);
+  int ks = (int)(512 / (tail_mt * nt));
+  if (ks > 8) ks = 8;
+  while (ks > 1 && nk / ks < 6) --ks;
+  if (ks < 2) return none;
+  const int per = (nk + ks - 1) / ks;
+  ks = (nk + per - 1) / per;
+  return ks >= 2 ? TailSplit{(int)(mt - tail_mt), ks} : none;
+}
 extern "C" size_t nrpn_conv3d_fwd_rows_workspace_bytes(int64_t nrows, int cin, int cout, int ksize, int dtype) {
-  const int s = rows_ksplit(nrows, cin, cout, ksize == 3 ? 27 : 1, dtype == NRPN_F32 ? 4 : 2);
-  return s > 1 ? (size_t)s * nrows * cout * 4 : 0;
+  const int es = dtype == NRPN_F32 ? 4 : 2, taps = ksize == 3 ? 27 : 1;
+  const int s = rows_ksplit(nrows, cin, cout, taps, es);
+  if (s > 1) return (size_t)s * nrows * cout * 4;
+  const TailSplit t = rows_tail_split(nrows, cin, cout, taps, es);
+  return t.ks > 1 ? (size_t)t.ks * (nrows - (long long)t.tile0 * 128) * cout * 4 : 0;
 }
 
 extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *bias, void *y, const uint32_t *rows, int64_t nrows, int nseg,
@@ -1680,6 +1721,14 @@ extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *
     return NRPN_OK;
   }
   dim3 grid((unsigned)(cdiv64(nrows, 128) * ((cout + 127) / 128) * ks));
+  if (ks == 1 && workspace) {
+    const TailSplit t = rows_tail_split(nrows, cin, cout, a.taps, es);
+    if (t.ks > 1) {
+      a.tail_tile0 = t.tile0; a.tail_ks = t.ks; a.ws = reinterpret_cast<float *>(workspace);
+      const long long mt = cdiv64(nrows, 128), nt = (cout + 127) / 128;
+      grid = dim3((unsigned)(t.tile0 * nt + (mt - t.tile0) * nt * t.ks));
+    }
+  }
   const size_t lds_ = 2 * (size_t)(128 + 128) * 128;
   int rc;
   if (dtype == NRPN_F32) rc = launch_igemm(conv_igemm_kernel<float, 128, 0, true, 128, true, 128, true>, grid, lds_, st, a);
@@ -1687,14 +1736,17 @@ extern "C" int nrpn_conv3d_fwd_rows(const void *x, const void *wp, const float *
   else rc = launch_igemm(conv_igemm_kernel<bf16s, 128, 0, false, 128, true, 128, true>, grid, lds_, st, a);
   if (rc) return rc;
   NRPN_LAUNCH_CHECK("conv3d_fwd_rows");
-  if (ks > 1) {
-    const long long total = nrows * cout;
+  if (ks > 1 || a.tail_ks > 1) {
+    const long long row0 = a.tail_ks > 1 ? (long long)a.tail_tile0 * 128 : 0;      // the partials cover the rows from row0 on
+    const int nsl = a.tail_ks > 1 ? a.tail_ks : ks;
+    const long long total = (nrows - row0) * cout;
     const int blocks = (int)min((long long)2048, (total + 255) / 256);
     const float *b = (flags & NRPN_CONV_BIAS) ? bias : nullptr;
     const int relu = (flags & NRPN_CONV_RELU) ? 1 : 0;
-    if (dtype == NRPN_F32) hipLaunchKernelGGL((rows_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, ks, (const float *)relu_mask, rows);
-    else if (out_f32) hipLaunchKernelGGL((rows_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, ks, (const bf16s *)relu_mask, rows);
-    else hipLaunchKernelGGL((rows_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, ks, (const bf16s *)relu_mask, rows);
+    const uint32_t *rw = rows + 2 * row0;
+    if (dtype == NRPN_F32) hipLaunchKernelGGL((rows_epilogue_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const float *)relu_mask, rw);
+    else if (out_f32) hipLaunchKernelGGL((rows_epilogue_kernel<bf16s, true>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)relu_mask, rw);
+    else hipLaunchKernelGGL((rows_epilogue_kernel<bf16s, false>), dim3(blocks), dim3(256), 0, st, a.ws, b, y, total, cout, relu, nsl, (const bf16s *)relu_mask, rw);
     NRPN_LAUNCH_CHECK("rows_epilogue");
   }
   return NRPN_OK;
