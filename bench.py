@@ -525,9 +525,10 @@ def main():
 
     # host side of a step (never part of `value`): C-ABI crossings per step and the time the host needs to enqueue one step when the GPU is
     # idle at its start (synchronise, then time until step() returns) -- the step is host-bound once this exceeds the GPU time
+    # (every rank runs these steps -- a step holds the gradient exchange's collectives -- rank 0 reports its own figures)
     host = None
-    if rank == 0:
-        from nerf_rpn_amd import lib as _lib, ops as _opsh
+    if True:
+        from nerf_rpn_amd import ops as _opsh
         cnt = [0]
         orig_call = _opsh.call
 
@@ -538,6 +539,8 @@ def main():
         enq = []
         for _ in range(6):
             torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
             th = time.perf_counter()
             step()
             enq.append(time.perf_counter() - th)
