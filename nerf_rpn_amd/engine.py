@@ -268,6 +268,9 @@ class FlatTrainer:
                 self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
                 self._exchange(b, g)
+                # an RCCL work handle's wait() orders the launch stream behind the collective without blocking the host, so the later phases
+                # of the multi-phase modes (reduce + all-gather) are enqueued right away and overlap backward as the first phase does
+                self._run_continuations()
         else:
             self._exchange(b, g)
 
@@ -327,22 +330,25 @@ class FlatTrainer:
             self.early = [self.static_graph and all(self.expected[j] > 0 for j in members) for members in self.bucket_params]
         self.seen = [0] * len(self.params)
 
+    def _run_continuations(self):
+        pending = list(self.finish)
+        self.finish = []
+        while pending:
+            nxt = []
+            for fn in pending:
+                r = fn()
+                if callable(r):
+                    nxt.append(r)
+                elif r is not None:
+                    self.handles.append(r)
+            pending = nxt
+
     def _finish_exchange(self):
         """Run the continuations of the multi-phase modes, wait for every handle, join the launch stream."""
         cuda = self.g_arena.is_cuda
         ctx = torch.cuda.stream(self._comm_stream) if (cuda and self._comm_stream is not None) else _null()
-        with ctx:                                           # multi-phase modes continue on the launch stream
-            pending = list(self.finish)
-            self.finish = []
-            while pending:
-                nxt = []
-                for fn in pending:
-                    r = fn()
-                    if callable(r):
-                        nxt.append(r)
-                    elif r is not None:
-                        self.handles.append(r)
-                pending = nxt
+        with ctx:                                           # multi-phase modes continue on the launch stream (gloo: wait() blocks the host, so only here)
+            self._run_continuations()
         for h in self.handles:
             h.wait()
         if cuda and self._comm_stream is not None:
