@@ -379,7 +379,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 step, eval protocol, 2 scenes per GPU)")
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="per-rank batch of the TIMED region (1 = the BASELINE metric; 2 = the reference's train.sh setting)")
     ap.add_argument("--exchange", default=None, choices=["auto", "allreduce", "rs_ag", "a2a_bf16"],
-                    help="gradient exchange of the trainer (N > 1); default auto = chosen from the comm-only measurement at start-up")
+                    help="gradient exchange of the trainer (N > 1); default auto = the fastest fp32 mode of the comm-only measurement at start-up")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="backbone + FPN forward / backward as captured HIP graphs (nerf_rpn_amd/graphs.py): auto = for the Swin-S backbone, whose "
                          "eager step is bound by the host's enqueue rate; the VGG19 step (the BASELINE metric) and the ResNet-50 step are GPU-bound and stay eager")
@@ -504,7 +504,7 @@ def main():
         # comm-only arm: every exchange mode x bucket size on the real arena with no compute in flight (the start-up measurement of
         # exchange='auto', or taken here when a mode was forced), next to the wait the training steps actually saw
         table = trainer.exchange_table or trainer.measure_exchange()
-        exch = {"mode": trainer.exchange, "mode_chosen_by": "comm-only measurement at start-up" if trainer.exchange_table else "--exchange / NRPN_GRAD_EXCHANGE",
+        exch = {"mode": trainer.exchange, "mode_chosen_by": "comm-only measurement at start-up (fastest fp32 mode; a2a_bf16 is timed but only ever forced)" if trainer.exchange_table else "--exchange / NRPN_GRAD_EXCHANGE",
                 "comm_only_ms": {f"{m}@{mib}MiB": v for (m, mib), v in sorted(table.items())},
                 "buckets": len(trainer.buckets), "bucket_mib": [round((e - s_) * 4 / 2 ** 20, 1) for s_, e in trainer.buckets],
                 "bytes_per_step_per_rank": int(trainer.g_arena.numel() * 4),

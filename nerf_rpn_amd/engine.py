@@ -46,7 +46,9 @@ def one_cycle(step, total_steps, max_lr, pct_start=0.3, div_factor=25.0, final_d
     return cos(max_lr, minimum, pct), cos(base_momentum, max_momentum, pct)
 
 
-EXCHANGE_MODES = ("allreduce", "rs_ag", "a2a_bf16")     # + "auto": measured at start-up (FlatTrainer.measure_exchange), fastest wins
+EXCHANGE_MODES = ("allreduce", "rs_ag", "a2a_bf16")     # + "auto": measured at start-up (FlatTrainer.measure_exchange), fastest of AUTO_MODES wins
+AUTO_MODES = ("allreduce", "rs_ag")     # what "auto" may pick: the fp32 exchanges (the reference's DDP all-reduce is fp32).  a2a_bf16 rounds the
+                                        # travelling chunks to bf16: it is timed and reported with the others but only ever chosen explicitly
 
 
 class _null:
@@ -159,10 +161,11 @@ class FlatTrainer:
         self._streams = {}                # raw handle -> torch stream of every stream gradients are produced on
         if self.exchange == "auto":
             # the mode (and bucket size) is chosen from a comm-only measurement on the real arena -- every rank takes part and all agree
-            # on the result (MAX over ranks) -- instead of assuming what the node's xGMI topology prefers
+            # on the result (MAX over ranks) -- instead of assuming what the node's xGMI topology prefers; only the fp32 modes are candidates
             if self.exchanging:
                 self.exchange_table = self.measure_exchange()
-                best = min(self.exchange_table, key=lambda k: self.exchange_table[k])
+                lossless = [k for k in self.exchange_table if k[0] in AUTO_MODES]
+                best = min(lossless, key=lambda k: self.exchange_table[k])
                 self.exchange = best[0]
                 self._build_buckets(best[1] << 20)
             else:
