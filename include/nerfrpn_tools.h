@@ -34,6 +34,8 @@ int nrpn_set_wgrad_transpose_read(int on);
 int nrpn_set_rows_big_tile(int on);
 /* row-list conv: 1 (default) = the M tiles of a short last round (tiles = k x 512 slots + a remainder <= 256) run on K slices, 0 = whole */
 int nrpn_set_rows_tail_split(int on);
+/* BatchNorm apply / backward-apply: 1 (default) = the hoisted-parameter kernels with 16-byte accesses, 0 = the general grid-stride kernels (A/B) */
+int nrpn_set_bn_fast(int on);
 /* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
 int nrpn_set_window_attn_mfma(int on);
 

@@ -42,12 +42,10 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // bf16 <-> f32 on raw 16-bit storage (round-to-nearest-even), usable in device code.
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+// Round-to-nearest-even on the conversion unit (fptrunc -> v_cvt_pk_bf16_f32 on gfx950): one instruction instead of the ~7 VALU
+// instructions of the integer formulation (add 0x7fff + lsb, NaN test, shift), on every bf16 output element of every kernel.  Same
+// result for every non-NaN input (the kernels keep fp32 denormals: float_denorm_mode_32 = 3); NaNs come out quiet.
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
 template <typename T> struct elem;
 template <> struct elem<float> {

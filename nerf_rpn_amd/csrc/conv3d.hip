@@ -2650,6 +2650,14 @@ __global__ void __launch_bounds__(256, 2) stem_wgrad_zrow_kernel(const StemZrArg
   const unsigned a_step = (unsigned)(KV * COUT * (int)sizeof(T));
   const int b_row = tid / BPR, b_slot = (tid % BPR) ^ zr_swz<RSB>(tid / BPR);   // X-row piece of this lane (logical slot; the same for every dy tap)
   constexpr int ZPP = 16 / (4 * (int)sizeof(T));                // z positions per 16-byte piece: 2 (bf16) / 1 (fp32)
+  // Output voxel of this lane's X-row piece, v = chunk * KV + b_row: decomposed ONCE and advanced by KV per chunk.  (Three 64-bit
+  // divisions per lane and chunk were ~350 VALU instructions next to the chunk's 16 MFMAs: the kernel was issue-bound on index arithmetic.)
+  long long b_v = c_begin * KV + b_row;
+  int b_oz, b_oy, b_ox, b_nb;
+  {
+    const long long q1 = b_v / p.OZ, q2 = q1 / p.OY, q3 = q2 / p.OX;
+    b_oz = (int)(b_v - q1 * p.OZ); b_oy = (int)(q1 - q2 * p.OY); b_ox = (int)(q2 - q3 * p.OX); b_nb = (int)q3;
+  }
 
   auto issue = [&](int buf, long long ch) {
     char *A = lds + buf * BUF;
@@ -2660,25 +2668,27 @@ __global__ void __launch_bounds__(256, 2) stem_wgrad_zrow_kernel(const StemZrArg
       lds_dma16(dyr, A + (64 * wave_u + 256 * i) * 16, v < p.M ? a_voff[i] : kOOB);
       a_voff[i] += a_step;
     }
-    const long long v = ch * KV + b_row;
-    const bool vok = v < p.M;
-    const long long vv = vok ? v : 0;
-    const int oz = (int)(vv % p.OZ);
-    const long long t1 = vv / p.OZ;
-    const int oy = (int)(t1 % p.OY);
-    const long long t2 = t1 / p.OY;
-    const int ox = (int)(t2 % p.OX);
-    const long long nb = t2 / p.OX;
-    const int ix = 2 * ox - 3 + dx;
-    const int zp = 2 * oz - 4 + b_slot * ZPP;                   // first z of this piece (ZPP z positions, never straddling the border: Z even)
+    // (issue() is called for consecutive chunks, starting at c_begin: b_v / b_oz.. are this chunk's, then advance)
+    const bool vok = b_v < p.M;
+    const int ix = 2 * b_ox - 3 + dx;
+    const int zp = 2 * b_oz - 4 + b_slot * ZPP;                 // first z of this piece (ZPP z positions, never straddling the border: Z even)
     const bool ok0 = vok && (unsigned)ix < (unsigned)p.X && zp >= 0 && zp + ZPP <= p.Z;
-    const long long rowbase = ((nb * p.X + ix) * p.Y) * (long long)p.Z;
+    const int rowbase = ((b_nb * p.X + ix) * p.Y) * p.Z;        // voxel index: fits 32 bits (x_bytes is a 32-bit buffer size); unused when !ok0
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
-      const int iy = 2 * oy - 3 + t;
+      const int iy = 2 * b_oy - 3 + t;
       const bool ok = ok0 && (unsigned)iy < (unsigned)p.Y;
-      const unsigned off = ok ? (unsigned)(((rowbase + (long long)iy * p.Z + zp) * 4) * (long long)sizeof(T)) : kOOB;
+      const unsigned off = ok ? (unsigned)(rowbase + iy * p.Z + zp) * (unsigned)(4 * sizeof(T)) : kOOB;
       lds_dma16(xr, B + t * B_BYTES + 64 * wave_u * 16, off);
+    }
+    b_v += KV;
+    b_oz += KV;
+    while (b_oz >= p.OZ) {
+      b_oz -= p.OZ;
+      if (++b_oy == p.OY) {
+        b_oy = 0;
+        if (++b_ox == p.OX) { b_ox = 0; ++b_nb; }
+      }
     }
   };
 
@@ -2769,8 +2779,13 @@ __global__ void unpack_stem_zrow_kernel(const float *__restrict__ gp, int cout, 
   const int tap = (int)(i % 343), c = (int)((i / 343) % 4), o = (int)(i / (343 * 4));
   const int dz = tap % 7, dxy = tap / 7;
   const float *src = gp + ((long long)dxy * cout + o) * 32 + (dz + 1) * 4 + c;
-  float v = 0.f;
-  for (int s = 0; s < slices; ++s) v += src[(long long)s * 49 * cout * 32];
+  // four independent chains (fixed order: deterministic): the loop is latency-bound, 73 slices x one strided float per thread
+  const long long st = (long long)49 * cout * 32;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int s = 0;
+  for (; s + 3 < slices; s += 4) { v0 += src[s * st]; v1 += src[(s + 1) * st]; v2 += src[(s + 2) * st]; v3 += src[(s + 3) * st]; }
+  for (; s < slices; ++s) v0 += src[s * st];
+  const float v = (v0 + v1) + (v2 + v3);
   gw[i] = accumulate ? gw[i] + v : v;
 }
 
@@ -2788,8 +2803,15 @@ static int stem_zrow_slices(long long M, int elem_bytes) {
 __global__ void bias_finalize_kernel(const float *__restrict__ part, int slices, int wrows, int cout, float *__restrict__ gbias, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cout) return;
-  float s = 0.f;
-  for (int k = 0; k < slices; ++k) s += part[(long long)k * wrows + c];
+  // eight independent chains in a fixed order (deterministic): one float per slice and lane, the serial loop over 73 stem slices was 26 us
+  // of pure load latency at the tail of backward
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 7 < slices; k += 8)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += part[(long long)(k + u) * wrows + c];
+  for (; k < slices; ++k) a[0] += part[(long long)k * wrows + c];
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   gbias[c] = accumulate ? gbias[c] + s : s;
 }
 

@@ -6,11 +6,15 @@
 // Replaces BatchNorm3d / ReLU / MaxPool3d / F.interpolate+add in reference feature_extractor.py:337-358, fpn.py:150-155
 // and clip_grad_norm_ + AdamW of run_rpn.py:345-349,390-395.
 #include "common.h"
+#include <atomic>
 
 typedef unsigned short bf16s;
 typedef __attribute__((ext_vector_type(4))) float f4;
 typedef __attribute__((ext_vector_type(4))) unsigned short us4;
 
+// bf16 stores of this file round on the conversion unit (fptrunc -> v_cvt_pk_bf16_f32, two values per instruction) instead of common.h's
+// integer routine (~7 VALU instructions per value): the same round-to-nearest-even result for every non-NaN input (these kernels keep
+// fp32 denormals), and the companions are VALU-, not bandwidth-limited when they share the chip with the weight-gradient stream.
 template <typename T> struct vec4;
 template <> struct vec4<float> {
   static __device__ __forceinline__ f4 ld(const float *p) { return *reinterpret_cast<const f4 *>(p); }
@@ -23,8 +27,30 @@ template <> struct vec4<bf16s> {
     return v;
   }
   static __device__ __forceinline__ void st(bf16s *p, f4 v) {
-    us4 u = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
-    *reinterpret_cast<us4 *>(p) = u;
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    *reinterpret_cast<us4 *>(p) = __builtin_bit_cast(us4, __builtin_convertvector(v, b4));      // v_cvt_pk_bf16_f32, see below
+  }
+};
+
+// V consecutive channels per thread: 4 (8 / 16-byte accesses) or, for bf16 with C % 8 == 0, 8 (16-byte accesses): half the
+// instructions per byte on kernels that are issue-bound (27 window positions per output of the 3/2/1 pool)
+template <typename T, int V> struct vecv;
+template <typename T> struct vecv<T, 4> {
+  static __device__ __forceinline__ void ld(const T *p, float *o) { const f4 v = vec4<T>::ld(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+  static __device__ __forceinline__ void st(T *p, const float *o) { vec4<T>::st(p, f4{o[0], o[1], o[2], o[3]}); }
+};
+template <> struct vecv<bf16s, 8> {
+  typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+  static __device__ __forceinline__ void ld(const bf16s *p, float *o) {
+    const us8 u = *reinterpret_cast<const us8 *>(p);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = bf16_bits_to_f32(u[q]);
+  }
+  static __device__ __forceinline__ void st(bf16s *p, const float *o) {
+    typedef __attribute__((ext_vector_type(8))) float f8;
+    typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+    const f8 v = {o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+    *reinterpret_cast<us8 *>(p) = __builtin_bit_cast(us8, __builtin_convertvector(v, b8));
   }
 };
 
@@ -220,13 +246,117 @@ __global__ void bn_apply_kernel(const T *__restrict__ x, T *__restrict__ y, long
 
 static inline int ew_blocks(long long work) { long long b = (work + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
+// Fast forms of bn_apply / bn_bwd_apply.  V channels per lane in 16-byte accesses (8 bf16 / 4 fp32) and a grid stride that is a multiple
+// of C / V: a lane then meets the SAME channels in every iteration, so the per-channel parameters, the rsqrt and the 64-bit "g % (C / V)"
+// leave the loop, whose body is the loads plus a handful of VALU operations per element.  These kernels run next to the weight-gradient
+// stream's MFMA kernels (3x their stand-alone time there): every VALU slot they take is one the MFMA waves wait for.  The arithmetic is
+// the expression of the general kernels, term for term (the ReLU mask recomputed in backward has to agree with what forward wrote).
+// Launch condition (bn_fast_v): 256 % (C / V) == 0, i.e. C / V a power of two <= 256 -- every BatchNorm of the three backbones.
+static std::atomic<int> g_bn_fast{1};      // tools-only A/B switch (nerfrpn_tools.h)
+extern "C" int nrpn_set_bn_fast(int on) { g_bn_fast = on ? 1 : 0; return NRPN_OK; }
+static inline int bn_fast_v(int c, int dtype) {
+  if (!g_bn_fast) return 0;
+  const int v = (dtype != NRPN_F32 && c % 8 == 0) ? 8 : 4;
+  const int ctv = c / v;
+  return (c % v == 0 && ctv > 0 && ctv <= 256 && 256 % ctv == 0) ? v : 0;
+}
+
+// V per-channel fp32 parameters as 16-byte loads (cg is a multiple of V >= 4 floats)
+template <int V>
+__device__ __forceinline__ void ld_params(const float *__restrict__ p, float *o) {
+#pragma unroll
+  for (int q = 0; q < V; q += 4) {
+    const f4 v = *reinterpret_cast<const f4 *>(p + q);
+    o[q] = v[0]; o[q + 1] = v[1]; o[q + 2] = v[2]; o[q + 3] = v[3];
+  }
+}
+
+// grid of the fast apply kernels: one group per lane up to one resident round of the chip (256 CUs x `per_cu` blocks at the kernel's register
+// count), beyond that more groups per lane -- every lane pays a prologue (parameters, V rsqrt), and a second round of blocks would only add a
+// tail.  The stride blocks * 256 is a multiple of every power of two <= 256.
+static inline int bn_fast_blocks(long long groups, int per_cu) {
+  const long long b = (groups + 255) / 256, cap = 256ll * per_cu;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) bn_apply_fast_kernel(const T *__restrict__ x, T *__restrict__ y, long long groups, int c,
+                                                            const float *__restrict__ mean, const float *__restrict__ var,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int relu) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int cg = ((int)g & (c / V - 1)) * V;              // C / V is a power of two dividing the stride: loop invariant
+  float mu[V], is[V], ga[V], be[V];
+  ld_params<V>(mean + cg, mu); ld_params<V>(var + cg, is); ld_params<V>(gamma + cg, ga); ld_params<V>(beta + cg, be);
+#pragma unroll
+  for (int k = 0; k < V; ++k) is[k] = 1.0f / sqrtf(is[k] + eps);
+#pragma unroll 2
+  for (; g < groups; g += stride) {
+    float xv[V], o[V];
+    vecv<T, V>::ld(x + g * V, xv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      o[k] = (xv[k] - mu[k]) * is[k] * ga[k] + be[k];
+      if (relu) o[k] = fmaxf(o[k], 0.f);
+    }
+    vecv<T, V>::st(y + g * V, o);
+  }
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
+                                                                T *__restrict__ dx, long long groups, int c, long long rows,
+                                                                const float *__restrict__ mean, const float *__restrict__ var,
+                                                                const float *__restrict__ gamma, float eps, int relu,
+                                                                const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+                                                                const float *__restrict__ beta) {
+  const float invr = 1.0f / (float)rows;
+  const long long stride = (long long)gridDim.x * 256;
+  long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int cg = ((int)g & (c / V - 1)) * V;
+  float mu[V], is[V], ga[V], dg[V], db[V], be[V];
+  ld_params<V>(mean + cg, mu); ld_params<V>(var + cg, is); ld_params<V>(gamma + cg, ga); ld_params<V>(dgamma + cg, dg); ld_params<V>(dbeta + cg, db);
+#pragma unroll
+  for (int k = 0; k < V; ++k) { is[k] = 1.0f / sqrtf(is[k] + eps); be[k] = 0.f; }
+  if (relu && beta) ld_params<V>(beta + cg, be);
+#pragma unroll 2
+  for (; g < groups; g += stride) {
+    float xv[V], gv[V], o[V];
+    vecv<T, V>::ld(x + g * V, xv);
+    vecv<T, V>::ld(dy + g * V, gv);
+    if (relu && !beta) {
+      float yv[V];
+      vecv<T, V>::ld(y + g * V, yv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      if (relu && beta && !(((xv[k] - mu[k]) * is[k] * ga[k] + be[k]) > 0.f)) gv[k] = 0.f;    // mask recomputed from x, y is not read
+      const float xh = (xv[k] - mu[k]) * is[k];
+      o[k] = ga[k] * is[k] * (gv[k] - db[k] * invr - xh * dg[k] * invr);
+    }
+    vecv<T, V>::st(dx + g * V, o);
+  }
+}
+
 extern "C" int nrpn_bn_apply(const void *x, void *y, int64_t rows, int c, int dtype, const float *mean, const float *var,
                              const float *gamma, const float *beta, float eps, int relu, nrpn_stream_t stream) {
   NRPN_REQUIRE(rows > 0 && c > 0 && c % 4 == 0, "bn_apply: C=%d must be a multiple of 4", c);
   NRPN_REQUIRE(x && y && mean && var && gamma && beta, "bn_apply: null pointer");
-  const long long groups = rows * (c / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y,
-                                       groups, c, mean, var, gamma, beta, eps, relu));
+  int fv = bn_fast_v(c, dtype);
+  if (fv == 8 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)) fv = 0;      // 16-byte accesses
+  const long long groups = rows * (c / (fv ? fv : 4));
+  if (fv == 8)
+    hipLaunchKernelGGL((bn_apply_fast_kernel<bf16s, 8>), dim3(bn_fast_blocks(groups, 8)), dim3(256), 0, as_stream(stream), (const bf16s *)x, (bf16s *)y,
+                       groups, c, mean, var, gamma, beta, eps, relu);
+  else if (fv == 4) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_fast_kernel<T, 4>), dim3(bn_fast_blocks(groups, 8)), dim3(256), 0, as_stream(stream), (const T *)x,
+                                         (T *)y, groups, c, mean, var, gamma, beta, eps, relu));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y,
+                                         groups, c, mean, var, gamma, beta, eps, relu));
+  }
   NRPN_LAUNCH_CHECK("bn_apply");
   return NRPN_OK;
 }
@@ -276,10 +406,23 @@ extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, vo
   DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
                                        (long long)rows, c, mean, var, eps, relu, (float *)workspace, kSlab, gamma, beta));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
-  const long long groups = rows * (c / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, st, (const T *)x, (const T *)y,
-                                       (const T *)dy, (T *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu,
-                                       (const float *)dgamma, (const float *)dbeta, beta));
+  int fv = bn_fast_v(c, dtype);
+  if (fv == 8 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15))
+    fv = 0;                                                                                                // 16-byte accesses
+  const long long groups = rows * (c / (fv ? fv : 4));
+  if (fv == 8)
+    hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<bf16s, 8>), dim3(bn_fast_blocks(groups, 5)), dim3(256), 0, st, (const bf16s *)x, (const bf16s *)y,
+                       (const bf16s *)dy, (bf16s *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu, (const float *)dgamma,
+                       (const float *)dbeta, beta);
+  else if (fv == 4) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T, 4>), dim3(bn_fast_blocks(groups, 8)), dim3(256), 0, st, (const T *)x, (const T *)y,
+                                         (const T *)dy, (T *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu,
+                                         (const float *)dgamma, (const float *)dbeta, beta));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(groups)), dim3(256), 0, st, (const T *)x, (const T *)y,
+                                         (const T *)dy, (T *)dx, groups, c, (long long)rows, mean, var, gamma, eps, relu,
+                                         (const float *)dgamma, (const float *)dbeta, beta));
+  }
   NRPN_LAUNCH_CHECK("bn_backward");
   return NRPN_OK;
 }
@@ -314,28 +457,6 @@ static inline int pool_out(int in, int k, int s, int p, int ceil_mode) {
   return o;
 }
 extern "C" int nrpn_pool_out_size(int in, int k, int s, int p, int ceil_mode) { return pool_out(in, k, s, p, ceil_mode); }
-
-// V consecutive channels per thread: 4 (8 / 16-byte accesses) or, for bf16 with C % 8 == 0, 8 (16-byte accesses): half the
-// instructions per byte on kernels that are issue-bound (27 window positions per output of the 3/2/1 pool)
-template <typename T, int V> struct vecv;
-template <typename T> struct vecv<T, 4> {
-  static __device__ __forceinline__ void ld(const T *p, float *o) { const f4 v = vec4<T>::ld(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
-  static __device__ __forceinline__ void st(T *p, const float *o) { vec4<T>::st(p, f4{o[0], o[1], o[2], o[3]}); }
-};
-template <> struct vecv<bf16s, 8> {
-  typedef __attribute__((ext_vector_type(8))) unsigned short us8;
-  static __device__ __forceinline__ void ld(const bf16s *p, float *o) {
-    const us8 u = *reinterpret_cast<const us8 *>(p);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = bf16_bits_to_f32(u[q]);
-  }
-  static __device__ __forceinline__ void st(bf16s *p, const float *o) {
-    us8 u;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = f32_to_bf16_bits(o[q]);
-    *reinterpret_cast<us8 *>(p) = u;
-  }
-};
 
 template <typename T, int V>
 __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int8_t *__restrict__ arg, int n, int gx, int gy, int gz, int ox,

@@ -111,15 +111,17 @@ def test_stem(stride, grid, dtype, dev):
     assert relerr(h.bias.grad.cpu(), conv.bias.grad) < tol
 
 
+# (128, small): 16 / 32 channel groups per row (8 bf16 / 4 fp32 channels per lane); (4, ...): one group per row, 8-byte bf16 accesses;
+# (64, 70 x 66 x 64): 2.4 M channel groups > one grid stride of the apply kernels (8192 blocks x 256 lanes), several iterations per lane
+@pytest.mark.parametrize("c,grid", [(128, (9, 7, 6)), (4, (5, 4, 3)), (64, (70, 66, 64))])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_batchnorm_relu(dtype, dev):
+def test_batchnorm_relu(dtype, c, grid, dev):
     from nerf_rpn_amd.model import hip_nn
     torch.manual_seed(0)
-    c = 128
     bn = nn.BatchNorm3d(c)
     bn.weight.data.uniform_(0.5, 1.5)
     bn.bias.data.normal_(0, 0.2)
-    x = torch.randn(2, c, 9, 7, 6) * 2 + 0.7
+    x = torch.randn(2 if grid[0] < 20 else 1, c, *grid) * 2 + 0.7
     if dtype == torch.bfloat16:
         x = x.bfloat16().float()
     xr = x.clone().requires_grad_(True)
