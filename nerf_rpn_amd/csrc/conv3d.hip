@@ -294,17 +294,19 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     load_step(ks_begin, ra0, rb0);
     store_step(0, ra0, rb0);
     __syncthreads();
-    while (ks < ks_end) {
-      if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+    for (; ks + 1 < ks_end; ks += 2) {        // pairs of K-steps, one loop exit (see the LDS-DMA pipeline above)
+      load_step(ks + 1, ra0, rb0);
       compute_step(0);
-      if (ks + 1 < ks_end) store_step(1, ra0, rb0);
+      store_step(1, ra0, rb0);
       __syncthreads();
-      if (++ks >= ks_end) break;
-      if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+      if (ks + 2 < ks_end) load_step(ks + 2, ra0, rb0);
       compute_step(1);
-      if (ks + 1 < ks_end) store_step(0, ra0, rb0);
+      if (ks + 2 < ks_end) store_step(0, ra0, rb0);
       __syncthreads();
-      ++ks;
+    }
+    if (ks < ks_end) {
+      compute_step(0);
+      __syncthreads();
     }
   }
 
