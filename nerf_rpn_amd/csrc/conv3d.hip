@@ -276,31 +276,37 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     // 2-buffer LDS-DMA pipeline: the DMA of step k+1 flies while step k is multiplied; __syncthreads() carries the vmcnt(0)
     issue_glds(0);
     __syncthreads();
-    while (ks < ks_end) {
-      if (ks + 1 < ks_end) issue_glds(1);
+    // pairs of K-steps with ONE exit at the top of the loop (an exit in the middle made the compiler keep the accumulators in two register
+    // sets and copy all 64 of them once per pair: 32 v_mov_b64 + s_nop bubbles behind the MFMAs, tools/isa_audit.py); the odd last step follows
+    for (; ks + 1 < ks_end; ks += 2) {
+      issue_glds(1);
       compute_step(0);
       __syncthreads();
-      if (++ks >= ks_end) break;
-      if (ks + 1 < ks_end) issue_glds(0);
+      if (ks + 2 < ks_end) issue_glds(0);
       compute_step(1);
       __syncthreads();
-      ++ks;
+    }
+    if (ks < ks_end) {
+      compute_step(0);
+      __syncthreads();
     }
   } else {
     load_step(ks_begin, ra0, rb0);
     store_step(0, ra0, rb0);
     __syncthreads();
-    while (ks < ks_end) {
-      if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+    for (; ks + 1 < ks_end; ks += 2) {        // pairs of K-steps, one loop exit (see the LDS-DMA pipeline above)
+      load_step(ks + 1, ra0, rb0);
       compute_step(0);
-      if (ks + 1 < ks_end) store_step(1, ra0, rb0);
+      store_step(1, ra0, rb0);
       __syncthreads();
-      if (++ks >= ks_end) break;
-      if (ks + 1 < ks_end) load_step(ks + 1, ra0, rb0);
+      if (ks + 2 < ks_end) load_step(ks + 2, ra0, rb0);
       compute_step(1);
-      if (ks + 1 < ks_end) store_step(0, ra0, rb0);
+      if (ks + 2 < ks_end) store_step(0, ra0, rb0);
       __syncthreads();
-      ++ks;
+    }
+    if (ks < ks_end) {
+      compute_step(0);
+      __syncthreads();
     }
   }
 
