@@ -81,6 +81,8 @@ class FlatTrainer:
         self.model = model
         self.static_graph = static_graph
         import os
+        import weakref
+        _graphs.SINK_GENERATION[0] += 1      # new arenas / sinks: trunk graphs captured under an earlier trainer are stale (graphs.GraphedBackbone)
         self.exchange = exchange or os.environ.get("NRPN_GRAD_EXCHANGE", "auto")
         if self.exchange not in EXCHANGE_MODES + ("auto",):
             raise ValueError(f"exchange must be one of {EXCHANGE_MODES + ('auto',)}, got {self.exchange!r}")
@@ -144,8 +146,12 @@ class FlatTrainer:
         # the second step on, a bucket's all-reduce is launched the moment its last expected notification arrives.
         self.expected = None
         self.seen = [0] * len(self.params)
+        me = weakref.ref(self)
+        self.index_of = {}
         for i, p in enumerate(self.params):
             p._nrpn_sink = ops.GradSink(p.grad, self._make_notify(i), self.flat_grad[i])
+            p._nrpn_trainer = me
+            self.index_of[id(p)] = i
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         self.buckets, self.bucket_params, self.bucket_of = [], [], {}
         self.handles = []
@@ -161,15 +167,28 @@ class FlatTrainer:
         self._streams = {}                # raw handle -> torch stream of every stream gradients are produced on
         if self.exchange == "auto":
             # the mode (and bucket size) is chosen from a comm-only measurement on the real arena -- every rank takes part and all agree
-            # on the result (MAX over ranks) -- instead of assuming what the node's xGMI topology prefers; only the fp32 modes are candidates
+            # on the result (MAX over ranks) -- instead of assuming what the node's xGMI topology prefers.  Only the candidates are timed
+            # (AUTO_MODES: the fp32 exchanges; bench.py times the full table), a mode whose collectives the backend lacks drops out instead
+            # of failing construction, and NRPN_GRAD_EXCHANGE / NRPN_GRAD_BUCKET_MIB pin the result: the winner of a wall-clock race can differ
+            # between runs, and mode / bucket size fix the fp32 summation order (run-to-run bit-reproducibility needs them pinned).
+            pinned_mib = os.environ.get("NRPN_GRAD_BUCKET_MIB")
             if self.exchanging:
-                self.exchange_table = self.measure_exchange()
-                lossless = [k for k in self.exchange_table if k[0] in AUTO_MODES]
-                best = min(lossless, key=lambda k: self.exchange_table[k])
+                sizes = (int(pinned_mib),) if pinned_mib else (16, 32, 64)
+                self.exchange_table = self.measure_exchange(modes=AUTO_MODES, bucket_mib=sizes)
+                if self.exchange_table:
+                    best = min(self.exchange_table, key=lambda k: self.exchange_table[k])
+                else:
+                    best = ("allreduce", bucket_bytes >> 20)
                 self.exchange = best[0]
                 self._build_buckets(best[1] << 20)
+                if (dist.get_rank(self.group) == 0) and os.environ.get("NRPN_QUIET") != "1":
+                    print(f"[nerf_rpn_amd] gradient exchange: {self.exchange} with {best[1]} MiB buckets "
+                          f"(comm-only ms: { {f'{m}@{b}': v for (m, b), v in sorted(self.exchange_table.items())} }); pin with "
+                          f"NRPN_GRAD_EXCHANGE={self.exchange} NRPN_GRAD_BUCKET_MIB={best[1]}", flush=True)
             else:
                 self.exchange = "allreduce"
+        elif self.exchanging and os.environ.get("NRPN_GRAD_BUCKET_MIB"):
+            self._build_buckets(int(os.environ["NRPN_GRAD_BUCKET_MIB"]) << 20)
 
     def _build_buckets(self, bucket_bytes):
         """Buckets of ~bucket_bytes in reverse parameter order (gradients arrive roughly back to front)."""
@@ -187,7 +206,29 @@ class FlatTrainer:
                 self.bucket_params.append(members)
                 end, members = o, []
         self.launched = [False] * len(self.buckets)
-        self.early = [False] * len(self.buckets)
+        # early launches survive a re-bucketing after the learning step (measure_exchange() from bench.py): recomputed from the learned counts
+        self.early = ([self.static_graph and all(self.expected[j] > 0 for j in members) for members in self.bucket_params]
+                      if getattr(self, "expected", None) is not None else [False] * len(self.buckets))
+
+    def trunk_gradients_ready(self, params):
+        """-> a callable for graphs._GraphedFn.backward: a replayed trunk backward runs no Python, so none of its parameters notifies; once the
+        replay is enqueued all of them are complete -- count them as arrived and launch the buckets that became ready, as the eager path's last
+        notification of a bucket does (with a captured trunk these buckets used to wait for sync_gradients)."""
+        idx = [self.index_of[id(p)] for p in params if id(p) in self.index_of]
+
+        def ready():
+            for i in idx:
+                self.seen[i] = self.expected[i] if (self.expected is not None and self.expected[i] > 0) else self.seen[i] + 1
+            if not (self.exchanging and self.expected is not None):
+                return
+            if self.g_arena.is_cuda:
+                h = ops._s()
+                if h not in self._streams:
+                    self._streams[h] = torch.cuda.current_stream(self.g_arena.device)
+            for b in sorted({self.bucket_of[i] for i in idx}):
+                if self.early[b] and not self.launched[b] and all(self.seen[j] >= self.expected[j] for j in self.bucket_params[b]):
+                    self._launch(b)
+        return ready
 
     def measure_exchange(self, modes=EXCHANGE_MODES, bucket_mib=(16, 32, 64), iters=3):
         """Comm-only timing of every exchange mode x bucket size on the real gradient arena (no compute in flight): {(mode, MiB): ms}, the
@@ -203,20 +244,31 @@ class FlatTrainer:
                 self.exchange = mode
                 self._build_buckets(mib << 20)
                 best = float("inf")
-                for it in range(iters + 1):          # first pass = warm-up (communicator / buffer set-up)
-                    if cuda:
-                        torch.cuda.synchronize()
-                    dist.barrier(group=self.group)
-                    t0 = time.perf_counter()
-                    for b in range(len(self.buckets)):
-                        self._launch(b)
-                    self._finish_exchange()
-                    if cuda:
-                        torch.cuda.synchronize()
-                    if it:
-                        best = min(best, time.perf_counter() - t0)
-                t = torch.tensor([best * 1e3], dtype=torch.float64, device=self.g_arena.device)
+                try:
+                    for it in range(iters + 1):          # first pass = warm-up (communicator / buffer set-up)
+                        if cuda:
+                            torch.cuda.synchronize()
+                        dist.barrier(group=self.group)
+                        t0 = time.perf_counter()
+                        for b in range(len(self.buckets)):
+                            self._launch(b)
+                        self._finish_exchange()
+                        if cuda:
+                            torch.cuda.synchronize()
+                        if it:
+                            best = min(best, time.perf_counter() - t0)
+                except (RuntimeError, NotImplementedError) as e:      # the backend lacks this mode's collectives: it is not a candidate
+                    self.handles, self.finish = [], []
+                    self.launched = [False] * len(self.buckets)
+                    self.unavailable = getattr(self, "unavailable", {})
+                    self.unavailable[mode] = str(e).splitlines()[0][:200]
+                    best = float("inf")
+                t = torch.tensor([best * 1e3 if best != float("inf") else -1.0], dtype=torch.float64, device=self.g_arena.device)
+                lo = t.clone()
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+                if lo.item() < 0:                    # failed on some rank: dropped on every rank (all ranks keep the same table)
+                    break
                 table[(mode, mib)] = round(t.item(), 4)
         self.g_arena.zero_()
         self.exchange = keep[0]

@@ -19,27 +19,47 @@ operand transposition on the side stream) stay eager and are ordered before the 
 
 Results are bit-identical to the eager path (tests/test_gpu_graph.py).  Opt-in: ``model.use_graph = True`` or NRPN_GRAPH=1."""
 import os
+import weakref
 
 import torch
 
 from . import ops
 
 ENABLED = [os.environ.get("NRPN_GRAPH", "0") == "1"]
+SINK_GENERATION = [0]     # bumped by engine.FlatTrainer.__init__: a new trainer installs new arenas / GradSinks, every capture made before is stale
 CAPTURING = [False]       # True while a trunk is being captured (nothing executes): the trainer's gradient notifications are ignored meanwhile.
 # NOTE for new trunk ops: every parameter gradient must be ADDED INTO ITS GradSink by the backward kernel sequence itself.  A gradient handed
 # back to autograd is accumulated by an AccumulateGrad node on the stream that node was created on -- outside the captured backward -- and
 # replays would silently miss it (what ops.WindowAttnFn did before round 4; tests/test_gpu_graph.py holds every backbone to bit-identity).
 
 
+class _Token:
+    __slots__ = ("__weakref__",)
+
+
 class _Captured:
-    __slots__ = ("static_x", "outs", "gouts", "fwd", "bwd", "pool", "dummy")
+    __slots__ = ("static_x", "outs", "gouts", "fwd", "bwd", "pool", "dummy", "node", "backward_done", "on_backward")
+
+    def pending(self):
+        """True while a replayed forward's saved activations (static, shared by every replay) are still waiting for their backward: the
+        autograd node of the last replay is alive and has not run.  A node that was dropped without a backward (a train-mode pass under
+        grad mode that never called backward) is garbage by then and does not count."""
+        return self.node is not None and self.node() is not None and not self.backward_done
 
 
 class _GraphedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cap, dummy):
+        if cap.pending():
+            raise RuntimeError("GraphedBackbone: a second captured forward before the backward of the first (the captured activations are "
+                               "static: the first pass' gradients would be computed from the second pass' activations)")
         cap.fwd.replay()
+        # the replay rewrote the BatchNorm running statistics behind torch's back (no Python of BatchNormFn.forward runs): the eval-mode
+        # (scale, shift) folds cached on this epoch are stale (ADVICE r4)
+        ops.BN_STATS_EPOCH[0] += 1
         ctx.cap = cap
+        ctx.token = _Token()             # dies with the autograd node: tells a pass that was dropped without backward from one still waiting
+        cap.node, cap.backward_done = weakref.ref(ctx.token), False
         return tuple(o.detach() for o in cap.outs)
 
     @staticmethod
@@ -52,6 +72,9 @@ class _GraphedFn(torch.autograd.Function):
                 sg.copy_(g)
         ops._wait_dgrad_operands()       # the side stream's operand refresh of the last optimiser step (an eager event) precedes the replay
         cap.bwd.replay()
+        cap.backward_done = True
+        if cap.on_backward is not None:
+            cap.on_backward()            # the trunk's gradients are in the arena now: the trainer may launch their buckets (engine.FlatTrainer)
         return None, None
 
 
@@ -64,11 +87,29 @@ class GraphedBackbone:
         self.max_shapes = int(max_shapes)     # every captured input shape pins its own activation pool: scenes of further shapes run eagerly
         self.captured = {}
         self.calls = {}
+        self._signature = None
+        self.eager_fallbacks = 0              # forwards that ran eagerly because a captured pass was still waiting for its backward
+
+    def _sink_signature(self):
+        """What a capture bakes in besides shapes: which parameters deliver gradients and WHERE (the trainer's arena addresses).  A second
+        FlatTrainer on the same model (resume, re-bucketing, a new optimiser) or a requires_grad toggle changes it; captures made under
+        another signature would keep adding gradients into the old -- possibly freed -- arena."""
+        sig = [SINK_GENERATION[0]]
+        for p in self.backbone.parameters():
+            k = getattr(p, "_nrpn_sink", None)
+            sig.append((p.requires_grad, k.slot.data_ptr() if (k is not None and p.requires_grad) else 0))
+        return tuple(sig)
 
     def __call__(self, x):
         bb = self.backbone
         if not (x.is_cuda and bb.training and torch.is_grad_enabled()) or torch.cuda.is_current_stream_capturing():
             return bb(x)
+        sig = self._sink_signature()
+        if sig != self._signature:           # new trainer / arenas / trainable set: every capture is stale (their pools are released with them)
+            self.captured.clear()
+            self.calls.clear()
+            self._sinks_ok = None
+            self._signature = sig
         if not self._sinks_everywhere():
             return bb(x)
         key = (tuple(x.shape), x.dtype, bb.compute_dtype)
@@ -81,6 +122,10 @@ class GraphedBackbone:
             if len(self.captured) >= self.max_shapes:
                 return bb(x)
             cap = self.captured[key] = self._capture(x)
+        if cap.pending():
+            # two trunk forwards before one backward (loss(A) + loss(B)): the captured activations are static, so the second pass runs eagerly
+            self.eager_fallbacks += 1
+            return bb(x)
         if cap.static_x.data_ptr() != x.data_ptr():
             cap.static_x.copy_(x)
         return _GraphedFn.apply(cap, cap.dummy)
@@ -96,6 +141,10 @@ class GraphedBackbone:
     def _capture(self, x):
         bb = self.backbone
         cap = _Captured()
+        cap.node, cap.backward_done, cap.on_backward = None, True, None
+        trainer = getattr(next(iter(bb.parameters())), "_nrpn_trainer", None)
+        if trainer is not None and trainer() is not None:
+            cap.on_backward = trainer().trunk_gradients_ready(list(bb.parameters()))
         cap.static_x = x.detach().clone()
         cap.dummy = torch.zeros(1, device=x.device, requires_grad=True)
         ops.wgrad_stream_join()
