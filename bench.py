@@ -346,6 +346,69 @@ def eval_forward_protocol(dtype_name, dev, iters=20, warm=3):
             "note": "eval forward incl. decode / top-k / NMS at the reference's benchmark shape (run_rpn.py:594-617)"}
 
 
+def make_step_for(model_, trainer_, xs_, gts_, fcos):
+    def step():
+        _, losses, _ = model_(xs_, gts_)
+        if fcos:
+            loss = losses["loss_cls"] + losses["loss_reg"] + losses["loss_centerness"]
+        else:
+            loss = losses["loss_objectness"] + 5.0 * losses["loss_rpn_box_reg"] + 0.0 * losses["loss_rpn_box_reg_2d"]
+        loss.backward()
+        trainer_.step()
+        return loss
+    return step
+
+
+def secondary_workloads(dtype, dev, xs, gts, make, steps=12):
+    """The other BASELINE.json configurations on the same 160^3 scene, in the same invocation (bounded: ``steps`` timed steps each, after the
+    headline's timed region): ResNet-50 + RPN (configs[2] / [4]), Swin-S + RPN, Swin-S + FCOS (configs[3]).  Trunk graphs as `--graph auto`
+    chooses them (Swin-S: captured; ResNet-50: eager).  Not the BASELINE metric."""
+    from nerf_rpn_amd import ops as _o
+    from nerf_rpn_amd.engine import FlatTrainer
+    out = {}
+    for name in ("resnet_rpn", "swin_rpn", "swin_fcos"):
+        backbone, head = name.split("_")
+        fcos = head == "fcos"
+        try:
+            m = build_fcos(dtype, dev, "swin0" if backbone == "swin" else backbone) if fcos else build_model(dtype, dev, backbone)
+            m.use_graph = backbone == "swin"
+            tr = FlatTrainer(m, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, total_steps=steps + 32)
+            g = [t.to(dev) for t in gts] if fcos else gts
+            st = make(m, tr, xs, g, fcos)
+            for _ in range(5):                  # 2 eager warm-ups + the capture + replays
+                st()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                loss = st()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t1) / steps
+            cnt = [0]
+            orig = _o.call
+
+            def counting(nm, *a):
+                cnt[0] += 1
+                return orig(nm, *a)
+            _o.call = counting
+            enq = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                st()
+                enq.append(time.perf_counter() - th)
+            torch.cuda.synchronize()
+            _o.call = orig
+            enq.sort()
+            out[name] = {"ms_per_step": round(ms, 3), "scenes_per_s": round(1e3 / ms, 2), "steps": steps, "trunk_hip_graph": bool(m.use_graph),
+                         "host_enqueue_ms_per_step": round(1e3 * enq[len(enq) // 2], 3), "c_abi_calls_per_step": round(cnt[0] / 4, 1),
+                         "final_loss": round(float(loss), 5)}
+            del m, tr, st
+        except Exception as e:                  # a secondary workload must never take the headline line down with it
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        torch.cuda.empty_cache()
+    return out
+
+
 def measured_ceiling():
     """What the MFMA array sustains at the part's power cap on the operands the conv layers multiply (tools/mfma_peak_probe.py: a
     register-only v_mfma_f32_32x32x16_bf16 loop, post-ReLU activations x small weights) -- profiles/r04_mfma_ceiling.json."""
@@ -405,6 +468,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from nerf_rpn_amd.affinity import pin_rank
+    pin = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # ranks > 1: own cores next to the GPU's NUMA node (NRPN_PIN=0: off)
     # NRPN_FORCE_EXCHANGE=1: a one-rank RCCL process group with the trainer's exchange machinery switched on -- the multi-GPU code path
     # of this file and of engine.FlatTrainer (buckets, launch stream, collectives, the prints) on a single-GPU box (tests only)
     dist_on = world > 1 or os.environ.get("NRPN_FORCE_EXCHANGE") == "1"
@@ -504,8 +569,10 @@ def main():
         per_rank_ms = [round(v[0].item(), 3) for v in allr]
         # comm-only arm: every exchange mode x bucket size on the real arena with no compute in flight (the start-up measurement of
         # exchange='auto', or taken here when a mode was forced), next to the wait the training steps actually saw
-        table = trainer.exchange_table or trainer.measure_exchange()
-        exch = {"mode": trainer.exchange, "mode_chosen_by": "comm-only measurement at start-up (fastest fp32 mode; a2a_bf16 is timed but only ever forced)" if trainer.exchange_table else "--exchange / NRPN_GRAD_EXCHANGE",
+        startup = dict(trainer.exchange_table) if trainer.exchange_table else None
+        table = trainer.measure_exchange()       # the full table (every mode x bucket size); start-up times only the candidates of 'auto'
+        exch = {"mode": trainer.exchange, "mode_chosen_by": "comm-only measurement at start-up (fastest of the fp32 modes x 16/32/64 MiB; pin with NRPN_GRAD_EXCHANGE / NRPN_GRAD_BUCKET_MIB)" if startup else "--exchange / NRPN_GRAD_EXCHANGE",
+                **({"startup_comm_only_ms": {f"{m}@{mib}MiB": v for (m, mib), v in sorted(startup.items())}} if startup else {}),
                 "comm_only_ms": {f"{m}@{mib}MiB": v for (m, mib), v in sorted(table.items())},
                 "buckets": len(trainer.buckets), "bucket_mib": [round((e - s_) * 4 / 2 ** 20, 1) for s_, e in trainer.buckets],
                 "bytes_per_step_per_rank": int(trainer.g_arena.numel() * 4),
@@ -549,7 +616,13 @@ def main():
         _opsh.call = orig_call
         enq.sort()
         host = {"c_abi_calls_per_step": round(cnt[0] / 6, 1), "enqueue_ms_per_step": round(1e3 * enq[len(enq) // 2], 3),
-                "note": "median of 6 steps, each started on an idle GPU: time until step() has enqueued forward + backward + optimiser"}
+                "note": "median of 6 steps, each started on an idle GPU: time until step() has enqueued forward + backward + optimiser",
+                "host_cores": os.cpu_count(), "pinning": pin}
+        if dist_on:
+            mine_enq = torch.tensor([1e3 * enq[len(enq) // 2]], device=dev, dtype=torch.float64)
+            all_enq = [torch.zeros_like(mine_enq) for _ in range(world)]
+            dist.all_gather(all_enq, mine_enq)
+            host["enqueue_ms_per_step_per_rank"] = [round(v.item(), 3) for v in all_enq]
     cone = getattr(getattr(model, "rpn", None), "last_cone", None)
 
     extras = {}
@@ -573,6 +646,28 @@ def main():
         if dist_on:
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
         extras["scenes_per_gpu_2"] = {"steps": n2, "ms_per_step": round(1e3 * t2.item() / n2, 3), "scenes_per_s": round(2 * world * n2 / t2.item(), 3)}
+    if not args.no_extras and args.model == "vgg_rpn" and spg == 1:
+        # (a') the dense head: the same step with the RPN head evaluated on every voxel (NRPN_CONE=0), as the reference computes it
+        model.rpn.use_cone = False
+        for _ in range(3):
+            step()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nd = max(5, args.steps // 5)
+        for _ in range(nd):
+            step()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        td = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if dist_on:
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        extras["dense_head_ms_per_step"] = round(1e3 * td.item() / nd, 3)
+        model.rpn.use_cone = True
+        step()
+        torch.cuda.synchronize()
     if rank == 0 and not args.no_extras and args.model == "vgg_rpn" and world == 1 and spg == 1:
         # (b) the parity mode: the same step in fp32 (exact fp32 MFMA chains); (c) the reference's own eval benchmark protocol
         del step
@@ -590,6 +685,7 @@ def main():
         del m32, tr32, s32
         torch.cuda.empty_cache()
         extras["eval_forward_protocol"] = eval_forward_protocol(args.dtype, dev)
+        extras["secondary"] = secondary_workloads(dtype, dev, xs, gts, make_step_for)
 
     if rank == 0:
         roof, rows = probe.summary(args.dtype) if not args.no_probe else (None, [])

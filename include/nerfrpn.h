@@ -250,7 +250,7 @@ typedef struct nrpn_conv_opts {
   int32_t stagger;
   int32_t big_split;
   int32_t debug;
-  int32_t reserved;
+  int32_t halo_pairing;   /* halo form only: 0 = default, 1 = pair taps across channel-chunk boundaries (Cin % 128 == 0), 2 = 14 K-steps per chunk */
   const float *scale;
   const void *relu_mask;
   float *stats;
@@ -415,6 +415,13 @@ int nrpn_ingest_augment(const void *src, int src_is_u8, void *dst, int w, int l,
 int nrpn_ncdhw_to_ndhwc(const float *src, void *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
 int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
 int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtype, int dst_dtype, nrpn_stream_t stream);
+/* bf16x3 operands of the parity-grade fast mode: src f32 [rows][C] -> hi = bf16(x), lo = bf16(x - hi), written as an interleaved operand
+ * bf16 [rows][3C] (forward / dgrad: the K axis tripled; segment s holds lo when bit s of ipattern is set, else hi -- activations 0b100,
+ * weights 0b010: x*w ~ hi*whi + hi*wlo + lo*whi) and / or as nplanes planes bf16 [nplanes][rows][C] stacked on the batch axis (weight
+ * gradient: x planes 0b010, dy planes 0b100).  Either destination may be NULL.  C % 8 == 0.  Replaces nothing in the reference: it lets
+ * the bf16 MFMA kernels reproduce torch.nn.Conv3d's fp32 arithmetic (feature_extractor.py:345-358) to fp32 accumulation error. */
+int nrpn_split_bf16x3(const float *src, int64_t rows, int c, void *interleaved, int ipattern, void *planes, int nplanes, int ppattern,
+                      nrpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Swin-3D backbone pieces, channels-last tokens [N,X,Y,Z,C].  [a6]  (feature_extractor.py:382-789)

@@ -22,6 +22,9 @@ int nrpn_set_conv_tile_m(int bm);
 /* tools-only default: 1 (default) = the halo form (NRPN_TILE_HALO) is chosen automatically where it applies (bf16 3x3x3, Cout >= 256, grids its
  * 4x8x8 blocks cover with <= 12 % waste and >= 200 workgroups), 0 = only on request */
 int nrpn_set_conv_halo_auto(int on);
+/* tools-only default of nrpn_conv_opts.halo_pairing: 1 = the halo kernel pairs taps across channel-chunk boundaries (108 instead of 112 K-steps at
+ * Cin = 256), 0 = 14 K-steps per chunk with a half-empty last one */
+int nrpn_set_conv_halo_pairing(int on);
 /* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
 int nrpn_set_conv_stagger(int on);
 /* tuning knob: 1 (default) = mid-size grids (16..199 tiles of 256x256) run the 256x256 kernel on K slices; 0 = 128-row kernel */

@@ -13,6 +13,10 @@
 // Replaces torch.nn.Conv3d (MIOpen/cuDNN) in reference feature_extractor.py:331-358, fpn.py:109-110, anchor.py:190-198.
 #include "conv_common.cuh"
 
+#ifndef NRPN_HALO_PAIRING_DEFAULT
+#define NRPN_HALO_PAIRING_DEFAULT 0      // set to 1 once measured faster on hardware (profiles/r05_*)
+#endif
+
 // ROWS (MODE 0): row-list form -- tile row v is voxel p.rows[2 v] of the ragged space with tap word p.rows[2 v + 1] (csrc/cone.hip); the
 // output (and the optional ReLU mask) row is that voxel.  The dense instantiations carry none of it.
 template <typename T, int BN, int MODE, bool OUTF32, int KB, bool GLDS, int BM = 128, bool ROWS = false>
@@ -1272,13 +1276,16 @@ struct Knobs {
   int kb;          // K-step bytes of the k1/k3 kernels (64 or 128)
   int dbg;         // tools only: NRPN_CONV_DEBUG_* bits
   int halo_auto;   // 1 (default): the halo form is chosen automatically where it applies (40^3-class grids), 0: only on request (tile 2048)
+  int halo_xp;     // halo form: taps paired across chunk boundaries (54 full K-steps per four chunks; Cin % 128 == 0) instead of 14 per chunk
 };
-static std::atomic<int> g_conv_glds{1}, g_conv_bm{0}, g_conv_stagger{1}, g_conv_big_split{1}, g_conv_kb{128}, g_conv_halo_auto{1};
+static std::atomic<int> g_conv_glds{1}, g_conv_bm{0}, g_conv_stagger{1}, g_conv_big_split{1}, g_conv_kb{128}, g_conv_halo_auto{1}, g_conv_halo_xp{NRPN_HALO_PAIRING_DEFAULT};
 static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
   Knobs k{g_conv_glds.load(std::memory_order_relaxed), g_conv_bm.load(std::memory_order_relaxed), g_conv_stagger.load(std::memory_order_relaxed),
           g_conv_big_split.load(std::memory_order_relaxed), g_conv_kb.load(std::memory_order_relaxed),
-          flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER | NRPN_CONV_DEBUG_VARIANT), g_conv_halo_auto.load(std::memory_order_relaxed)};
+          flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER | NRPN_CONV_DEBUG_VARIANT), g_conv_halo_auto.load(std::memory_order_relaxed),
+          g_conv_halo_xp.load(std::memory_order_relaxed)};
   if (o) {
+    if (o->halo_pairing == 1 || o->halo_pairing == 2) k.halo_xp = o->halo_pairing == 1;
     if (o->tile > 0) k.bm = o->tile;
     if (o->lds_dma >= 0) k.glds = o->lds_dma ? 1 : 0;
     if (o->kstep_bytes == 64 || o->kstep_bytes == 128) k.kb = o->kstep_bytes;
@@ -1290,6 +1297,7 @@ static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
 }
 extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_halo_auto(int on) { g_conv_halo_auto = on ? 1 : 0; return NRPN_OK; }
+extern "C" int nrpn_set_conv_halo_pairing(int on) { g_conv_halo_xp = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_stagger(int on) { g_conv_stagger = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_big_split(int on) { g_conv_big_split = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
@@ -1371,7 +1379,8 @@ static long long halo_tiles(const Grid &g) {
   return (long long)g.n * ((g.gx + hk::TX - 1) / hk::TX) * ((g.gy + hk::TY - 1) / hk::TY) * ((g.gz + hk::TZ - 1) / hk::TZ);
 }
 static bool halo_ok(const Grid &g, int cin, int cout, int taps, int elem_bytes, bool out_f32, const Knobs &kn) {
-  if (g.n <= 0 || taps != 27 || elem_bytes != 2 || out_f32 || !kn.glds || (cin % 32) != 0 || (cout & 7) != 0 || cout < 256) return false;
+  (void)out_f32;      // round 5: the halo kernel has an fp32-output epilogue (no mask / statistics there: the entry points reject those)
+  if (g.n <= 0 || taps != 27 || elem_bytes != 2 || !kn.glds || (cin % 32) != 0 || (cout & 7) != 0 || cout < 256) return false;
   if (kn.bm != 2048 && !(kn.bm == 0 && kn.halo_auto)) return false;
   const long long tiles = halo_tiles(g) * ((cout + 255) / 256);
   const double waste = (double)halo_tiles(g) * 256.0 / ((double)g.n * g.gx * g.gy * g.gz);
@@ -1536,7 +1545,8 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
     if (halo_ok(g, cin, cout, a.taps, es, out_f32, kn)) {
       const long long wgs = halo_tiles(g) * ((cout + 255) / 256);
       NRPN_REQUIRE(wgs < (1ll << 31), "conv3d_fwd: too many tiles");
-      return nrpn_launch_conv_halo(a, (unsigned)wgs, st, (kn.dbg >> 12) & 3);
+      const int variant = ((kn.dbg >> 12) & 3) | ((kn.halo_xp && cin % 128 == 0 && !((kn.dbg >> 12) & 3)) ? 4 : 0) | (out_f32 ? 8 : 0);
+      return nrpn_launch_conv_halo(a, (unsigned)wgs, st, variant);
     }
   }
   const int bs = workspace ? conv_big_split(a.M, cout, cin, a.taps, es, kn) : 0;

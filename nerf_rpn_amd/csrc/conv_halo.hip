@@ -2,6 +2,8 @@
 // anchor.py:190-198 -- the 256 -> 256 @ 40^3 layers are 66 % of the model's FLOPs).  Own translation unit: it is the kernel under work.
 #include "conv_common.cuh"
 
+#include <type_traits>
+
 // ---------------------------------------------------------------------------------------------------------------------
 // "Halo" form of the 3x3x3 implicit GEMM for the wide bf16 layers (256 x 256 tile, 8 waves as conv_igemm_big_kernel).
 //
@@ -42,7 +44,20 @@ __device__ __forceinline__ void block_voxel(int r, int &xl, int &yl, int &zl) {
 // V (tools-only A/B variants, selected by the NRPN_CONV_DEBUG_VARIANT bits; the production instantiation is V = 0 -- set below to the measured
 // winner): bit 0 = static priority for the second-dispatched waves 4-7 (MI355X guide, "two waves per SIMD" item 4); bit 1 = waves 4-7 issue
 // their weight pieces one sub-step later than waves 0-3 (the two waves of a SIMD are then not both in their DMA-issue phase).
-template <int V>
+// XP (round 5): taps are paired ACROSS chunk boundaries -- the 4 x 27 (tap, chunk) entries of four consecutive chunks form 54 full K-steps
+// (entry e = 27 j + tap -> K-step e / 2) instead of 4 x 14 with a half-empty one per chunk: 108 K-steps instead of 112 for Cin = 256, and
+// no K-step pays a barrier + a weight tile for 16 MFMAs.  Four chunks per loop iteration because 27 K-steps per chunk pair is odd: the weight
+// double buffer (a compile-time immediate in every fragment address) only returns to buffer 0 after 54.  Needs Cin % 128 == 0.
+// OF32: fp32 output rows (NRPN_CONV_OUT_F32: the bf16x3 parity mode feeds split bf16 operands and keeps fp32 activations); no mask / statistics.
+template <int K, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {      // f(integral_constant<K>) ... f(integral_constant<N-1>): unrolled by construction
+  if constexpr (K < N) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, N>(f);
+  }
+}
+
+template <int V, bool XP = false, bool OF32 = false>
 __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
   using namespace hk;
   typedef bf16s T;
@@ -102,6 +117,20 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
       unsigned step = b_row_step * i;
       asm volatile("" : "+s"(step));                      // opaque scalar: the address is formed here (not hoisted 56-fold out of the chunk loop)
       const bool ok = brow + 64 * i < p.wrows && sel_off != kOOB;
+      lds_dma16(wr, Bb + buf * B_BYTES + (wave_u * 8 + 64 * i) * 128, ok ? b_voff + sel_off + step : kOOB);
+    }
+  };
+
+  // XP: the two 64-byte runs of a weight-tile row come from two arbitrary (tap, chunk) entries
+  auto issue_b2 = [&](int buf, int chunk_a, int tap_a, int chunk_b, int tap_b) {
+    const unsigned off_a = (unsigned)tap_a * w_tap_bytes + (unsigned)(chunk_a * 64);
+    const unsigned off_b = (unsigned)tap_b * w_tap_bytes + (unsigned)(chunk_b * 64);
+    const unsigned sel_off = b_sel ? off_b : off_a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned step = b_row_step * i;
+      asm volatile("" : "+s"(step));
+      const bool ok = brow + 64 * i < p.wrows;
       lds_dma16(wr, Bb + buf * B_BYTES + (wave_u * 8 + 64 * i) * 128, ok ? b_voff + sel_off + step : kOOB);
     }
   };
@@ -192,6 +221,60 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
   };
   load(0, 0, 0, 0, af[0], bfv[0]);
   if ((V & 1) && wave_u >= 4) __builtin_amdgcn_s_setprio(1);
+  if constexpr (XP) {
+    // entry e (0..107) of a four-chunk group = (chunk e / 27, tap e % 27); K-step k = entries 2k, 2k + 1; sub-steps (entry, channel half)
+    auto load_xp = [&](int k, int s4, f4 (&a)[TM], f4 (&b)[TN]) {
+      const int e = 2 * k + (s4 >> 1), cj = e / 27, tap = e % 27;
+      const int dxyz = (tap / 9) * PX + ((tap / 3) % 3) * PY + (tap % 3);
+      const int aoff = (cj & 1) * A_BYTES + (s4 & 1) * (2 * RP * 16) + dxyz * 16;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f4 *>(lds + b_addr[j][s4] + (k & 1) * B_BYTES);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f4 *>(lds + a_base[i] + aoff);
+    };
+    auto kstep_xp = [&](auto kc, int chunk, bool more) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int bbuf = k & 1;
+      constexpr bool last = k == 53;
+      if constexpr (!last) {
+        constexpr int e0 = 2 * k + 2, e1 = e0 + 1;
+        issue_b2(bbuf ^ 1, chunk + e0 / 27, e0 % 27, chunk + e1 / 27, e1 % 27);
+      } else if (more) {
+        issue_b2(bbuf ^ 1, chunk + 4, 0, chunk + 4, 1);
+      }
+      // halo of chunk j + 1 goes into the buffer chunk j - 1 used: free once the K-step holding chunk j - 1's last entry has passed its barrier
+      // (chunk 0 / 1 / 2 / 3 of the group end in K-steps 13 / 26 / 40 / 53)
+      if constexpr (k < A_PER_WAVE) issue_halo_piece(1, chunk + 1, k);
+      else if constexpr (k >= 14 && k < 14 + A_PER_WAVE) issue_halo_piece(0, chunk + 2, k - 14);
+      else if constexpr (k >= 27 && k < 27 + A_PER_WAVE) issue_halo_piece(1, chunk + 3, k - 27);
+      else if constexpr (k >= 41 && k < 41 + A_PER_WAVE) { if (more) issue_halo_piece(0, chunk + 4, k - 41); }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 < 3) {
+          load_xp(k, s4 + 1, af[(s4 + 1) & 1], bfv[(s4 + 1) & 1]);
+        } else {
+          __syncthreads();
+          if constexpr (!last) load_xp(k + 1, 0, af[0], bfv[0]);
+          else if (more) load_xp(0, 0, af[0], bfv[0]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[s4 & 1][i], bfv[s4 & 1][j]);
+#pragma unroll
+        for (int q = 0; q < TM + TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+      }
+    };
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunk; chunk += 4) {
+      const bool more = chunk + 4 < nchunk;
+      static_for<0, 54>([&](auto kc) { kstep_xp(kc, chunk, more); });
+    }
+  } else {
   // chunks in pairs so that the halo buffer is a compile-time constant inside the unrolled K-steps (immediate ds offsets); 14 K-steps
   // per chunk flip the weight buffer an even number of times, so every chunk starts on weight buffer 0
 #pragma unroll 1
@@ -202,6 +285,7 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) kstep(1, ks, chunk + 1, chunk + 2 < nchunk);
     }
+  }
   }
 
   // ---- epilogue: scale / bias / ReLU / optional ReLU mask / optional BatchNorm statistics; staged through LDS, 16-byte stores
@@ -216,6 +300,50 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
   T *yp = reinterpret_cast<T *>(p.y);
   float ssum[TN] = {0.f, 0.f}, qsum[TN] = {0.f, 0.f};
   const bool full_block = x0 + TX <= p.X && y0 + TY <= p.Y && z0 + TZ <= p.Z;
+  if constexpr (OF32) {
+    // fp32 rows: the same staging with 4-byte elements (64 rows x 64 columns per pass = 256-byte rows, pitch 272), 16-byte stores
+    constexpr int PITCH32 = 272;
+    char *stage32 = lds + wave * (64 * PITCH32);
+    float *yf = reinterpret_cast<float *>(p.y);
+    __syncthreads();                                   // the staging regions overlap other waves' K-loop buffers
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + efr;
+        const float bv = (has_bias && col < p.Cout) ? p.bias[col] : 0.f;
+        const float sv = (p.scale && col < p.Cout) ? p.scale[col] : 1.f;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = half * 2 + ii;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = frag_row(r, elane);
+            float o = acc[i][j][r] * sv + bv;
+            if (relu) o = fmaxf(o, 0.f);
+            *reinterpret_cast<float *>(stage32 + (ii * 32 + rr) * PITCH32 + (j * 32 + efr) * 4) = o;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int pc = elane + 64 * q;                  // 64 rows x 16 pieces of 4 floats
+        const int row = pc >> 4, seg = pc & 15;
+        const int blk = wm * TM + half * 2 + (row >> 5);
+        int xl, yl, zl;
+        block_voxel(row & 31, xl, yl, zl);
+        const int gx = x0 + 2 * (blk >> 2) + xl, gy = y0 + 2 * (blk & 3) + yl, gz = z0 + zl;
+        const int col = n0 + wn * 64 + seg * 4;
+        if (gx < p.X && gy < p.Y && gz < p.Z && col < p.Cout) {
+          const long long v = vbase + ((long long)gx * p.Y + gy) * p.Z + gz;
+          *reinterpret_cast<f4 *>(yf + v * p.Cout + col) = *reinterpret_cast<const f4 *>(stage32 + row * PITCH32 + seg * 16);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -281,17 +409,26 @@ __global__ void __launch_bounds__(512, 1) conv_halo_kernel(const ConvArgs p) {
 }
 
 
+// variant: bits 0-1 = V (tools-only A/B variants of the classic K order), bit 2 = XP (cross-chunk tap pairing; the caller guarantees
+// Cin % 128 == 0), bit 3 = OF32 (fp32 output rows)
 int nrpn_launch_conv_halo(const ConvArgs &a, unsigned workgroups, hipStream_t st, int variant) {
-#define NRPN_HALO(V_)                                                                                       \
-  do {                                                                                                      \
-    NRPN_LDS(conv_halo_kernel<V_>, hk::LDS_BYTES);                                                          \
-    hipLaunchKernelGGL(conv_halo_kernel<V_>, dim3(workgroups), dim3(512), hk::LDS_BYTES, st, a);            \
+#define NRPN_HALO(...)                                                                                                \
+  do {                                                                                                                \
+    NRPN_LDS((conv_halo_kernel<__VA_ARGS__>), hk::LDS_BYTES);                                                         \
+    hipLaunchKernelGGL((conv_halo_kernel<__VA_ARGS__>), dim3(workgroups), dim3(512), hk::LDS_BYTES, st, a);           \
   } while (0)
-  switch (variant & 3) {
-    case 1: NRPN_HALO(1); break;
-    case 2: NRPN_HALO(2); break;
-    case 3: NRPN_HALO(3); break;
-    default: NRPN_HALO(0); break;
+  const bool xp = (variant & 4) != 0, of32 = (variant & 8) != 0;
+  if (of32) {
+    if (xp) NRPN_HALO(0, true, true); else NRPN_HALO(0, false, true);
+  } else if (xp) {
+    NRPN_HALO(0, true, false);
+  } else {
+    switch (variant & 3) {
+      case 1: NRPN_HALO(1); break;
+      case 2: NRPN_HALO(2); break;
+      case 3: NRPN_HALO(3); break;
+      default: NRPN_HALO(0); break;
+    }
   }
 #undef NRPN_HALO
   NRPN_LAUNCH_CHECK("conv_halo");

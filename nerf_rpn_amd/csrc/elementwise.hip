@@ -801,6 +801,57 @@ extern "C" int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, in
   return NRPN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3 ("split bf16") operands of the parity-grade fast mode (round 5): an fp32 value x is carried as hi = bf16(x) and
+// lo = bf16(x - hi) (the subtraction is exact in fp32; hi + lo reproduces x to 2^-17 relative), and a product x * w is evaluated as
+// hi*whi + hi*wlo + lo*whi on the bf16 MFMA kernels with fp32 accumulation (every bf16 x bf16 product is exact in fp32; what is dropped,
+// lo*wlo and the two residuals, is <= 2^-16 relative per product: the size of the fp32 accumulation error of a K = 27 * 256 dot product).
+// The conv kernels are NOT changed for it: the K axis is tripled.  Forward / dgrad read an INTERLEAVED operand [rows][3C] whose three
+// C-wide segments hold (hi | hi | lo) for activations and (hi | lo | hi) for weights; the weight gradient sums over voxels, so it reads
+// PLANES [p][rows][C] stacked on the batch axis -- x as (hi ; lo ; hi), dy as (hi ; hi ; lo) -- which the wgrad kernels sum like scenes.
+// One pass over the fp32 source writes either or both forms.  Segment / plane s holds lo when bit s of the pattern is set, else hi.
+// 8 channels per lane: two 16-byte loads, 16-byte stores (C % 8 == 0).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void split_bf16x3_kernel(const float *__restrict__ src, long long rows, int c, bf16s *__restrict__ inter, int ipat,
+                                    bf16s *__restrict__ planes, int nplanes, int ppat) {
+  typedef __attribute__((ext_vector_type(8))) unsigned short u8v;
+  const int groups = c >> 3;
+  const long long total = rows * groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / groups;
+    const int g = (int)(i - r * groups);
+    const f4 a = *reinterpret_cast<const f4 *>(src + r * c + g * 8), b = *reinterpret_cast<const f4 *>(src + r * c + g * 8 + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u8v hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned short h = f32_to_bf16_bits(v[e]);
+      hi[e] = h;
+      lo[e] = f32_to_bf16_bits(v[e] - bf16_bits_to_f32(h));
+    }
+    if (inter) {
+      bf16s *d = inter + r * 3 * c + g * 8;
+#pragma unroll
+      for (int sgm = 0; sgm < 3; ++sgm) *reinterpret_cast<u8v *>(d + sgm * c) = ((ipat >> sgm) & 1) ? lo : hi;
+    }
+    if (planes) {
+      bf16s *d = planes + r * c + g * 8;
+      for (int pl = 0; pl < nplanes; ++pl) *reinterpret_cast<u8v *>(d + (long long)pl * rows * c) = ((ppat >> pl) & 1) ? lo : hi;
+    }
+  }
+}
+
+extern "C" int nrpn_split_bf16x3(const float *src, int64_t rows, int c, void *interleaved, int ipattern, void *planes, int nplanes, int ppattern,
+                                 nrpn_stream_t stream) {
+  NRPN_REQUIRE(src && rows > 0 && c > 0 && (c & 7) == 0, "split_bf16x3: rows > 0 and C a multiple of 8 (got C = %d)", c);
+  NRPN_REQUIRE(interleaved || planes, "split_bf16x3: nothing to write");
+  NRPN_REQUIRE(!planes || (nplanes >= 1 && nplanes <= 3), "split_bf16x3: 1..3 planes (got %d)", nplanes);
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(ew_blocks((long long)rows * (c >> 3))), dim3(256), 0, as_stream(stream), src, (long long)rows, c,
+                     reinterpret_cast<bf16s *>(interleaved), ipattern, reinterpret_cast<bf16s *>(planes), nplanes, ppattern);
+  NRPN_LAUNCH_CHECK("split_bf16x3");
+  return NRPN_OK;
+}
+
 template <typename S, typename D>
 __global__ void cast_kernel(const S *__restrict__ s, D *__restrict__ d, long long count) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)

@@ -25,12 +25,12 @@ TILE_AUTO, TILE_128, TILE_256X128_WS, TILE_256X256, TILE_256X256_W4, TILE_HALO =
 class ConvOpts(ctypes.Structure):
     """``nrpn_conv_opts`` (include/nerfrpn.h): per-call plan + fused-epilogue extras of ``nrpn_conv3d_fwd_ex``."""
     _fields_ = [("size", ctypes.c_int32), ("tile", ctypes.c_int32), ("lds_dma", ctypes.c_int32), ("kstep_bytes", ctypes.c_int32),
-                ("stagger", ctypes.c_int32), ("big_split", ctypes.c_int32), ("debug", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("stagger", ctypes.c_int32), ("big_split", ctypes.c_int32), ("debug", ctypes.c_int32), ("halo_pairing", ctypes.c_int32),
                 ("scale", ctypes.c_void_p), ("relu_mask", ctypes.c_void_p), ("stats", ctypes.c_void_p)]
 
-    def __init__(self, tile=0, lds_dma=-1, kstep_bytes=0, stagger=-1, big_split=-1, debug=0, scale=0, relu_mask=0, stats=0):
-        super().__init__(ctypes.sizeof(ConvOpts), tile, lds_dma, kstep_bytes, stagger, big_split, debug, 0, scale or None, relu_mask or None,
-                         stats or None)
+    def __init__(self, tile=0, lds_dma=-1, kstep_bytes=0, stagger=-1, big_split=-1, debug=0, scale=0, relu_mask=0, stats=0, halo_pairing=0):
+        super().__init__(ctypes.sizeof(ConvOpts), tile, lds_dma, kstep_bytes, stagger, big_split, debug, halo_pairing, scale or None,
+                         relu_mask or None, stats or None)
 
     def ptr(self):
         return ctypes.addressof(self)

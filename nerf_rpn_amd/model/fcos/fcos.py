@@ -167,8 +167,13 @@ class FCOSOverNeRF(nn.Module):
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dtype):
+        if isinstance(dtype, str):       # "bf16x3": see NeRFRegionProposalNetwork.set_compute_dtype
+            if dtype not in ("bf16x3", "fp32", "bf16"):
+                raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
+            ops.SPLIT3[0] = dtype == "bf16x3"
+            dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+            raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
         self.compute_dtype = dtype
         self.backbone.compute_dtype = dtype
         return self

@@ -256,6 +256,11 @@ class ShiftedWindowAttention(nn.Module):
         super().__init__()
         if len(window_size) != 3 or len(shift_size) != 3:
             raise ValueError("window_size and shift_size must be of length 3")
+        if dim % num_heads != 0:
+            # --backbone_type swin_b (run_rpn.py:284: embed_dim 128 with heads 3/6/12/24) cannot run in the reference either: its attention
+            # reshapes the 3*C qkv columns to [3, heads, C // heads] (feature_extractor.py:446) and 3 * 3 * 42 != 384 raises in torch
+            raise ValueError(f"embed dim {dim} is not divisible by num_heads {num_heads} (the reference's swin_b table, run_rpn.py:284, has this "
+                             "defect: its own attention reshape fails)")
         if list(window_size) != [4, 4, 4] or dim != 32 * num_heads or list(shift_size) not in ([0, 0, 0], [2, 2, 2]):
             raise NotImplementedError("the HIP attention kernel is specialised for window 4x4x4, shift 0|2, head_dim 32 "
                                       "(swin_t / swin_s / swin_l of run_rpn.py)")

@@ -50,8 +50,16 @@ class NeRFRegionProposalNetwork(nn.Module):
         self.set_compute_dtype(kwargs.get("compute_dtype", torch.float32))
 
     def set_compute_dtype(self, dtype):
+        """torch.float32 (exact fp32 MFMA chains: the parity mode), torch.bfloat16 (throughput) or "bf16x3": fp32 activations / weights /
+        gradients with the 3x3x3 convolutions evaluated as three bf16 MFMA products of split operands (ops.SPLIT3: a process-wide switch,
+        like torch's allow_tf32 -- fp32 results to fp32 accumulation error at a fraction of the fp32 MFMA time)."""
+        if isinstance(dtype, str):
+            if dtype not in ("bf16x3", "fp32", "bf16"):
+                raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
+            ops.SPLIT3[0] = dtype == "bf16x3"
+            dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+            raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
         self.compute_dtype = dtype
         self.backbone.compute_dtype = dtype
         self.rpn.compute_dtype = dtype

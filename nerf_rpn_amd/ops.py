@@ -701,18 +701,73 @@ class PackedWeight:
         return fwd, dgrad
 
 
+
+# ======================================================================================================================
+# bf16x3: the parity-grade fast mode (round 5).  fp32 activations / weights / gradients everywhere; the dense and row-list 3x3x3
+# convolutions -- 95 % of the step's FLOPs -- multiply SPLIT operands (hi = bf16(x), lo = bf16(x - hi)) on the bf16 MFMA kernels:
+# x * w ~ hi*whi + hi*wlo + lo*whi, fp32 accumulation, fp32 rows out (csrc/elementwise.hip: split_bf16x3_kernel).  The K axis is tripled,
+# the kernels are the bf16 ones unchanged.  A process-wide switch in the spirit of torch.backends.cuda.matmul.allow_tf32: it decides HOW an
+# fp32 convolution is computed, not what it returns (to fp32 accumulation error).  NeRFRegionProposalNetwork.set_compute_dtype("bf16x3"),
+# run_rpn.py --dtype bf16x3, NRPN_BF16X3=1.
+# ======================================================================================================================
+SPLIT3 = [_os.environ.get("NRPN_BF16X3", "0") == "1"]
+_ACT_I, _W_I = 0b100, 0b010          # interleaved [rows][3C]: activations (hi | hi | lo), weights (hi | lo | hi)
+_X_P, _DY_P = 0b010, 0b100           # planes stacked on the batch axis: x (hi ; lo ; hi), dy (hi ; hi ; lo)
+
+
+def split3(src, ipattern=None, nplanes=0, ppattern=0):
+    """src f32 [..., C] -> (bf16 [..., 3C] interleaved or None, bf16 [nplanes, ..., C] planes or None); see nrpn_split_bf16x3."""
+    src = src.contiguous()
+    _chk(src)
+    c = src.shape[-1]
+    inter = torch.empty(tuple(src.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=src.device) if ipattern is not None else None
+    planes = torch.empty((nplanes,) + tuple(src.shape), dtype=torch.bfloat16, device=src.device) if nplanes else None
+    call("split_bf16x3", _p(src), src.numel() // c, c, _p(inter), ipattern or 0, _p(planes), nplanes, ppattern, _s())
+    return inter, planes
+
+
+def _x3_ok(x, ksize, segs, rows_total):
+    # ragged voxel lists (the dense head over all pyramid levels) only without autograd: their weight gradient has no batch axis to stack on
+    return (SPLIT3[0] and x.dtype == torch.float32 and ksize == 3 and (segs is None or not torch.is_grad_enabled())
+            and x.shape[-1] % 32 == 0 and rows_total % 32 == 0)
+
+
+def _x3_weights(pack, weights, wp, wpd):
+    """Split forms of a conv's fp32 GEMM operands (forward [taps][rows][Cin] -> [taps][rows][3 Cin], dgrad [taps][Cin][rows] ->
+    [taps][Cin][3 rows]), refreshed when the parameters change (the same epochs PackedWeight.get keys on)."""
+    arena = getattr(weights[0], "_nrpn_arena", None) if len(weights) == 1 else None
+    key = (wp.data_ptr(), wpd.data_ptr() if wpd is not None else 0, _weight_epoch, arena[0].epoch if arena is not None else pack.key)
+    ent = pack.__dict__.get("x3")
+    if ent is None or ent[0] != key:
+        w3 = split3(wp, _W_I)[0]
+        wd3 = split3(wpd, _W_I)[0] if wpd is not None else None
+        ent = (key, w3, wd3)
+        pack.__dict__["x3"] = ent
+    return ent[1], ent[2]
+
+
+def column_sum_f32(t):
+    """f32 [rows, C] -> f32 [C] column sums (deterministic: the BatchNorm statistics kernels' fixed-order reduction, fp64 finish)."""
+    rows, c = t.shape
+    mean, var = torch.empty(c, dtype=torch.float32, device=t.device), torch.empty(c, dtype=torch.float32, device=t.device)
+    ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=t.device)
+    call("bn_stats", _p(t), rows, c, F32, _p(mean), _p(var), 0, 0, 0.1, _p(ws), _s())
+    return mean * float(rows)
+
+
 def _seg_dims(segs):
     import ctypes
     flat = [int(v) for d in segs for v in d]
     return (ctypes.c_int32 * len(flat))(*flat)
 
 
-def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask=None, stats=None, scale=None, tile=0):
+def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask=None, stats=None, scale=None, tile=0, halo_pairing=0):
     """segs: None, or the (X, Y, Z) dims of the grids laid end to end in x = [1, sum(X*Y*Z), 1, 1, C] (ragged list).
     stats: None, or a dict that asks for BatchNorm statistics out of the conv epilogue: when the shape's kernel has them, the launch
     fills stats['partials'] = f32 [P, 2, cout] (see nrpn_conv3d_fwd_stats); otherwise the dict stays empty.
     scale: None or f32 [cout]: y = acc * scale + bias (eval-mode BatchNorm folded into the conv, nrpn_conv_opts.scale).
-    tile: per-call kernel selection (lib.TILE_*; 0 = the library's choice for the shape)."""
+    tile: per-call kernel selection (lib.TILE_*; 0 = the library's choice for the shape); halo_pairing: nrpn_conv_opts.halo_pairing (0 = default,
+    1 = taps paired across chunk boundaries, 2 = 14 K-steps per chunk)."""
     import ctypes
     n, gx, gy, gz, cin = x.shape
     y = torch.empty((n, gx, gy, gz, cout), dtype=out_dtype, device=x.device)
@@ -729,7 +784,7 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask
         call("conv3d_fwd_ragged", _p(x), _p(wp), _p(bias), _p(y), len(segs), ctypes.addressof(dims), cin, cout, wrows, ksize, _dt(x), flags,
              _p(ws), _s())
         return y
-    opts = lib.ConvOpts(tile=tile or CONV_TILE[0], scale=_p(scale), relu_mask=_p(mask))
+    opts = lib.ConvOpts(tile=tile or CONV_TILE[0], scale=_p(scale), relu_mask=_p(mask), halo_pairing=halo_pairing or CONV_HALO_PAIRING[0])
     if stats is not None and segs is None and mask is None and out_dtype == x.dtype and wrows == cout:
         rows = _query_opts("conv3d_fwd_stats_rows_ex", opts, n, gx, gy, gz, cin, cout, ksize, _dt(x))
         if rows > 0:
@@ -747,6 +802,7 @@ def _conv_fwd(x, wp, bias, cout, wrows, ksize, flags, out_dtype, segs=None, mask
 # Tile override of every forward / dgrad launch of this process ([0] = lib.TILE_*; 0 = the library's per-shape choice).  A per-call
 # nrpn_conv_opts field underneath -- NOT a library global -- so it is safe next to other threads; bench.py / tools set it for A/B runs.
 CONV_TILE = [int(_os.environ.get("NRPN_CONV_TILE", "0"))]
+CONV_HALO_PAIRING = [int(_os.environ.get("NRPN_HALO_PAIRING", "0"))]      # A/B: 0 = library default, 1 = cross-chunk tap pairing, 2 = off
 
 
 # wgrad workspace = [27-bit tap mask per voxel (k3) | per-slice bias partials]; the masks depend only on the grid, so one workspace per
@@ -814,15 +870,21 @@ class ConvFn(torch.autograd.Function):
                     pack.bias, pack.bias_key = torch.cat(parts), bkey
                 bias = pack.bias
         out_dtype = torch.float32 if out_f32 else x.dtype
+        x3 = _x3_ok(x, ksize, segs, rows_total)
+        xin = x
+        if x3:      # bf16x3: split operands on the bf16 MFMA kernels, fp32 rows out; BatchNorm statistics then come from their own pass
+            wp, wpd = _x3_weights(pack, weights, wp, wpd)
+            xin, stats = split3(x, _ACT_I)[0], None
         if affine is not None:
             # eval-mode BatchNorm folded into this conv: y = acc * scale + shift (the conv's own bias is inside `shift`); forward only --
             # the HIP path has no eval-mode BatchNorm backward either (BatchNormFn.backward)
             scale, shift = affine
-            y = _conv_fwd(x, wp, shift, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, None, scale)
+            y = _conv_fwd(xin, wp, shift, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, None, scale)
             ctx.mark_non_differentiable(y)       # hip_nn._can_fold only folds when nothing upstream needs a gradient
             return y
-        y = _conv_fwd(x, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, stats)
+        y = _conv_fwd(xin, wp, bias, rows_total, rows_total, ksize, CONV_RELU if relu else 0, out_dtype, segs, None, stats)
         ctx.save_for_backward(x, y if relu else None, wpd, *weights)
+        ctx.x3 = x3
         ctx.meta = (rows_total, relu, nw, ksize, biases[0] is not None, segs, chain)
         ctx.sinks = ([_sink(w) for w in weights], [_sink(b) for b in biases])
         return y
@@ -849,28 +911,62 @@ class ConvFn(torch.autograd.Function):
             call("relu_backward", _p(yy), _p(dy), _p(dyr), dy.numel(), _dt(dy), _s())
             dy = dyr
         dx = None
+        x3 = getattr(ctx, "x3", False)
+        dyp = None
+        if x3:
+            # bf16x3: one pass over dy writes the interleaved operand of the dgrad launch and the planes of the wgrad launch
+            dys, dyp = split3(dy, _ACT_I if ctx.needs_input_grad[0] else None, 3, _DY_P)
         if ctx.needs_input_grad[0]:
             _wait_dgrad_operands()
             # CHAIN_MASK_INPUT_GRAD: x is the ReLU output of the layer that receives dx and this conv is its only consumer, so that
             # layer's ReLU backward is applied in this dgrad's epilogue (dx = 0 where x <= 0) instead of a separate pass
             mask = x if (chain & CHAIN_MASK_INPUT_GRAD) and segs is None else None
-            dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype, segs, mask)
+            if x3:
+                dx = _conv_fwd(dys, wpd, None, cin, cin, ksize, 0, torch.float32)
+                if mask is not None:          # fp32 rows out of bf16 operands: the epilogue takes no mask, one elementwise pass instead
+                    dxm = torch.empty_like(dx)
+                    call("relu_backward", _p(x), _p(dx), _p(dxm), dx.numel(), _dt(dx), _s())
+                    dx = dxm
+            else:
+                dx = _conv_fwd(dy, wpd, None, cin, cin, ksize, 0, x.dtype, segs, mask)
         taps = ksize ** 3
         wsinks, bsinks = ctx.sinks
         side = _wgrad_side_stream(x.device) if all(k is not None for k in wsinks) and (not has_bias or all(k is not None for k in bsinks)) else None
+        wgrad = (lambda: ConvFn._wgrad_x3(ctx, x, dy, dyp, weights)) if x3 else (lambda: ConvFn._wgrad(ctx, x, dy, weights))
         if side is None:
-            return (dx, None, None, None, None, None, *ConvFn._wgrad(ctx, x, dy, weights))
+            return (dx, None, None, None, None, None, *wgrad())
         main = torch.cuda.current_stream(x.device)
         side.wait_stream(main)              # dy (after the ReLU mask) is ready; also orders this wgrad behind the arena's zero fill
         x.record_stream(side)
         dy.record_stream(side)
-        _WGRAD_SIDE["keep"].append((x, dy))
+        if dyp is not None:
+            dyp.record_stream(side)
+        _WGRAD_SIDE["keep"].append((x, dy, dyp))
         with torch.cuda.stream(side):       # every gradient goes straight into the arena here: nothing is handed back to autograd
-            res = ConvFn._wgrad(ctx, x, dy, weights)
+            res = wgrad()
         if not _WGRAD_SIDE["dirty"]:        # first side-stream wgrad of this backward pass: join when the pass ends
             _WGRAD_SIDE["dirty"] = True
             torch.autograd.Variable._execution_engine.queue_callback(wgrad_stream_join)
         return (dx, None, None, None, None, None, *res)
+
+    @staticmethod
+    def _wgrad_x3(ctx, x, dy, dyp, weights):
+        """bf16x3 weight gradient: dW = dy_hi (x) x_hi + dy_hi (x) x_lo + dy_lo (x) x_hi as ONE bf16 wgrad launch over three "scenes"
+        (planes stacked on the batch axis, which the kernel sums over); the bias gradient is the fp32 column sum of dy."""
+        rows_total, relu, nw, ksize, has_bias, segs, chain = ctx.meta
+        n, gx, gy, gz, cin = x.shape
+        taps = ksize ** 3
+        wsinks, bsinks = ctx.sinks
+        xp = split3(x, None, 3, _X_P)[1]
+        n3 = 3 * n
+        slices = query("conv3d_wgrad_slices", n3, gx, gy, gz, cin, rows_total, rows_total, ksize, BF16)
+        gwp = torch.empty((slices, taps, rows_total, cin), dtype=torch.float32, device=x.device)
+        ws, mask_ready = _wgrad_workspace(x.device, (n3, gx, gy, gz, ksize, None),
+                                          query("conv3d_wgrad_workspace_bytes", n3, gx, gy, gz, cin, rows_total, rows_total, ksize, BF16))
+        call("conv3d_wgrad", _p(xp), _p(dyp), _p(gwp), 0, n3, gx, gy, gz, cin, rows_total, rows_total, ksize, BF16, 2 if mask_ready else 0, _p(ws), _s())
+        res = _deliver_wgrad(weights, wsinks, bsinks, gwp, None, 0, slices, rows_total, cin, taps, False, False, False)
+        gbs = _deliver_bias_x3(dy.reshape(-1, rows_total), weights, bsinks) if has_bias else tuple([None] * nw)
+        return (*res[:nw], *gbs)
 
     @staticmethod
     def _wgrad(ctx, x, dy, weights):
@@ -936,6 +1032,22 @@ def _deliver_wgrad(weights, wsinks, bsinks, gwp, gb, bias_part, slices, rows_tot
             gbs.append(gb[row:row + w.shape[0]].clone())
         row += w.shape[0]
     return (*gws, *gbs)
+
+
+def _deliver_bias_x3(dy2d, weights, bsinks):
+    """Bias gradients of a (possibly fused multi-weight) GEMM from the fp32 column sums of dy: into the sinks, or handed back."""
+    gb = column_sum_f32(dy2d)
+    out, row = [], 0
+    for i, w in enumerate(weights):
+        part = gb[row:row + w.shape[0]]
+        if bsinks[i] is not None:
+            bsinks[i].slot.add_(part)
+            bsinks[i].notify()
+            out.append(None)
+        else:
+            out.append(part.clone())
+        row += w.shape[0]
+    return tuple(out)
 
 
 def _on_wgrad_stream(device, tensors, sinks_complete, fn):
@@ -1076,6 +1188,30 @@ def conv_rows_wgrad(x, dy, weights, biases, rows_total, ksize, plan, k, sinks=No
     return _deliver_wgrad(weights, wsinks, bsinks, gwp, gb, ws.data_ptr(), slices, rows_total, cin, taps, has_bias, direct_bias, defer_bias)
 
 
+def conv_rows_wgrad_x3(x, dy, weights, biases, rows_total, ksize, plan, k, sinks=None):
+    """bf16x3 form of conv_rows_wgrad (one weight): the three split products dy_hi (x) x_hi, dy_hi (x) x_lo, dy_lo (x) x_hi as three bf16
+    row-list launches whose slice partials are summed together by the usual delivery; bias gradient = fp32 column sum of dy (zero outside
+    the list)."""
+    rows, nrows = plan.rows(k)
+    if nrows == 0 or len(weights) != 1:
+        return conv_rows_wgrad(x, dy, weights, biases, rows_total, ksize, plan, k, sinks)
+    cin = x.shape[-1]
+    taps = ksize ** 3
+    wsinks, bsinks = sinks if sinks is not None else ([_sink(w) for w in weights], [_sink(b) for b in biases])
+    has_bias = biases[0] is not None
+    xpl = split3(x, None, 2, 0b10)[1]          # [hi ; lo]
+    dpl = split3(dy, None, 2, 0b10)[1]
+    slices = lib.query("conv3d_wgrad_slices", 1, nrows, 1, 1, cin, rows_total, rows_total, ksize, BF16)
+    gwp = torch.empty((3 * slices, taps, rows_total, cin), dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(256, slices * rows_total * 4), dtype=torch.uint8, device=x.device)
+    for j, (di, xi) in enumerate(((0, 0), (0, 1), (1, 0))):
+        call("conv3d_wgrad_rows", _p(xpl[xi]), _p(dpl[di]), gwp[j * slices].data_ptr(), 0, rows, nrows, plan.nseg, plan.dims_ptr, cin, rows_total,
+             rows_total, ksize, BF16, 0, _p(ws), _s())
+    res = _deliver_wgrad(weights, wsinks, bsinks, gwp, None, 0, 3 * slices, rows_total, cin, taps, False, False, False)
+    gbs = _deliver_bias_x3(dy.reshape(-1, rows_total), weights, bsinks) if has_bias else (None,)
+    return (res[0], *gbs)
+
+
 class ConeHeadFn(torch.autograd.Function):
     """The whole RPN head in training -- conv_depth x [Conv3d k3 + ReLU] + the fused cls / bbox GEMM over all pyramid levels + the
     reference's flatten (anchor.py:RPNHead, rpn.py:105-130) -- evaluated on the sampled-anchor cones of ``plan`` only: layer i (0-based,
@@ -1106,11 +1242,17 @@ class ConeHeadFn(torch.autograd.Function):
         from .model.hip_nn import _pack_of
         hs, ops_w = [x0], []
         need_dgrad = any(f.requires_grad for f in feats)
+        x3 = SPLIT3[0] and dt == torch.float32 and C % 32 == 0      # bf16x3: the 3x3x3 layers multiply split operands (the output GEMM stays fp32)
         for i, cv in enumerate(convs):
             wp, wpd = _pack_of(cv).get([cw[i]], dt, C, True, C)
             bias = cb[i].detach().float().contiguous() if cb[i] is not None else None
             y = torch.empty((V, C), dtype=dt, device=dev)
-            conv_rows_fwd(hs[-1], wp, bias, y, plan, D - 1 - i, C, C, C, 3, CONV_RELU)
+            if x3:
+                wp, wpd = _x3_weights(_pack_of(cv), [cw[i]], wp, wpd)
+                # (rows outside the cone hold whatever the allocator left: split like the rest, never read by a listed row's taps)
+                conv_rows_fwd(split3(hs[-1], _ACT_I)[0], wp, bias, y, plan, D - 1 - i, 3 * C, C, C, 3, CONV_RELU)
+            else:
+                conv_rows_fwd(hs[-1], wp, bias, y, plan, D - 1 - i, C, C, C, 3, CONV_RELU)
             hs.append(y)
             ops_w.append(wpd)
         rows_total = head.head_rows
@@ -1139,6 +1281,7 @@ class ConeHeadFn(torch.autograd.Function):
             off += c * A
         ctx.save_for_backward(*hs, *ops_w, wpdo, *cw, *[b for b in cb if b is not None], *ow, *[b for b in ob if b is not None])
         ctx.meta = (plan, head, A, dw, L, D, n, C, dt, rows_total, [b is not None for b in cb], [b is not None for b in ob], need_dgrad)
+        ctx.x3 = x3
         # gradient sinks are attributes of the Parameter objects: looked up here, on the objects the caller passed (as ConvFn does)
         ctx.sinks = ([_sink(w) for w in cw], [_sink(b) for b in cb], [_sink(w) for w in ow], [_sink(b) for b in ob])
         return logits, deltas
@@ -1192,22 +1335,34 @@ class ConeHeadFn(torch.autograd.Function):
             for l in range(L):
                 g = plan.grids[l]
                 g_feats[l] = dh[plan.level_start[l]:plan.level_start[l + 1]].view(n, g[0], g[1], g[2], C)
+        x3 = getattr(ctx, "x3", False)
+        rows_wgrad = conv_rows_wgrad_x3 if x3 else conv_rows_wgrad
         for i in range(D - 1, -1, -1):
             k = D - 1 - i
             x_i, dy_i = hs[i], dh
             res = _on_wgrad_stream(dev, [x_i, dy_i, plan.lists], sinks_ok([cws[i]], [cbs[i]], [cb[i]]),
-                                   lambda x_i=x_i, dy_i=dy_i, i=i, k=k: conv_rows_wgrad(x_i, dy_i, [cw[i]], [cb[i]], C, 3, plan, k, ([cws[i]], [cbs[i]])))
+                                   lambda x_i=x_i, dy_i=dy_i, i=i, k=k: rows_wgrad(x_i, dy_i, [cw[i]], [cb[i]], C, 3, plan, k, ([cws[i]], [cbs[i]])))
             g_cw[i] = res[0]
             g_cb[i] = res[1] if len(res) > 1 else None
+            dhs = split3(dh, _ACT_I)[0] if (x3 and (i > 0 or need_dgrad)) else None      # bf16x3: the dgrad launches read the split gradient
             if i > 0:
                 dprev = torch.zeros((V, C), dtype=dt, device=dev)
-                conv_rows_fwd(dh, wpds[i], None, dprev, plan, k + 1, C, C, C, 3, 0, mask=hs[i])
+                if x3:       # fp32 rows out of bf16 operands take no epilogue mask: the layer's ReLU backward is one elementwise pass
+                    raw = torch.zeros((V, C), dtype=dt, device=dev)
+                    conv_rows_fwd(dhs, wpds[i], None, raw, plan, k + 1, 3 * C, C, C, 3, 0)
+                    call("relu_backward", _p(hs[i]), _p(raw), _p(dprev), raw.numel(), _dt(raw), _s())
+                else:
+                    conv_rows_fwd(dh, wpds[i], None, dprev, plan, k + 1, C, C, C, 3, 0, mask=hs[i])
                 dh = dprev
             elif need_dgrad:
                 # first layer: its input gradient goes to the FPN output convs of every level -- dense, per level (halo kernel on the
                 # finest grid); dh is zero outside S_{D-1}
                 for l, c in enumerate(plan.cells):
                     g = plan.grids[l]
+                    if x3:
+                        dyl = dhs[plan.level_start[l]:plan.level_start[l + 1]].view(n, g[0], g[1], g[2], 3 * C)
+                        g_feats[l] = _conv_fwd(dyl, wpds[0], None, C, C, 3, 0, torch.float32)
+                        continue
                     dyl = dh[plan.level_start[l]:plan.level_start[l + 1]].view(n, g[0], g[1], g[2], C)
                     g_feats[l] = _conv_fwd(dyl, wpds[0], None, C, C, 3, 0, dt)
         return (None, None, None, None, *g_feats, *g_cw, *g_cb, *g_ow)

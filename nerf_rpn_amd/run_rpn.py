@@ -7,7 +7,7 @@ the HIP kernels, multi-GPU training is one process per GPU with ``engine.FlatTra
 all-reduce overlapped with backward, fused clip + AdamW) instead of DDP + torch.optim, and the per-iteration
 barrier + 4 scalar all-reduces of the reference become one fused all-reduce at logging time.
 
-Extra flags (not in the reference): ``--dtype {fp32,bf16}`` (default bf16 for train/benchmark, fp32 for eval), ``--fix_obb_clip``.
+Extra flags (not in the reference): ``--dtype {fp32,bf16,bf16x3}`` (default bf16 for train/benchmark, fp32 for eval), ``--fix_obb_clip``.
 """
 import argparse
 import glob
@@ -97,7 +97,9 @@ def build_parser():
     p.add_argument('--save_results_path', default='', help='The path to save features')
     p.add_argument('--output_all', action='store_true', help='Output proposals for train/val/test set in inference.')
     # --- extras of this implementation
-    p.add_argument('--dtype', choices=['fp32', 'bf16'], default=None, help='Compute dtype of the HIP conv path (default: bf16 for train/benchmark, fp32 for eval).')
+    p.add_argument('--dtype', choices=['fp32', 'bf16', 'bf16x3'], default=None,
+                   help='Compute dtype of the HIP conv path (default: bf16 for train/benchmark, fp32 for eval).  bf16x3 = fp32 tensors, 3x3x3 convs as '
+                        'three bf16 MFMA products of split operands: fp32-grade results (the reference tolerances) at 2-3x the fp32 speed.')
     p.add_argument('--fix_obb_clip', action='store_true', help='Drop scores/levels together with out-of-grid OBBs (fixes reference quirk B3).')
     return p
 
@@ -140,6 +142,8 @@ class Trainer:
             rpn_batch_size_per_mesh=args.rpn_batch_size_per_mesh, rpn_positive_fraction=args.rpn_positive_fraction,
             rpn_score_thresh=args.rpn_score_thresh, rotated_bbox=args.rotated_bbox, reg_loss_type=args.reg_loss_type,
             compute_dtype=torch.bfloat16 if dtype == 'bf16' else torch.float32)
+        if dtype == 'bf16x3':
+            self.model.set_compute_dtype('bf16x3')
         self.model.rpn.fix_obb_clip = args.fix_obb_clip
         self.model.rpn.loss_2d_requires_grad = args.reg_loss_weight_2d != 0
         if args.check_arch:
@@ -372,6 +376,10 @@ def _make_logger(name, args, to_console=True):
 
 def main_worker(proc, nprocs, args, gpu_ids, init_method, trainer_cls=None):
     torch.cuda.set_device(gpu_ids[proc])
+    from .affinity import pin_rank
+    pin = pin_rank(proc, nprocs, gpu_ids)       # each rank's enqueue thread on its own cores, next to its GPU's NUMA node (NRPN_PIN=0: off)
+    if pin.get("pinned"):
+        logging.info(f'rank {proc}: GPU {gpu_ids[proc]} pinned to cores {pin["cores"][0]}-{pin["cores"][1]} (NUMA node {pin["numa_node"]})')
     dist.init_process_group(backend='nccl', init_method=init_method, world_size=nprocs, rank=proc,
                             device_id=torch.device('cuda', gpu_ids[proc]))
     trainer = (trainer_cls or Trainer)(args, proc, nprocs, gpu_ids[proc], _make_logger(f'worker_{proc}', args))

@@ -352,6 +352,8 @@ def main(argv=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     if world > 1:
+        from .affinity import pin_rank
+        pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))      # NRPN_PIN=0: off
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     trainer = Trainer(args, rank, world, local, logger)

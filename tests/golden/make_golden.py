@@ -278,15 +278,20 @@ def gen_cli():
 
 
 SWIN_S = dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24])      # run_rpn.py:283
+# every --backbone_type of the reference CLI (run_rpn.py:274-292)
+SWIN_VARIANTS = {"swin": SWIN_S, "swin_s": SWIN_S,
+                 "swin_t": dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24]),
+                 "swin_b": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24]),
+                 "swin_l": dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48])}
 
 
 def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
-    if kw.get("backbone") == "swin":
+    if str(kw.get("backbone")).startswith("swin"):
         bb = SwinTransformer_FPN(patch_size=[4, 4, 4], window_size=[4, 4, 4], stochastic_depth_prob=kw.get("sd", 0.1), expand_dim=True,
-                                 **SWIN_S)
+                                 **SWIN_VARIANTS[kw["backbone"]])
     else:
         bb = ResNet_FPN_256(Bottleneck, [3, 4, 6, 3], input_dim=4, is_max_pool=True) if kw.get("backbone") == "resnet" \
-            else VGG_FPN("EF", 4, True, resolution)
+            else VGG_FPN("AF" if kw.get("backbone") == "vgg_AF" else "EF", 4, True, resolution)
     hd = R_anchor.RPNHead(256, 13, 4, rotate=rotated)
     seeded_state(bb, 1); seeded_state(hd, 2)
     return NeRFRegionProposalNetwork(bb, ref_anchor_gen(), hd, rpn_pre_nms_top_n_train=2500, rpn_pre_nms_top_n_test=kw.get("pre", 2500),
@@ -296,10 +301,11 @@ def build_ref(rotated, resolution, reg_loss="smooth_l1", **kw):
 
 
 def build_oracle(rotated, resolution, reg_loss="smooth_l1", **kw):
-    if kw.get("backbone") == "swin":
-        bb = ON.SwinFPN(SWIN_S["embed_dim"], SWIN_S["depths"], SWIN_S["num_heads"], kw.get("sd", 0.1))
+    if str(kw.get("backbone")).startswith("swin"):
+        v = SWIN_VARIANTS[kw["backbone"]]
+        bb = ON.SwinFPN(v["embed_dim"], v["depths"], v["num_heads"], kw.get("sd", 0.1))
     else:
-        bb = ON.ResNetFPN() if kw.get("backbone") == "resnet" else ON.VGGFPN("EF", 4, resolution)
+        bb = ON.ResNetFPN() if kw.get("backbone") == "resnet" else ON.VGGFPN("AF" if kw.get("backbone") == "vgg_AF" else "EF", 4, resolution)
     hd = ON.RPNHead(256, 13, 4, rotated)
     seeded_state(bb, 1); seeded_state(hd, 2)
     return OR.Detector(bb, OR.RPN(hd, rotated=rotated, reg_loss_type=reg_loss, pre_nms_top_n=kw.get("pre", 2500),
@@ -329,15 +335,34 @@ def gen_eval():
              # swin_s: token grids 20x14x12 -> 10x7x6 -> 5x4x3 -> 3x2x2: window padding on every stage, a stage whose
              # shift applies to one axis only (padded 8x4x4), and odd sizes in the patch merging
              ("eval_swin_obb", True, 160, [(80, 56, 48)], {"backbone": "swin"}),
-             ("eval_swin_aabb_batch2", False, 160, [(64, 64, 48), (48, 40, 40)], {"backbone": "swin"})]
+             ("eval_swin_aabb_batch2", False, 160, [(64, 64, 48), (48, 40, 40)], {"backbone": "swin"}),
+             # round 5: the remaining --backbone_type choices of the CLI (run_rpn.py:274-292), each compared once:
+             # VGG11-"AF" (two extra pools: five stages), Swin-T (depth 6 third stage), Swin-B (embed 128: channel widths 128..1024, 64-byte
+             # K-step rows), Swin-L (embed 192, heads 6/12/24/48)
+             ("eval_vgg_af_obb", True, 160, [(48, 40, 32)], {"backbone": "vgg_AF"}),
+             ("eval_swin_t_obb", True, 160, [(64, 56, 48)], {"backbone": "swin_t"}),
+             # swin_b: the reference's own table (embed 128, heads 3/6/12/24) does not run -- its attention reshape raises; recorded as such
+             ("eval_swin_b_obb", True, 160, [(64, 56, 48)], {"backbone": "swin_b", "expect_reference_error": True}),
+             ("eval_swin_l_aabb", False, 160, [(64, 48, 48)], {"backbone": "swin_l"})]
     only = os.environ.get("GOLDEN_ONLY")
     for name, rot, res, shapes, kw in cases:
         if only and only not in name:
             continue
         ref = build_ref(rot, res, **kw).eval()
+        xs = [scene(s, 100 + i) for i, s in enumerate(shapes)]
+        if kw.get("expect_reference_error"):
+            import json
+            try:
+                with torch.no_grad():
+                    ref([x.clone() for x in xs])
+                raise AssertionError(f"{name}: the reference was expected to fail")
+            except RuntimeError as e:
+                rec = {"backbone_type": kw["backbone"], "shapes": shapes, "reference_raises": type(e).__name__, "message": str(e).splitlines()[0]}
+                json.dump(rec, open(os.path.join(HERE, name + "_reference_failure.json"), "w"), indent=1)
+                print(f"   {name}: the reference raises {rec['reference_raises']}: {rec['message']}")
+            continue
         orc = build_oracle(rot, res, **kw)
         orc.backbone.eval()
-        xs = [scene(s, 100 + i) for i, s in enumerate(shapes)]
         with torch.no_grad():
             (feats, props, lvls), _, scores = ref([x.clone() for x in xs])
             (ofeats, oprops, olvls), _, oscores, aux = orc([x.clone() for x in xs])

@@ -141,3 +141,37 @@ def test_host_side_geometry_helpers():
     assert tuple(rs.shape) == (4, 7, 6, 5)
     import pickle
     assert pickle.loads(pickle.dumps(rs)).alpha_mode == 1                              # travels through DataLoader workers
+
+
+def test_rank_to_core_pinning_plan():
+    """affinity.plan: every local rank gets its own contiguous share of the cores of its GPU's NUMA node; without topology the allowed cores
+    are divided evenly; shares never overlap and never leave the allowed set (VERDICT r4 #6)."""
+    from nerf_rpn_amd import affinity
+    allowed = list(range(0, 128))
+    numa = {0: 0, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1, 6: 1, 7: 1}
+    cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    shares = [affinity.plan(r, 8, allowed=allowed, numa_of=numa.get, cpus_of=cpus.get) for r in range(8)]
+    for r, (cores, node) in enumerate(shares):
+        assert node == numa[r] and len(cores) == 16 and cores == list(range(cores[0], cores[0] + 16))
+        assert set(cores) <= set(cpus[node])
+    flat = [c for cores, _ in shares for c in cores]
+    assert len(flat) == len(set(flat)) == 128
+    # no topology: even split of what the process may use (a cgroup-limited container: 24 cores, 8 ranks)
+    shares = [affinity.plan(r, 8, allowed=list(range(8, 32)), numa_of=lambda d: None, cpus_of=lambda n: None) for r in range(8)]
+    assert [c for cores, _ in shares for c in cores] == list(range(8, 32)) and all(node is None for _, node in shares)
+    # fewer cores than ranks: ranks share, nobody is left without a core
+    shares = [affinity.plan(r, 8, allowed=[0, 1, 2], numa_of=lambda d: None, cpus_of=lambda n: None) for r in range(8)]
+    assert all(len(cores) == 1 and cores[0] in (0, 1, 2) for cores, _ in shares)
+    # a single rank is never pinned (bench.py's cpu_baseline leg uses every core)
+    assert affinity.pin_rank(0, 1)["pinned"] is False
+
+
+def test_swin_b_of_the_reference_cli_is_rejected_like_the_reference_rejects_it():
+    """run_rpn.py:284 lists swin_b as embed_dim 128 with heads [3, 6, 12, 24]; 128 is not divisible by 3, and the reference's attention
+    (feature_extractor.py:446, qkv.reshape(..., 3, heads, C // heads)) raises on the first forward.  Here construction fails with a message
+    that says so (VERDICT r4 #9: every --backbone_type has been compared with the reference once -- for swin_b the comparison is 'both fail')."""
+    import pytest
+    from nerf_rpn_amd.model.feature_extractor import SwinTransformer_FPN
+    with pytest.raises(ValueError, match="not divisible"):
+        SwinTransformer_FPN(patch_size=[4, 4, 4], embed_dim=128, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=[4, 4, 4],
+                            stochastic_depth_prob=0.1, expand_dim=True)

@@ -562,6 +562,35 @@ def test_two_threads_with_different_plans_share_no_state(dev):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("n,grid,cin,cout", [(1, (40, 40, 40), 256, 256), (1, (37, 42, 29), 128, 256), (2, (12, 16, 19), 384, 512), (1, (9, 8, 8), 128, 264)])
+def test_halo_kernel_cross_chunk_tap_pairing_and_fp32_rows(n, grid, cin, cout, dev):
+    """Round 5: (a) nrpn_conv_opts.halo_pairing = 1 pairs the taps of the halo kernel across channel-chunk boundaries (54 full K-steps per four
+    chunks instead of 4 x 14 with a half-empty one).  Every accumulator still meets the (chunk, tap, channel half) products in the same order,
+    so the outputs must be BIT-IDENTICAL to the classic K order -- plain, with scale / mask, and the statistics partials.  (b) the fp32-row
+    epilogue (NRPN_CONV_OUT_F32 on the halo form, used by the bf16x3 parity mode): rounded to bf16 it is the bf16 output exactly, and it
+    agrees with the 128-row kernel's fp32 rows to fp32 summation-order error."""
+    from nerf_rpn_amd import lib, ops
+    x, wp, bias = _conv_case(dev, n, grid, cin, cout, seed=cin + grid[0])
+    scale = torch.rand(cout, device=dev) + 0.5
+    mask = torch.randn(n, *grid, cout, device=dev).bfloat16()
+    for kw in (dict(), dict(scale=scale), dict(mask=mask)):
+        flags = lib.CONV_RELU if "mask" not in kw else 0
+        a = ops._conv_fwd(x, wp, bias, cout, cout, 3, flags, torch.bfloat16, tile=lib.TILE_HALO, halo_pairing=2, **kw)
+        b = ops._conv_fwd(x, wp, bias, cout, cout, 3, flags, torch.bfloat16, tile=lib.TILE_HALO, halo_pairing=1, **kw)
+        assert torch.equal(a, b), (list(kw), (a.float() - b.float()).abs().max().item())
+    sa, sb = {}, {}
+    ya = ops._conv_fwd(x, wp, bias, cout, cout, 3, 0, torch.bfloat16, stats=sa, tile=lib.TILE_HALO, halo_pairing=2)
+    yb = ops._conv_fwd(x, wp, bias, cout, cout, 3, 0, torch.bfloat16, stats=sb, tile=lib.TILE_HALO, halo_pairing=1)
+    assert torch.equal(ya, yb) and torch.equal(sa["partials"], sb["partials"])
+    for pairing in (2, 1):
+        for kw in (dict(), dict(scale=scale)):
+            f = ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU, torch.float32, tile=lib.TILE_HALO, halo_pairing=pairing, **kw)
+            h = ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU, torch.bfloat16, tile=lib.TILE_HALO, halo_pairing=pairing, **kw)
+            assert f.dtype == torch.float32 and torch.equal(f.bfloat16(), h), (pairing, list(kw))
+            g = ops._conv_fwd(x, wp, bias, cout, cout, 3, lib.CONV_RELU, torch.float32, tile=lib.TILE_128, **kw)
+            assert (f - g).abs().max().item() <= 2e-5 * g.abs().max().item() + 1e-6, (pairing, (f - g).abs().max().item(), g.abs().max().item())
+
+
 @pytest.mark.parametrize("n,grid,cin,cout", [(1, (40, 40, 40), 256, 256), (1, (37, 42, 29), 256, 256), (2, (12, 16, 19), 128, 512), (1, (9, 8, 8), 64, 264)])
 def test_halo_form_of_the_3x3x3_kernel(n, grid, cin, cout, dev):
     """conv_halo_kernel (4 x 8 x 8 voxel blocks, input halo staged once per 32-channel chunk, slot-major LDS tiles; nrpn_conv_opts.tile =
@@ -599,3 +628,60 @@ def test_halo_form_of_the_3x3x3_kernel(n, grid, cin, cout, dev):
         got = ops._conv_fwd(xx, wpp, None, cout, cout, 3, 0, torch.bfloat16, tile=lib.TILE_HALO).float().cpu()
         ref = F.conv3d(cf(xx.float().cpu()), ww.bfloat16().float().cpu(), padding=1)
         assert relerr(cf(got), ref) < 1e-2
+
+
+def test_split_bf16x3_operands(dev):
+    """nrpn_split_bf16x3: hi = bf16(x), lo = bf16(x - hi); hi + lo reproduces x to 2^-16 relative; the interleaved segments and the planes hold
+    hi / lo where the pattern bits say."""
+    from nerf_rpn_amd import ops
+    torch.manual_seed(3)
+    x = (torch.randn(5, 7, 64, device=dev) * torch.logspace(-6, 6, 64, device=dev)).contiguous()
+    inter, planes = ops.split3(x, 0b100, 3, 0b010)
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    assert inter.shape == (5, 7, 192) and planes.shape == (3, 5, 7, 64)
+    assert torch.equal(inter[..., :64], hi) and torch.equal(inter[..., 64:128], hi) and torch.equal(inter[..., 128:], lo)
+    assert torch.equal(planes[0], hi) and torch.equal(planes[1], lo) and torch.equal(planes[2], hi)
+    rec = hi.double() + lo.double()
+    assert ((rec - x.double()).abs() <= 2.0 ** -16 * x.double().abs()).all()
+    only_planes = ops.split3(x, None, 2, 0b10)
+    assert only_planes[0] is None and torch.equal(only_planes[1][0], hi) and torch.equal(only_planes[1][1], lo)
+
+
+@pytest.mark.parametrize("n,grid,cin,cout,relu", [(2, (7, 6, 5), 64, 96, True), (1, (5, 5, 5), 128, 256, False), (1, (12, 16, 19), 256, 256, True),
+                                                  (1, (20, 20, 20), 256, 512, True)])
+def test_bf16x3_conv_is_fp32_grade(n, grid, cin, cout, relu, dev):
+    """The bf16x3 mode (ops.SPLIT3) of ConvFn -- forward, input gradient, weight gradient (three planes on the batch axis), bias gradient (fp32
+    column sums) -- against torch fp32 on the CPU at the tolerance the exact-fp32 MFMA kernels are held to (test_conv_forward_backward: 2e-5
+    of the tensor's maximum; 3e-5 here: the dropped lo*lo term adds 2^-16 per product to the fp32 accumulation error), and against the
+    HIP fp32 kernels themselves.  Shapes: 64-column / 128-row tiles, the K-sliced 256x256 tile (20^3), a ragged small grid."""
+    from nerf_rpn_amd import ops
+    from nerf_rpn_amd.model import hip_nn
+    torch.manual_seed(cin + cout)
+    conv = nn.Conv3d(cin, cout, 3, padding=1)
+    x = torch.randn(n, cin, *grid)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    yr = F.relu(yr) if relu else yr
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    ref = dict(y=yr.detach(), dx=xr.grad, dw=conv.weight.grad.clone(), db=conv.bias.grad.clone())
+    out = {}
+    for mode in (False, True):
+        h = nn.Conv3d(cin, cout, 3, padding=1).to(dev)
+        h.load_state_dict(conv.state_dict())
+        xh = cl(x).to(dev).requires_grad_(True)
+        ops.SPLIT3[0] = mode
+        try:
+            yh = hip_nn.conv3d(h, xh, relu=relu)
+            yh.backward(cl(gy).to(dev))
+            torch.cuda.synchronize()
+        finally:
+            ops.SPLIT3[0] = False
+        assert yh.dtype == torch.float32 and xh.grad.dtype == torch.float32
+        out[mode] = dict(y=cf(yh.detach().cpu()), dx=cf(xh.grad.cpu()), dw=h.weight.grad.cpu(), db=h.bias.grad.cpu())
+    for k in ("y", "dx", "dw", "db"):
+        e32, e3, e = relerr(out[False][k], ref[k]), relerr(out[True][k], ref[k]), relerr(out[True][k], out[False][k])
+        print(f"[bf16x3] {cin}->{cout}@{grid} {k}: fp32 kernel {e32:.2e}, bf16x3 {e3:.2e} vs torch fp32; bf16x3 vs fp32 kernel {e:.2e}")
+        assert e3 < 3e-5, (k, e3, e32)
+        assert e < 3e-5, (k, e)

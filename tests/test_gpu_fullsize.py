@@ -28,16 +28,23 @@ def _ingest(g, dev, dtype):
     return ops.ingest_rgbsigma(raw, alpha_mode=1 if bool(g["normalize_density"]) else 0, dtype=dtype)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", CASES)
-def test_fullsize_fp32_matches_reference(name, golden, dev):
-    from nerf_rpn_amd import lib
+def test_fullsize_fp32_matches_reference(name, mode, golden, dev):
+    """mode bf16x3 (round 5): the same fixtures at the same fp32 tolerances with the 3x3x3 convolutions on split-bf16 operands -- at these sizes
+    the halo kernel's fp32-row epilogue, the K-sliced 256x256 tile and the 128-row kernel with a tripled K axis."""
+    from nerf_rpn_amd import lib, ops
     g = golden(name)
     X, Y, Z = [int(v) for v in g["shape"]]
     m = build(True, 160, dev).eval()
-    with torch.no_grad():
-        (feats, props, lvls), losses, scores = m([_ingest(g, dev, torch.float32)])
+    try:
+        m.set_compute_dtype(mode)
+        with torch.no_grad():
+            (feats, props, lvls), losses, scores = m([_ingest(g, dev, torch.float32)])
+    finally:
+        ops.SPLIT3[0] = False
     assert losses == {}
-    assert_eval_matches(name, g, feats, props, lvls, scores, 1, dev, m.rpn.last_aux, [(X, Y, Z)])
+    assert_eval_matches(name, g, feats, props, lvls, scores, 1, dev, m.rpn.last_aux, [(X, Y, Z)], mode)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -87,3 +87,52 @@ def test_swin_steps_are_bit_reproducible_with_the_weight_gradient_stream(golden,
     assert a[0] == b[0]
     for x, y in zip(a[1], b[1]):
         assert torch.equal(x, y), (x - y).abs().max().item()
+
+
+def test_a_second_trainer_invalidates_the_captures_and_a_second_forward_runs_eagerly(golden, dev):
+    """a capture bakes in the FlatTrainer's arena addresses.  (1) A second trainer on the same model (resume, a new
+    optimiser) must drop the captures: its gradient arena has to receive the trunk's gradients -- equal, bit for bit, to an eager run under
+    the same second trainer.  (2) Two trunk forwards before one backward (loss(A) + loss(B)): the second pass must not overwrite the first
+    pass' captured activations -- it runs eagerly, and the summed gradients equal the all-eager ones."""
+    from nerf_rpn_amd.engine import FlatTrainer
+    g = golden("train_obb")
+    shape = tuple(int(v) for v in g["shapes"][0])
+    gts = [T(g["gt0"], dev)]
+    pos, neg = T(g["pos_idx"], dev), T(g["neg_idx"], dev)
+
+    def run(use_graph):
+        m = build(True, 160, dev, backbone="vgg", sd=0.0).train()
+        m.set_compute_dtype(torch.bfloat16)
+        m.use_graph = use_graph
+        m.rpn.sampler_hook = lambda labels: (pos, neg)
+        tr = FlatTrainer(m, lr=3e-4, weight_decay=0.01, clip_grad_norm=0.1)
+
+        def one(tr_, seed):
+            _, l, _ = m([scene(shape, seed).to(dev)], gts)
+            (l["loss_objectness"] + 5.0 * l["loss_rpn_box_reg"]).backward()
+            torch.cuda.synchronize()
+            ga = tr_.g_arena.clone()
+            tr_.step()
+            return ga
+        for it in range(4):                       # 2 eager warm-ups, the capture, a replay
+            one(tr, 200 + it)
+        captured_before = 0 if m._trunk is None else len(m._trunk.captured)
+        tr2 = FlatTrainer(m, lr=3e-4, weight_decay=0.01, clip_grad_norm=0.1)      # new arenas, new sinks
+        arenas = [one(tr2, 300 + it) for it in range(4)]
+        old_arena_touched = float(tr.g_arena.abs().max())          # the first trainer's arena (AdamW cleared it) must stay untouched
+        # two forwards, one backward
+        _, la, _ = m([scene(shape, 400).to(dev)], gts)
+        _, lb, _ = m([scene(shape, 401).to(dev)], gts)
+        (la["loss_objectness"] + 5.0 * la["loss_rpn_box_reg"] + lb["loss_objectness"] + 5.0 * lb["loss_rpn_box_reg"]).backward()
+        torch.cuda.synchronize()
+        both = tr2.g_arena.clone()
+        fallbacks = 0 if m._trunk is None else m._trunk.eager_fallbacks
+        return captured_before, arenas, old_arena_touched, both, fallbacks, (0 if m._trunk is None else len(m._trunk.captured))
+
+    eager, graph = run(False), run(True)
+    assert graph[0] == 1 and graph[5] == 1            # captured under the first trainer, re-captured (once) under the second
+    assert graph[2] == 0.0, "a replay under the second trainer wrote into the first trainer's gradient arena"
+    for i, (a, b) in enumerate(zip(eager[1], graph[1])):
+        assert float(b.abs().max()) > 0 and torch.equal(a, b), (i, (a - b).abs().max().item())
+    assert graph[4] == 1                              # the second forward of the pair ran eagerly
+    assert torch.equal(eager[3], graph[3]), (eager[3] - graph[3]).abs().max().item()
