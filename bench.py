@@ -682,6 +682,21 @@ def main():
             s32()
         torch.cuda.synchronize()
         extras["fp32_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / 5, 3)
+        # (b') the parity-grade FAST mode: the same fp32 model, 3x3x3 convolutions on split-bf16 operands (ops.SPLIT3)
+        from nerf_rpn_amd import ops as _o3
+        _o3.SPLIT3[0] = True
+        try:
+            for _ in range(2):
+                s32()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                l3 = s32()
+            torch.cuda.synchronize()
+            extras["bf16x3_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / 8, 3)
+            extras["bf16x3_final_loss"] = round(float(l3), 5)
+        finally:
+            _o3.SPLIT3[0] = False
         del m32, tr32, s32
         torch.cuda.empty_cache()
         extras["eval_forward_protocol"] = eval_forward_protocol(args.dtype, dev)

@@ -66,64 +66,84 @@ template <> struct vecv<bf16s, 8> {
 static inline int slab_rows(long long rows) { const long long s = (rows + 1023) / 1024; return (int)(s < 64 ? 64 : s); }
 
 // MODE 0: (sum x, sum x^2)           MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * (y > 0 if relu)
-template <typename T, int MODE>
+// V channels per lane: 4, or 8 for bf16 with C % 8 == 0 (16-byte loads: half the load instructions and address arithmetic per byte; round 5 --
+// the 8-byte form ran at 0.27-0.39 of the HBM rate on the 64000-row maps).
+template <typename T, int MODE, int V>
 __global__ void __launch_bounds__(256)
 chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, long long rows, int c,
                     const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu, float *__restrict__ partial,
                     int kSlab, const float *__restrict__ gamma = nullptr, const float *__restrict__ beta = nullptr) {
-  __shared__ float red[2][256][4];
-  // channels are tiled over blockIdx.y in chunks of `cw` (<= 1024) so any C that is a multiple of 4 works
+  __shared__ float red[2][256][V];
+  // channels are tiled over blockIdx.y in chunks of `cw` (<= 1024) so any C that is a multiple of V works
   const int cw = min(c, 1024), coff = blockIdx.y * 1024;
   x += coff; y = y ? y + coff : y; dy = dy ? dy + coff : dy;
   if (MODE == 1) { mean += coff; var += coff; if (beta) { gamma += coff; beta += coff; } }
-  const int ct = min(cw, c - coff) / 4;       // channel groups of this tile (<= 256)
+  const int ct = min(cw, c - coff) / V;       // channel groups of this tile (<= 256)
   const int ty_n = 256 / ct;                  // row lanes
   const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
   const long long r0 = (long long)blockIdx.x * kSlab, r1 = min(rows, r0 + kSlab);
-  f4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-  if (ty < ty_n) {
-    f4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
-    f4 ga = {1, 1, 1, 1}, be = {0, 0, 0, 0};
-    if (MODE == 1) {
-      mu = *reinterpret_cast<const f4 *>(mean + tx * 4);
-      const f4 vv = *reinterpret_cast<const f4 *>(var + tx * 4);
+  float s0[V], s1[V];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) is[k] = 1.0f / sqrtf(vv[k] + eps);
-      if (beta) { ga = *reinterpret_cast<const f4 *>(gamma + tx * 4); be = *reinterpret_cast<const f4 *>(beta + tx * 4); }
+  for (int k = 0; k < V; ++k) { s0[k] = 0.f; s1[k] = 0.f; }
+  if (ty < ty_n) {
+    float mu[V], is[V], ga[V], be[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { mu[k] = 0.f; is[k] = 1.f; ga[k] = 1.f; be[k] = 0.f; }
+    if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        mu[k] = mean[tx * V + k];
+        is[k] = 1.0f / sqrtf(var[tx * V + k] + eps);
+        if (beta) { ga[k] = gamma[tx * V + k]; be[k] = beta[tx * V + k]; }
+      }
     }
 #pragma unroll 4
     for (long long r = r0 + ty; r < r1; r += ty_n) {
-      const f4 xv = vec4<T>::ld(x + r * c + tx * 4);
+      float xv[V];
+      vecv<T, V>::ld(x + r * c + tx * V, xv);
       if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s0[k] += xv[k]; s1[k] += xv[k] * xv[k]; }
+        for (int k = 0; k < V; ++k) { s0[k] += xv[k]; s1[k] += xv[k] * xv[k]; }
       } else {
-        f4 g = vec4<T>::ld(dy + r * c + tx * 4);
+        float g[V];
+        vecv<T, V>::ld(dy + r * c + tx * V, g);
         if (relu && beta) {   // ReLU mask recomputed from x (the bn_apply expression) instead of reading y: one tensor less
 #pragma unroll
-          for (int k = 0; k < 4; ++k) g[k] = ((xv[k] - mu[k]) * is[k] * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
+          for (int k = 0; k < V; ++k) g[k] = ((xv[k] - mu[k]) * is[k] * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
         } else if (relu) {
-          const f4 yv = vec4<T>::ld(y + r * c + tx * 4);
+          float yv[V];
+          vecv<T, V>::ld(y + r * c + tx * V, yv);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+          for (int k = 0; k < V; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s0[k] += g[k]; s1[k] += g[k] * ((xv[k] - mu[k]) * is[k]); }
+        for (int k = 0; k < V; ++k) { s0[k] += g[k]; s1[k] += g[k] * ((xv[k] - mu[k]) * is[k]); }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; }
+  for (int k = 0; k < V; ++k) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; }
   __syncthreads();
   if (threadIdx.x < ct) {
-    f4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    float a[V], b[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { a[k] = 0.f; b[k] = 0.f; }
     for (int q = 0; q < ty_n; ++q)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a[k] += red[0][q * ct + threadIdx.x][k]; b[k] += red[1][q * ct + threadIdx.x][k]; }
+      for (int k = 0; k < V; ++k) { a[k] += red[0][q * ct + threadIdx.x][k]; b[k] += red[1][q * ct + threadIdx.x][k]; }
     float *out = partial + (long long)blockIdx.x * 2 * c + coff;
-    *reinterpret_cast<f4 *>(out + threadIdx.x * 4) = a;
-    *reinterpret_cast<f4 *>(out + c + threadIdx.x * 4) = b;
+#pragma unroll
+    for (int k = 0; k < V; k += 4) {
+      *reinterpret_cast<f4 *>(out + threadIdx.x * V + k) = f4{a[k], a[k + 1], a[k + 2], a[k + 3]};
+      *reinterpret_cast<f4 *>(out + c + threadIdx.x * V + k) = f4{b[k], b[k + 1], b[k + 2], b[k + 3]};
+    }
   }
+}
+// 8 channels per lane where the shape and the pointers allow 16-byte bf16 accesses
+static inline bool chan_v8(int dtype, int c, const void *a, const void *b, const void *d) {
+  const int tile = c > 1024 ? 1024 : c;
+  return dtype == NRPN_BF16 && c % 8 == 0 && tile % 8 == 0 && 256 % (tile / 8) == 0 &&
+         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
 }
 
 // finalize: block = (64 channels, 16 partial-lanes); fp64 accumulation of the fp32 block partials
@@ -202,9 +222,14 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
   const int kSlab = slab_rows(rows);
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 0>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
-                                       (const T *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0,
-                                       (float *)workspace, kSlab));
+  if (chan_v8(dtype, c, x, nullptr, nullptr)) {
+    hipLaunchKernelGGL((chan_partial_kernel<bf16s, 0, 8>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const bf16s *)x, (const bf16s *)nullptr,
+                       (const bf16s *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0, (float *)workspace, kSlab);
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 0, 4>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)nullptr,
+                                         (const T *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0,
+                                         (float *)workspace, kSlab));
+  }
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
                      var, running_mean, running_var, momentum);
   NRPN_LAUNCH_CHECK("bn_stats");
@@ -403,8 +428,13 @@ extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, vo
   const int kSlab = slab_rows(rows);
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
-                                       (long long)rows, c, mean, var, eps, relu, (float *)workspace, kSlab, gamma, beta));
+  if (chan_v8(dtype, c, x, y, dy)) {
+    hipLaunchKernelGGL((chan_partial_kernel<bf16s, 1, 8>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const bf16s *)x, (const bf16s *)y,
+                       (const bf16s *)dy, (long long)rows, c, mean, var, eps, relu, (float *)workspace, kSlab, gamma, beta);
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1, 4>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
+                                         (long long)rows, c, mean, var, eps, relu, (float *)workspace, kSlab, gamma, beta));
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
   int fv = bn_fast_v(c, dtype);
   if (fv == 8 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15))
@@ -458,18 +488,26 @@ static inline int pool_out(int in, int k, int s, int p, int ceil_mode) {
 }
 extern "C" int nrpn_pool_out_size(int in, int k, int s, int p, int ceil_mode) { return pool_out(in, k, s, p, ceil_mode); }
 
-template <typename T, int V>
+// I = index type of the flat group / voxel arithmetic: unsigned (one 32-bit division per axis) whenever the tensors hold < 2^31 elements --
+// the 64-bit divisions of the first version were ~4x the VALU work of everything else in these kernels and bound them at a third of the HBM
+// rate (round 5) -- long long otherwise.
+template <int V> struct argpack;
+template <> struct argpack<4> { typedef unsigned int type; };
+template <> struct argpack<8> { typedef unsigned long long type; };
+
+template <typename T, int V, typename I>
 __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int8_t *__restrict__ arg, int n, int gx, int gy, int gz, int ox,
                                    int oy, int oz, int c, int k, int s, int p) {
-  const int ct = c / V;
-  const long long total = (long long)n * ox * oy * oz * ct;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(g % ct) * V;
-    long long v = g / ct;
-    const int z = (int)(v % oz); v /= oz;
-    const int yy = (int)(v % oy); v /= oy;
-    const int xx = (int)(v % ox);
-    const long long b = v / ox;
+  const I ct = (I)(c / V);
+  const I total = (I)n * ox * oy * oz * ct;
+  for (I g = (I)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (I)gridDim.x * blockDim.x) {
+    const I vox = g / ct;
+    const int cg = (int)(g - vox * ct) * V;
+    I v = vox;
+    const int z = (int)(v % (I)oz); v /= (I)oz;
+    const int yy = (int)(v % (I)oy); v /= (I)oy;
+    const int xx = (int)(v % (I)ox);
+    const long long b = (long long)(v / (I)ox);
     float best[V];
     int bi[V];
     bool first = true;
@@ -497,11 +535,13 @@ __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, i
 #pragma unroll
       for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
     }
-    const long long o = (g / ct) * (long long)c + cg;
+    const long long o = (long long)vox * c + cg;
     vecv<T, V>::st(y + o, best);
-    if (arg) {
+    if (arg) {           // V argmax codes as one 4- / 8-byte store
+      typename argpack<V>::type pk = 0;
 #pragma unroll
-      for (int q = 0; q < V; ++q) arg[o + q] = (int8_t)bi[q];
+      for (int q = 0; q < V; ++q) pk |= (typename argpack<V>::type)(unsigned char)bi[q] << (8 * q);
+      *reinterpret_cast<typename argpack<V>::type *>(arg + o) = pk;
     }
   }
 }
@@ -509,18 +549,19 @@ __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, i
 // gather form: every input voxel sums the dy of the windows whose argmax points at it (no atomics, deterministic).  Per axis the
 // windows containing coordinate x are those with offset a = (x + p) mod s, + s, + 2s, ... < k: at most ceil(k / s) candidates,
 // enumerated directly (8 for the 3/2/1 pool instead of testing all 27 offsets).
-template <typename T, int V>
+template <typename T, int V, typename I>
 __global__ void maxpool_bwd_kernel(const T *__restrict__ dy, const int8_t *__restrict__ arg, T *__restrict__ dx, int n, int gx, int gy, int gz,
                                    int ox, int oy, int oz, int c, int k, int s, int p) {
-  const int ct = c / V;
-  const long long total = (long long)n * gx * gy * gz * ct;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(g % ct) * V;
-    long long v = g / ct;
-    const int z = (int)(v % gz); v /= gz;
-    const int yy = (int)(v % gy); v /= gy;
-    const int xx = (int)(v % gx);
-    const long long b = v / gx;
+  const I ct = (I)(c / V);
+  const I total = (I)n * gx * gy * gz * ct;
+  for (I g = (I)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (I)gridDim.x * blockDim.x) {
+    const I vox = g / ct;
+    const int cg = (int)(g - vox * ct) * V;
+    I v = vox;
+    const int z = (int)(v % (I)gz); v /= (I)gz;
+    const int yy = (int)(v % (I)gy); v /= (I)gy;
+    const int xx = (int)(v % (I)gx);
+    const long long b = (long long)(v / (I)gx);
     float acc[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) acc[q] = 0.f;
@@ -537,12 +578,13 @@ __global__ void maxpool_bwd_kernel(const T *__restrict__ dy, const int8_t *__res
           const int code = (a * k + bq) * k + d;
           float gv[V];
           vecv<T, V>::ld(dy + o, gv);
+          const typename argpack<V>::type pk = *reinterpret_cast<const typename argpack<V>::type *>(arg + o);      // V codes in one load
 #pragma unroll
-          for (int q = 0; q < V; ++q) acc[q] += (arg[o + q] == code) ? gv[q] : 0.f;
+          for (int q = 0; q < V; ++q) acc[q] += ((int)((pk >> (8 * q)) & 0xff) == code) ? gv[q] : 0.f;
         }
       }
     }
-    vecv<T, V>::st(dx + (g / ct) * (long long)c + cg, acc);
+    vecv<T, V>::st(dx + (long long)vox * c + cg, acc);
   }
 }
 
@@ -551,15 +593,17 @@ extern "C" int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n,
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_fwd: bad sizes");
   NRPN_REQUIRE(x && y, "maxpool_fwd: null pointer");
   const int ox = pool_out(gx, k, s, p, ceil_mode), oy = pool_out(gy, k, s, p, ceil_mode), oz = pool_out(gz, k, s, p, ceil_mode);
+  const bool small = (long long)n * gx * gy * gz * c < (1ll << 31);      // 32-bit index arithmetic (every real shape); 64-bit beyond
+#define NRPN_POOL_FWD(T_, V_, I_) hipLaunchKernelGGL((maxpool_fwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                     (const T_ *)x, (T_ *)y, argmax, n, gx, gy, gz, ox, oy, oz, c, k, s, p)
   if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * ox * oy * oz * (c / 8);
-    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16s, 8>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const bf16s *)x, (bf16s *)y, argmax, n,
-                       gx, gy, gz, ox, oy, oz, c, k, s, p);
+    if (small) NRPN_POOL_FWD(bf16s, 8, unsigned); else NRPN_POOL_FWD(bf16s, 8, long long);
   } else {
     const long long total = (long long)n * ox * oy * oz * (c / 4);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T, 4>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)x, (T *)y,
-                                         argmax, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+    if (small) { DISPATCH_T(dtype, NRPN_POOL_FWD(T, 4, unsigned)); } else { DISPATCH_T(dtype, NRPN_POOL_FWD(T, 4, long long)); }
   }
+#undef NRPN_POOL_FWD
   NRPN_LAUNCH_CHECK("maxpool_fwd");
   return NRPN_OK;
 }
@@ -569,15 +613,17 @@ extern "C" int nrpn_maxpool3d_bwd(const void *dy, const int8_t *argmax, void *dx
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_bwd: bad sizes");
   NRPN_REQUIRE(dy && argmax && dx, "maxpool_bwd: null pointer");
   const int ox = pool_out(gx, k, s, p, ceil_mode), oy = pool_out(gy, k, s, p, ceil_mode), oz = pool_out(gz, k, s, p, ceil_mode);
+  const bool small = (long long)n * gx * gy * gz * c < (1ll << 31);
+#define NRPN_POOL_BWD(T_, V_, I_) hipLaunchKernelGGL((maxpool_bwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                     (const T_ *)dy, argmax, (T_ *)dx, n, gx, gy, gz, ox, oy, oz, c, k, s, p)
   if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * gx * gy * gz * (c / 8);
-    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16s, 8>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const bf16s *)dy, argmax, (bf16s *)dx,
-                       n, gx, gy, gz, ox, oy, oz, c, k, s, p);
+    if (small) NRPN_POOL_BWD(bf16s, 8, unsigned); else NRPN_POOL_BWD(bf16s, 8, long long);
   } else {
     const long long total = (long long)n * gx * gy * gz * (c / 4);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 4>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)dy, argmax,
-                                         (T *)dx, n, gx, gy, gz, ox, oy, oz, c, k, s, p));
+    if (small) { DISPATCH_T(dtype, NRPN_POOL_BWD(T, 4, unsigned)); } else { DISPATCH_T(dtype, NRPN_POOL_BWD(T, 4, long long)); }
   }
+#undef NRPN_POOL_BWD
   NRPN_LAUNCH_CHECK("maxpool_bwd");
   return NRPN_OK;
 }
@@ -591,64 +637,71 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
   return s < in - 1 ? s : in - 1;
 }
 
-template <typename T>
+template <typename T, int V, typename I>
 __global__ void upsample_add_fwd_kernel(T *__restrict__ fine, const T *__restrict__ coarse, int n, int fx, int fy, int fz, int cx, int cy,
                                         int cz, int c) {
-  const int ct = c / 4;
-  const long long total = (long long)n * fx * fy * fz * ct;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(g % ct) * 4;
-    long long v = g / ct;
-    const int z = (int)(v % fz); v /= fz;
-    const int y = (int)(v % fy); v /= fy;
-    const int x = (int)(v % fx);
-    const long long b = v / fx;
+  const I ct = (I)(c / V);
+  const I total = (I)n * fx * fy * fz * ct;
+  for (I g = (I)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (I)gridDim.x * blockDim.x) {
+    const I vox = g / ct;
+    const int cg = (int)(g - vox * ct) * V;
+    I v = vox;
+    const int z = (int)(v % (I)fz); v /= (I)fz;
+    const int y = (int)(v % (I)fy); v /= (I)fy;
+    const int x = (int)(v % (I)fx);
+    const long long b = (long long)(v / (I)fx);
     const long long src = (((b * cx + nearest_src(x, cx, fx)) * cy + nearest_src(y, cy, fy)) * cz + nearest_src(z, cz, fz)) * (long long)c + cg;
-    const long long dst = (g / ct) * (long long)c + cg;
-    f4 a = vec4<T>::ld(fine + dst);
-    const f4 bq = vec4<T>::ld(coarse + src);
+    const long long dst = (long long)vox * c + cg;
+    float a[V], bq[V];
+    vecv<T, V>::ld(fine + dst, a);
+    vecv<T, V>::ld(coarse + src, bq);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] += bq[k];
-    vec4<T>::st(fine + dst, a);
+    for (int k = 0; k < V; ++k) a[k] += bq[k];
+    vecv<T, V>::st(fine + dst, a);
   }
 }
 
-template <typename T>
+template <typename T, int V, typename I>
 __global__ void upsample_add_bwd_kernel(const T *__restrict__ dfine, T *__restrict__ dcoarse, int n, int fx, int fy, int fz, int cx, int cy,
                                         int cz, int c, int accumulate) {
-  const int ct = c / 4;
-  const long long total = (long long)n * cx * cy * cz * ct;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(g % ct) * 4;
-    long long v = g / ct;
-    const int z = (int)(v % cz); v /= cz;
-    const int y = (int)(v % cy); v /= cy;
-    const int x = (int)(v % cx);
-    const long long b = v / cx;
+  const I ct = (I)(c / V);
+  const I total = (I)n * cx * cy * cz * ct;
+  for (I g = (I)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (I)gridDim.x * blockDim.x) {
+    const I vox = g / ct;
+    const int cg = (int)(g - vox * ct) * V;
+    I v = vox;
+    const int z = (int)(v % (I)cz); v /= (I)cz;
+    const int y = (int)(v % (I)cy); v /= (I)cy;
+    const int x = (int)(v % (I)cx);
+    const long long b = (long long)(v / (I)cx);
     // candidate fine indices around x * fx / cx
     const int x0 = max(0, (int)((long long)x * fx / cx) - 1), x1 = min(fx - 1, (int)((long long)(x + 1) * fx / cx) + 1);
     const int y0 = max(0, (int)((long long)y * fy / cy) - 1), y1 = min(fy - 1, (int)((long long)(y + 1) * fy / cy) + 1);
     const int z0 = max(0, (int)((long long)z * fz / cz) - 1), z1 = min(fz - 1, (int)((long long)(z + 1) * fz / cz) + 1);
-    f4 acc = {0, 0, 0, 0};
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
     for (int a = x0; a <= x1; ++a) {
       if (nearest_src(a, cx, fx) != x) continue;
       for (int bq = y0; bq <= y1; ++bq) {
         if (nearest_src(bq, cy, fy) != y) continue;
         for (int d = z0; d <= z1; ++d) {
           if (nearest_src(d, cz, fz) != z) continue;
-          const f4 gv = vec4<T>::ld(dfine + ((((b * fx + a) * fy + bq) * fz + d) * (long long)c + cg));
+          float gv[V];
+          vecv<T, V>::ld(dfine + ((((b * fx + a) * fy + bq) * fz + d) * (long long)c + cg), gv);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] += gv[k];
+          for (int k = 0; k < V; ++k) acc[k] += gv[k];
         }
       }
     }
-    const long long dst = (g / ct) * (long long)c + cg;
+    const long long dst = (long long)vox * c + cg;
     if (accumulate) {
-      const f4 old = vec4<T>::ld(dcoarse + dst);
+      float old[V];
+      vecv<T, V>::ld(dcoarse + dst, old);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += old[k];
+      for (int k = 0; k < V; ++k) acc[k] += old[k];
     }
-    vec4<T>::st(dcoarse + dst, acc);
+    vecv<T, V>::st(dcoarse + dst, acc);
   }
 }
 
@@ -656,9 +709,17 @@ extern "C" int nrpn_upsample_add_fwd(void *fine, const void *coarse, int n, int 
                                      nrpn_stream_t stream) {
   NRPN_REQUIRE(n > 0 && fx > 0 && fy > 0 && fz > 0 && cx > 0 && cy > 0 && cz > 0 && c % 4 == 0, "upsample_add_fwd: bad sizes");
   NRPN_REQUIRE(fine && coarse, "upsample_add_fwd: null pointer");
-  const long long total = (long long)n * fx * fy * fz * (c / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_fwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (T *)fine,
-                                       (const T *)coarse, n, fx, fy, fz, cx, cy, cz, c));
+  const bool small = (long long)n * fx * fy * fz * c < (1ll << 31);      // 32-bit index arithmetic; bf16 with C % 8 == 0: 16-byte accesses
+#define NRPN_UP_FWD(T_, V_, I_) hipLaunchKernelGGL((upsample_add_fwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                   (T_ *)fine, (const T_ *)coarse, n, fx, fy, fz, cx, cy, cz, c)
+  if (dtype == NRPN_BF16 && c % 8 == 0) {
+    const long long total = (long long)n * fx * fy * fz * (c / 8);
+    if (small) NRPN_UP_FWD(bf16s, 8, unsigned); else NRPN_UP_FWD(bf16s, 8, long long);
+  } else {
+    const long long total = (long long)n * fx * fy * fz * (c / 4);
+    if (small) { DISPATCH_T(dtype, NRPN_UP_FWD(T, 4, unsigned)); } else { DISPATCH_T(dtype, NRPN_UP_FWD(T, 4, long long)); }
+  }
+#undef NRPN_UP_FWD
   NRPN_LAUNCH_CHECK("upsample_add_fwd");
   return NRPN_OK;
 }
@@ -667,9 +728,17 @@ extern "C" int nrpn_upsample_add_bwd(const void *dfine, void *dcoarse, int n, in
                                      int accumulate, nrpn_stream_t stream) {
   NRPN_REQUIRE(n > 0 && fx > 0 && fy > 0 && fz > 0 && cx > 0 && cy > 0 && cz > 0 && c % 4 == 0, "upsample_add_bwd: bad sizes");
   NRPN_REQUIRE(dfine && dcoarse, "upsample_add_bwd: null pointer");
-  const long long total = (long long)n * cx * cy * cz * (c / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_bwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), (const T *)dfine,
-                                       (T *)dcoarse, n, fx, fy, fz, cx, cy, cz, c, accumulate));
+  const bool small = (long long)n * fx * fy * fz * c < (1ll << 31);
+#define NRPN_UP_BWD(T_, V_, I_) hipLaunchKernelGGL((upsample_add_bwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                   (const T_ *)dfine, (T_ *)dcoarse, n, fx, fy, fz, cx, cy, cz, c, accumulate)
+  if (dtype == NRPN_BF16 && c % 8 == 0) {
+    const long long total = (long long)n * cx * cy * cz * (c / 8);
+    if (small) NRPN_UP_BWD(bf16s, 8, unsigned); else NRPN_UP_BWD(bf16s, 8, long long);
+  } else {
+    const long long total = (long long)n * cx * cy * cz * (c / 4);
+    if (small) { DISPATCH_T(dtype, NRPN_UP_BWD(T, 4, unsigned)); } else { DISPATCH_T(dtype, NRPN_UP_BWD(T, 4, long long)); }
+  }
+#undef NRPN_UP_BWD
   NRPN_LAUNCH_CHECK("upsample_add_bwd");
   return NRPN_OK;
 }

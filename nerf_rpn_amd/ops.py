@@ -740,6 +740,9 @@ def _x3_weights(pack, weights, wp, wpd):
     ent = pack.__dict__.get("x3")
     if ent is None or ent[0] != key:
         w3 = split3(wp, _W_I)[0]
+        if wpd is not None:
+            _wait_dgrad_operands()       # the trainer refreshes the dgrad operands on the weight-gradient stream (ArenaWeights.prefetch_dgrad): this
+                                         # stream reads them here, in the FORWARD pass, before the first dgrad's own wait
         wd3 = split3(wpd, _W_I)[0] if wpd is not None else None
         ent = (key, w3, wd3)
         pack.__dict__["x3"] = ent
