@@ -149,13 +149,17 @@ class ConvProbe:
         es = 2 if dtype_name == "bf16" else 4
         algo_bytes = vox * cin_ * es + vox * cout_ * es + (_k ** 3) * cin_ * cout_ * es      # x + y + w, each once
         traffic, note = None, "no PMC collection for this kernel in profiles/ (null = not measured)"
-        for pmc_name in ("r04_pmc_conv_256x256_40c.json", "r03_pmc_conv_256x256_40c.json", "r02_pmc_conv_256x256_40c.json"):
+        for pmc_name in ("r05_pmc_conv_256x256_40c.json", "r04_pmc_conv_256x256_40c.json", "r03_pmc_conv_256x256_40c.json", "r02_pmc_conv_256x256_40c.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if not (os.path.exists(pmc) and shape == (64000, 256, 256, 3)):
                 continue
             d = json.load(open(pmc))
             base = kernel.split(" ")[0]          # the counter file keys carry template arguments ("conv_halo_kernel<0>")
-            k = next((v for name, v in d.get("kernels", {}).items() if name.split("<")[0] == base), None)
+            cands = [(name, v) for name, v in d.get("kernels", {}).items() if name.split("<")[0] == base]
+            # several instantiations of the halo kernel are profiled (K orders, fp32 rows): the one this shape runs by default pairs taps
+            # across chunk boundaries (Cin >= 256) and stores bf16 rows = conv_halo_kernel<0, true, false>
+            prod = [v for name, v in cands if name.replace(" ", "").endswith("<0,true,false>")]
+            k = prod[0] if prod else (cands[0][1] if cands else None)
             if not (k and k.get("hbm_bytes") is not None):
                 continue
             # the counters describe the kernel SOURCE they were collected on: a newer conv3d.hip makes them stale, and stale is null
@@ -412,7 +416,7 @@ def secondary_workloads(dtype, dev, xs, gts, make, steps=12):
 def measured_ceiling():
     """What the MFMA array sustains at the part's power cap on the operands the conv layers multiply (tools/mfma_peak_probe.py: a
     register-only v_mfma_f32_32x32x16_bf16 loop, post-ReLU activations x small weights) -- profiles/r04_mfma_ceiling.json."""
-    path = os.path.join(ROOT, "profiles", "r04_mfma_ceiling.json")
+    path = os.path.join(ROOT, "profiles", "r04_mfma_ceiling.json")      # (round 4's measurement: the probe and the part are unchanged)
     if not os.path.exists(path):
         return None
     rows = json.load(open(path)).get("rows", [])

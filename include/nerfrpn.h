@@ -415,6 +415,11 @@ int nrpn_ingest_augment(const void *src, int src_is_u8, void *dst, int w, int l,
 int nrpn_ncdhw_to_ndhwc(const float *src, void *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
 int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, int64_t voxels, int dtype, nrpn_stream_t stream);
 int nrpn_cast(const void *src, void *dst, int64_t count, int src_dtype, int dst_dtype, nrpn_stream_t stream);
+/* Column sums of f32 x [rows][C] -> out [C] (+= when accumulate): the bias gradient of a convolution (sum of dy over the voxels; torch's
+ * Conv3d backward, feature_extractor.py:345-358) in the bf16x3 mode, where the weight-gradient launch sees split planes.  Deterministic
+ * (fixed slab order, fp64 finish).  workspace: nrpn_column_sum_workspace_bytes. */
+size_t nrpn_column_sum_workspace_bytes(int64_t rows, int c);
+int nrpn_column_sum_f32(const float *x, int64_t rows, int c, float *out, int accumulate, void *workspace, nrpn_stream_t stream);
 /* bf16x3 operands of the parity-grade fast mode: src f32 [rows][C] -> hi = bf16(x), lo = bf16(x - hi), written as an interleaved operand
  * bf16 [rows][3C] (forward / dgrad: the K axis tripled; segment s holds lo when bit s of ipattern is set, else hi -- activations 0b100,
  * weights 0b010: x*w ~ hi*whi + hi*wlo + lo*whi) and / or as nplanes planes bf16 [nplanes][rows][C] stacked on the batch axis (weight

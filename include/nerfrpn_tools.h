@@ -22,9 +22,10 @@ int nrpn_set_conv_tile_m(int bm);
 /* tools-only default: 1 (default) = the halo form (NRPN_TILE_HALO) is chosen automatically where it applies (bf16 3x3x3, Cout >= 256, grids its
  * 4x8x8 blocks cover with <= 12 % waste and >= 200 workgroups), 0 = only on request */
 int nrpn_set_conv_halo_auto(int on);
-/* tools-only default of nrpn_conv_opts.halo_pairing: 1 = the halo kernel pairs taps across channel-chunk boundaries (108 instead of 112 K-steps at
- * Cin = 256), 0 = 14 K-steps per chunk with a half-empty last one */
-int nrpn_set_conv_halo_pairing(int on);
+/* tools-only default of the halo kernel's K order: 1 = taps paired across channel-chunk boundaries whenever Cin % 128 == 0 (108 instead of 112
+ * K-steps at Cin = 256), 2 (default) = from Cin 256 up, 0 = 14 K-steps per chunk with a half-empty last one.  nrpn_conv_opts.halo_pairing
+ * (1 = on, 2 = off) overrides it per call. */
+int nrpn_set_conv_halo_pairing(int mode);
 /* tuning knob: 1 (default) = the two waves of a SIMD issue their LDS-DMA in different sub-steps of the 256x256 kernel's K-step */
 int nrpn_set_conv_stagger(int on);
 /* tuning knob: 1 (default) = mid-size grids (16..199 tiles of 256x256) run the 256x256 kernel on K slices; 0 = 128-row kernel */
@@ -39,6 +40,8 @@ int nrpn_set_rows_big_tile(int on);
 int nrpn_set_rows_tail_split(int on);
 /* BatchNorm apply / backward-apply: 1 (default) = the hoisted-parameter kernels with 16-byte accesses, 0 = the general grid-stride kernels (A/B) */
 int nrpn_set_bn_fast(int on);
+/* BatchNorm channel reductions (statistics / backward sums), bf16: 1 = 8 channels per lane (16-byte loads), 0 (default) = 4 -- measured slower with 8 */
+int nrpn_set_bn_reduce_v8(int on);
 /* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
 int nrpn_set_window_attn_mfma(int on);
 

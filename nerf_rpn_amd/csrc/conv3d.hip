@@ -13,8 +13,12 @@
 // Replaces torch.nn.Conv3d (MIOpen/cuDNN) in reference feature_extractor.py:331-358, fpn.py:109-110, anchor.py:190-198.
 #include "conv_common.cuh"
 
+// Halo kernel, taps paired across channel-chunk boundaries (conv_halo.hip XP): 0 = never, 1 = whenever Cin % 128 == 0, 2 = from Cin 256 up.
+// Measured (profiles/r05_halo_pairing.json, one MI355X, alternating rounds, bit-identical outputs): 256->256@40^3 176.1 vs 176.5 us (post-ReLU
+// operands) / 181.5 vs 182.0 us (random) -- the half-empty 14th K-step was not what the kernel waits for; 128->256 (one four-chunk group) 96.9 vs
+// 96.8 / 100.1 vs 99.9 us; the bf16x3 form of 256->256 (Cin 768: six groups, fp32 rows) 496 vs 525 us (-5.5 %).
 #ifndef NRPN_HALO_PAIRING_DEFAULT
-#define NRPN_HALO_PAIRING_DEFAULT 0      // set to 1 once measured faster on hardware (profiles/r05_*)
+#define NRPN_HALO_PAIRING_DEFAULT 2
 #endif
 
 // ROWS (MODE 0): row-list form -- tile row v is voxel p.rows[2 v] of the ragged space with tap word p.rows[2 v + 1] (csrc/cone.hip); the
@@ -1285,7 +1289,7 @@ static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
           flags & (NRPN_CONV_DEBUG_ALIAS_TAPS | NRPN_CONV_DEBUG_NO_SYNC | NRPN_CONV_DEBUG_STAGGER | NRPN_CONV_DEBUG_VARIANT), g_conv_halo_auto.load(std::memory_order_relaxed),
           g_conv_halo_xp.load(std::memory_order_relaxed)};
   if (o) {
-    if (o->halo_pairing == 1 || o->halo_pairing == 2) k.halo_xp = o->halo_pairing == 1;
+    if (o->halo_pairing == 1 || o->halo_pairing == 2) k.halo_xp = o->halo_pairing == 1 ? 1 : 0;
     if (o->tile > 0) k.bm = o->tile;
     if (o->lds_dma >= 0) k.glds = o->lds_dma ? 1 : 0;
     if (o->kstep_bytes == 64 || o->kstep_bytes == 128) k.kb = o->kstep_bytes;
@@ -1297,7 +1301,7 @@ static Knobs resolve_knobs(const nrpn_conv_opts *o, int flags = 0) {
 }
 extern "C" int nrpn_set_conv_lds_dma(int on) { g_conv_glds = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_halo_auto(int on) { g_conv_halo_auto = on ? 1 : 0; return NRPN_OK; }
-extern "C" int nrpn_set_conv_halo_pairing(int on) { g_conv_halo_xp = on ? 1 : 0; return NRPN_OK; }
+extern "C" int nrpn_set_conv_halo_pairing(int mode) { g_conv_halo_xp = (mode == 1 || mode == 2) ? mode : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_stagger(int on) { g_conv_stagger = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_big_split(int on) { g_conv_big_split = on ? 1 : 0; return NRPN_OK; }
 extern "C" int nrpn_set_conv_kstep_bytes(int kb) {
@@ -1545,7 +1549,8 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
     if (halo_ok(g, cin, cout, a.taps, es, out_f32, kn)) {
       const long long wgs = halo_tiles(g) * ((cout + 255) / 256);
       NRPN_REQUIRE(wgs < (1ll << 31), "conv3d_fwd: too many tiles");
-      const int variant = ((kn.dbg >> 12) & 3) | ((kn.halo_xp && cin % 128 == 0 && !((kn.dbg >> 12) & 3)) ? 4 : 0) | (out_f32 ? 8 : 0);
+      const bool xp = cin % 128 == 0 && !((kn.dbg >> 12) & 3) && (kn.halo_xp == 1 || (kn.halo_xp == 2 && cin >= 256));
+      const int variant = ((kn.dbg >> 12) & 3) | (xp ? 4 : 0) | (out_f32 ? 8 : 0);
       return nrpn_launch_conv_halo(a, (unsigned)wgs, st, variant);
     }
   }

@@ -139,7 +139,12 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
     }
   }
 }
-// 8 channels per lane where the shape and the pointers allow 16-byte bf16 accesses
+// 8 channels per lane where the shape and the pointers allow 16-byte bf16 accesses.  MEASURED SLOWER (round 5, one MI355X, bench.py
+// hbm_stages): bn_stats 64@512000 23.1 vs 21.3 us, bn_backward 256@64000 52.4 vs 39.2 us -- half the row lanes per block and twice the
+// accumulator registers per lane cost more than the wider loads save; these reductions are bound by their two-launch structure
+// (partials + finish) and the ~60-row slabs, not by load width.  Kept as a tools switch (nrpn_set_bn_reduce_v8), OFF by default.
+static std::atomic<int> g_chan_v8{0};
+extern "C" int nrpn_set_bn_reduce_v8(int on) { g_chan_v8 = on ? 1 : 0; return NRPN_OK; }
 static inline bool chan_v8(int dtype, int c, const void *a, const void *b, const void *d) {
   const int tile = c > 1024 ? 1024 : c;
   return dtype == NRPN_BF16 && c % 8 == 0 && tile % 8 == 0 && 256 % (tile / 8) == 0 &&
@@ -222,7 +227,7 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
   const int kSlab = slab_rows(rows);
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
-  if (chan_v8(dtype, c, x, nullptr, nullptr)) {
+  if (g_chan_v8.load(std::memory_order_relaxed) && chan_v8(dtype, c, x, nullptr, nullptr)) {
     hipLaunchKernelGGL((chan_partial_kernel<bf16s, 0, 8>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const bf16s *)x, (const bf16s *)nullptr,
                        (const bf16s *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0, (float *)workspace, kSlab);
   } else {
@@ -428,7 +433,7 @@ extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, vo
   const int kSlab = slab_rows(rows);
   const int nb = (int)cdiv64(rows, kSlab);
   hipStream_t st = as_stream(stream);
-  if (chan_v8(dtype, c, x, y, dy)) {
+  if (g_chan_v8.load(std::memory_order_relaxed) && chan_v8(dtype, c, x, y, dy)) {
     hipLaunchKernelGGL((chan_partial_kernel<bf16s, 1, 8>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const bf16s *)x, (const bf16s *)y,
                        (const bf16s *)dy, (long long)rows, c, mean, var, eps, relu, (float *)workspace, kSlab, gamma, beta);
   } else {
@@ -867,6 +872,39 @@ extern "C" int nrpn_ndhwc_to_ncdhw(const void *src, float *dst, int n, int c, in
   DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_kernel<T, false>), grid, dim3(32, 8), 0, as_stream(stream), src, (void *)dst, c,
                                        (long long)voxels));
   NRPN_LAUNCH_CHECK("ndhwc_to_ncdhw");
+  return NRPN_OK;
+}
+
+// Column sums of an f32 [rows][C] matrix, any C (the bias gradient of the bf16x3 mode: sum over voxels of dy).  Deterministic: slabs of rows
+// summed in row order per column (coalesced 4-byte loads across adjacent columns), slab partials summed in slab order in fp64.
+__global__ void colsum_partial_kernel(const float *__restrict__ x, long long rows, int c, int slab, float *__restrict__ partial) {
+  const long long r0 = (long long)blockIdx.x * slab, r1 = min(rows, r0 + slab);
+  for (int ch = blockIdx.y * blockDim.x + threadIdx.x; ch < c; ch += gridDim.y * blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long r = r0;
+    for (; r + 3 < r1; r += 4) {
+      a0 += x[r * c + ch]; a1 += x[(r + 1) * c + ch]; a2 += x[(r + 2) * c + ch]; a3 += x[(r + 3) * c + ch];
+    }
+    for (; r < r1; ++r) a0 += x[r * c + ch];
+    partial[(long long)blockIdx.x * c + ch] = (a0 + a1) + (a2 + a3);
+  }
+}
+__global__ void colsum_finish_kernel(const float *__restrict__ partial, int nslabs, int c, float *__restrict__ out, int accumulate) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0;
+  for (int k = 0; k < nslabs; ++k) s += (double)partial[(long long)k * c + ch];
+  out[ch] = accumulate ? out[ch] + (float)s : (float)s;
+}
+static inline int colsum_slab(long long rows) { const long long s = (rows + 511) / 512; return (int)(s < 32 ? 32 : s); }
+extern "C" size_t nrpn_column_sum_workspace_bytes(int64_t rows, int c) { return (size_t)(cdiv64(rows, colsum_slab(rows)) * c * 4); }
+extern "C" int nrpn_column_sum_f32(const float *x, int64_t rows, int c, float *out, int accumulate, void *workspace, nrpn_stream_t stream) {
+  NRPN_REQUIRE(x && out && workspace && rows > 0 && c > 0, "column_sum: bad arguments");
+  const int slab = colsum_slab(rows), nslabs = (int)cdiv64(rows, slab);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nslabs, (c + 255) / 256), dim3(256), 0, st, x, (long long)rows, c, slab, (float *)workspace);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((c + 255) / 256), dim3(256), 0, st, (const float *)workspace, nslabs, c, out, accumulate);
+  NRPN_LAUNCH_CHECK("column_sum");
   return NRPN_OK;
 }
 

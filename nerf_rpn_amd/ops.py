@@ -749,13 +749,15 @@ def _x3_weights(pack, weights, wp, wpd):
     return ent[1], ent[2]
 
 
-def column_sum_f32(t):
-    """f32 [rows, C] -> f32 [C] column sums (deterministic: the BatchNorm statistics kernels' fixed-order reduction, fp64 finish)."""
+def column_sum_f32(t, out=None, accumulate=False):
+    """f32 [rows, C] -> f32 [C] column sums (nrpn_column_sum_f32: deterministic, any C); ``out`` += when ``accumulate``."""
+    t = t.contiguous()
     rows, c = t.shape
-    mean, var = torch.empty(c, dtype=torch.float32, device=t.device), torch.empty(c, dtype=torch.float32, device=t.device)
-    ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=t.device)
-    call("bn_stats", _p(t), rows, c, F32, _p(mean), _p(var), 0, 0, 0.1, _p(ws), _s())
-    return mean * float(rows)
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=t.device)
+    ws = torch.empty(query("column_sum_workspace_bytes", rows, c), dtype=torch.uint8, device=t.device)
+    call("column_sum_f32", _p(t), rows, c, _p(out), 1 if accumulate else 0, _p(ws), _s())
+    return out
 
 
 def _seg_dims(segs):

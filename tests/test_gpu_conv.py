@@ -661,9 +661,14 @@ def test_bf16x3_conv_is_fp32_grade(n, grid, cin, cout, relu, dev):
     conv = nn.Conv3d(cin, cout, 3, padding=1)
     x = torch.randn(n, cin, *grid)
     xr = x.clone().requires_grad_(True)
-    yr = conv(xr)
-    yr = F.relu(yr) if relu else yr
+    pre = conv(xr)
+    yr = F.relu(pre) if relu else pre
     gy = torch.randn_like(yr)
+    if relu:
+        # a pre-activation within 1e-5 of zero may come out on the other side of the ReLU in another arithmetic -- ONE such routing flip moves
+        # 27 * Cin entries of dx by |gy * w| ~ 1e-2 of the tensor's maximum (first version of this test: 1.5e-2 on dx with y equal to 4e-6).
+        # The incoming gradient is therefore zero wherever the ReLU's decision is not safe: the kernels are compared on identical routing.
+        gy = gy * (pre.detach().abs() > 1e-3 * pre.detach().abs().max())
     yr.backward(gy)
     ref = dict(y=yr.detach(), dx=xr.grad, dw=conv.weight.grad.clone(), db=conv.bias.grad.clone())
     out = {}
