@@ -98,11 +98,12 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
         loss.backward()
         torch.cuda.synchronize()
         # routing-flip detector (tools/diag_trainer_cone.py): per tensor, the trainer's gradient against autograd's on the SAME step.  After
-        # an identical first step the weights differ in the last bit, which leaves the gradients equal to ~1e-6 -- unless a ReLU / max-pool
-        # input within rounding distance of zero changed side: then the tensors downstream of it differ by 1e-3 .. 1e-1
+        # an identical first step the weights differ in the last bit; train-mode BatchNorm at batch 1 amplifies that to 2e-3 .. 7e-3 of every
+        # tensor's gradient scale on steps 2 and 3 (measured, round 5) -- and a ReLU / max-pool input within rounding distance of zero that
+        # changes side adds percents to the tensors downstream of it (measured: layers.5.6 / 5.7, fpn_convs.1: 1.3e-2 .. 2.5e-2)
         for k, (p, gr) in enumerate(zip(m.parameters(), ref_grads[it])):
             rel = (p.grad - gr).abs().max().item() / (gr.abs().max().item() + 1e-30)
-            if rel > 1e-4 and names[k] not in dead:
+            if rel > 1e-2 and names[k] not in dead:
                 flipped[names[k]] = max(flipped.get(names[k], 0.0), rel)
         tr.step()
         losses.append(loss.item())
@@ -139,7 +140,8 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
         d = (tr.flat_params() - after_ref)[sig].abs()
         assert (d < 0.05 * lr * steps).float().mean().item() > 0.999, (d < 0.05 * lr * steps).float().mean().item()
         # an entry further off than 0.3 lr x steps must BELONG to a tensor whose gradient the detector above saw change by
-        # > 1e-4 on some step (a routing flip upstream of it); every other tensor stays inside 0.3 lr x steps.  Flipped tensors: at most one
+        # > 1e-2 on some step (a routing flip upstream of it); every other tensor stays inside 0.3 lr x steps (measured on the round-5 tree:
+        # NO tensor leaves it -- the allowance below exists for the flipped ones only).  Flipped tensors: at most one
         # reversed Adam step (2 lr; measured 1.25 lr), they are few, and the first step -- identical weights -- has none.
         full = (tr.flat_params() - after_ref).abs()
         off, outside = 0, {}
@@ -152,7 +154,7 @@ def test_flat_trainer_trains_like_torch_adamw(dtype, golden, dev):
         print(f"[trainer] tensors with a detected routing flip: { {k: f'{v:.1e}' for k, v in flipped.items()} }; beyond 0.3 lr x steps: "
               f"{ {k: f'{v / lr:.2f} lr' for k, v in outside.items()} }")
         assert set(outside) <= set(flipped), (outside, flipped)
-        assert len(flipped) <= len(names) // 4, flipped          # a flip is local: the tensors downstream of one coarse-level voxel
+        assert len(flipped) <= 8, flipped          # a flip is local: the tensors right downstream of one voxel (measured: 4 tensors)
         assert d.max().item() < 2.2 * lr, d.max().item()
         init = torch.cat([p.detach().reshape(-1) for p in build(True, 160, dev).parameters()])
         a, b = (tr.flat_params() - init)[sig].double(), (after_ref - init)[sig].double()
