@@ -541,6 +541,31 @@ int nrpn_roi_align_rotated_3d_bwd(const void *grad_out, const float *rois, int n
                                   float spatial_scale, int pw, int pl, int ph, int sampling_ratio, void *grad_in, void *workspace,
                                   int dtype, nrpn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ROIPool without the op -- the reference CLI's DEFAULT second-stage pooling (detector.py ROIPool(use_cuda=False)).  [f3]
+ *   One launch per pyramid level over ALL RoIs of a scene: level_of [R] names each RoI's level, RoIs of other levels are skipped by the
+ *   kernel (no host-side grouping).  feat: channels-last map [X][Y][Z][C] of that level, f32 | bf16; out: f32 [R][o0][o1][o2][C] (rows of
+ *   other levels untouched); argmax: i32, same shape (max-pool forms).  Backward: dfeat [X][Y][Z][C] in feat's dtype = the gradient of THIS
+ *   level from all its RoIs (deterministic: 64-bit fixed-point atomics), workspace nrpn_roipool_bwd_workspace_bytes.
+ *   aabb (normal_forward, detector.py:397-438): crop [R][6] = (start x, y, z, size x, y, z) in level voxels -- the python slice
+ *     [floor(lo / s), floor(hi / s)] after clipping; adaptive max-pool with zero padding at the high side (:377-384): kernel = stride =
+ *     ceil(size / output); ties: first element in scan order (torch max_pool3d).  size <= 0 pools to zeros (the reference raises).
+ *   obb (:264-395): rois [R][7] = (x, y, z, w, l, h, theta) in input voxels with the extents already enlarged; scale = input voxels per level
+ *     voxel; grid of ceil(extent / scale) points rotated about the centre, each the reference's 8-corner blend
+ *     sum feat[corner] * (1 - |dx||dy||dz|) / 8 (zero outside the map), then the adaptive max-pool (interpolation = 0) or a trilinear resize
+ *     with aligned corners (interpolation = 1, :385-393).
+ * ---------------------------------------------------------------------------------------------- */
+size_t nrpn_roipool_bwd_workspace_bytes(int x, int y, int z, int c);
+int nrpn_roipool_aabb_fwd(const void *feat, int x, int y, int z, int c, const int32_t *crop, const int32_t *level_of, int level, int num_rois,
+                          int o0, int o1, int o2, float *out, int32_t *argmax, int dtype, nrpn_stream_t stream);
+int nrpn_roipool_aabb_bwd(const float *dout, const int32_t *argmax, const int32_t *crop, const int32_t *level_of, int level, int num_rois,
+                          int x, int y, int z, int c, int o0, int o1, int o2, void *dfeat, void *workspace, int dtype, nrpn_stream_t stream);
+int nrpn_roipool_obb_fwd(const void *feat, int x, int y, int z, int c, const float *rois, const int32_t *level_of, int level, int num_rois,
+                         float scale, int interpolation, int o0, int o1, int o2, float *out, int32_t *argmax, int dtype, nrpn_stream_t stream);
+int nrpn_roipool_obb_bwd(const float *dout, const int32_t *argmax, const float *rois, const int32_t *level_of, int level, int num_rois,
+                         float scale, int interpolation, int x, int y, int z, int c, int o0, int o1, int o2, void *dfeat, void *workspace,
+                         int dtype, nrpn_stream_t stream);
+
 /* Reduction step of the trainer's bf16 all-to-all gradient exchange (engine.FlatTrainer, exchange "a2a_bf16"): recv = bf16 [world][chunk]
  * (chunk `rank` of every peer's bucket), local = this rank's own fp32 chunk; out[i] = bf16(sum over ranks in ascending order, fp32
  * accumulation, the local chunk taken from `local`).  chunk % 4 == 0. */

@@ -8,9 +8,11 @@ What runs where:
   * the head's 3x3x3 convs: the MFMA implicit-GEMM conv kernels; the two Linear layers: the same GEMM with one tap.
 
 ``ROIPool`` modes:
-  * ``use_cuda=False`` (the reference CLI's default): the reference's torch paths restated on device tensors, bit-exact against outputs of
-    the reference itself (tests/golden/roipool.npz) -- integer crops + adaptive max-pool for AABBs, the rotated 8-corner gather + max-pool
-    / trilinear resize for OBBs, including its in-place enlargement of the caller's OBB RoIs and its AABB "enlargement" by (1 + e) / 2.
+  * ``use_cuda=False`` (the reference CLI's default): the reference's pooling WITHOUT the op as HIP kernels (csrc/roipool.hip, round 5; one
+    launch per pyramid level over all RoIs of a scene, forward and backward) -- integer crops + adaptive max-pool for AABBs, the rotated
+    8-corner gather + max-pool / trilinear resize for OBBs, including its in-place enlargement of the caller's OBB RoIs and its AABB
+    "enlargement" by (1 + e) / 2; held to outputs of the reference itself (tests/golden/roipool.npz) and to the torch restatement of those
+    paths in oracle/roipool.py (which is bit-exact against the same outputs on the CPU).
   * ``use_cuda=True``: the rotated RoIAlign kernel; axis-aligned RoIs go through it as theta = 0 boxes.  Two behaviours of the reference's
     op path are corrected by default and available verbatim with ``reference_op_quirks=True`` (or NRPN_ROIPOOL_REFERENCE_QUIRKS=1): it hands the box heading in RADIANS to an
     op that reads DEGREES and rotates sample points by -theta (ROIAlignRotated3D_cuda.cu:103,146-147; here: converted, so the sampled
@@ -120,8 +122,8 @@ class ROIPool(nn.Module):
             raise NameError("Unkown feature_extracting_type")
         # use_cuda=True: the rotated RoIAlign op (the reference's --use_cuda path, :247-261).  use_cuda=False (the reference CLI's DEFAULT):
         # its torch paths -- integer crops + adaptive max-pool for AABBs (:397-438), a rotated 8-corner gather followed by max-pool or a
-        # trilinear resize for OBBs (:264-395) -- restated below on device tensors, so that an RCNN trained with the reference's default
-        # pooling reproduces its scores.  They are per-RoI torch loops exactly like the reference's (second-stage glue, not the hot path).
+        # trilinear resize for OBBs (:264-395) -- as HIP kernels (csrc/roipool.hip), so that an RCNN trained with the reference's default
+        # pooling reproduces its scores.
         # Dispatch as the reference (:239-245): the op serves ROTATED RoIs when use_cuda is set; axis-aligned RoIs always take the integer
         # crop + adaptive max-pool (normal_forward), whatever use_cuda says -- AABB RCNN weights trained with the reference expect that
         # pooling.  ``aabb_use_kernel=True`` is an explicit opt-in (not in the reference) that sends AABBs through the RoIAlign kernel as
@@ -189,89 +191,50 @@ class ROIPool(nn.Module):
         return out
 
 
-    # ---------------------------------------------------------------------------------------------- reference torch paths (use_cuda=False)
-    def _adaptive_max_pool(self, feat):
-        """[C, a, b, c] -> [C, *output_size]: zero padding at the high side up to a multiple of the output size, then a max-pool whose kernel
-        = stride = ceil(extent / output) (reference :377-384, :425-432)."""
-        size = torch.tensor(feat.shape[1:], dtype=torch.float32)
-        out = torch.tensor(self.output_size, dtype=torch.float32)
-        kernel = torch.ceil(size / out).int()
-        pad = (kernel * out.int() - size.int()).int()
-        feat = F.pad(feat, (0, int(pad[2]), 0, int(pad[1]), 0, int(pad[0])))
-        k = [int(v) for v in kernel]
-        return F.max_pool3d(feat[None], kernel_size=k, stride=k)[0]
+    # ---------------------------------------------------------------------------------------------- the reference's default pooling (use_cuda=False)
+    def _level_dims(self, f, device):
+        return torch.tensor([[int(v) for v in lv.shape[1:]] for lv in f], dtype=torch.long, device=device)
 
     def _normal_forward(self, features, rois):
-        """AABB RoIs: the enlarged box in feature voxels, floor of both corners, the inclusive integer crop, adaptive max-pool (:397-438)."""
+        """AABB RoIs (reference :397-438): the box placed at centre -+ 0.5 * (half extent * (1 + enlarge)) -- the reference's "enlargement" pools
+        (1 + e) / 2 of the RoI; kept, it is what its RCNN weights were trained on -- in level voxels, floor of both corners, the inclusive
+        integer crop with python slicing semantics (the high end is clipped to the map), adaptive max-pool.  Crops are computed with a few
+        tensor ops on the device (no host read-back); cropping + pooling of ALL RoIs of a scene = one HIP launch per level (csrc/roipool.hip)."""
         out = []
         for f, r in zip(features, rois):
             r = r.reshape(-1, r.shape[-1])
+            if r.shape[0] == 0:
+                out.append(f[0].new_zeros((0, f[0].shape[0], *self.output_size), dtype=torch.float32))
+                continue
             lv = r[..., 0].long()
             scale = torch.tensor(self.spatial_scale, dtype=r.dtype, device=r.device)[lv][:, None]
             roi = r[..., 1:]
-            # the reference's AABB "enlargement" places the corners at centre -+ 0.5 * (half extent * (1 + enlarge)): the pooled box is
-            # (1 + enlarge) / 2 of the RoI, not larger than it (:203-209).  Kept: it is what its RCNN weights were trained on.
             ext = (roi[..., 3:] - roi[..., :3]) / 2 * (1 + self.enlarge_scale)
             ctr = (roi[..., 3:] + roi[..., :3]) / 2
-            pos = torch.floor(torch.cat([ctr - 0.5 * ext, ctr + 0.5 * ext], dim=-1) / scale)
-            pos = pos.long().tolist()
-            feats = []
-            for j, p in enumerate(pos):
-                crop = f[int(lv[j])][..., p[0]:p[3] + 1, p[1]:p[4] + 1, p[2]:p[5] + 1]
-                feats.append(self._adaptive_max_pool(crop.float()))
-            out.append(torch.stack(feats) if feats else f[0].new_zeros((0, f[0].shape[0], *self.output_size)))
+            pos = torch.floor(torch.cat([ctr - 0.5 * ext, ctr + 0.5 * ext], dim=-1) / scale).long()
+            dims = self._level_dims(f, r.device)[lv]
+            lo, hi = pos[:, :3], pos[:, 3:] + 1                      # python slice lo : hi
+            start = torch.where(lo < 0, (dims + lo).clamp_min(0), torch.minimum(lo, dims))
+            stop = torch.where(hi < 0, (dims + hi).clamp_min(0), torch.minimum(hi, dims))
+            crop = torch.cat([start, (stop - start).clamp_min(0)], dim=1).int()
+            out.append(ops.RoiPoolFn.apply("aabb", crop, lv.int(), self.spatial_scale, self.output_size, *f))
         return out
 
     def _rotated_forward(self, features, rois):
-        """OBB RoIs without the op (:264-395): a regular grid of ceil(extent / scale) points per RoI, rotated by theta about the box centre,
-        each point the reference's 8-corner blend  sum_corners feat[corner] * (1 - |dx| |dy| |dz|) / 8  (not a trilinear interpolation;
-        kept as it is), zero outside the map; then adaptive max-pool ('pooling') or a trilinear resize ('interpolation').  Like the
-        reference, the RoI extents are enlarged IN PLACE (its ``enlarge_roi`` writes through the view it is given), so the caller's
+        """OBB RoIs without the op (reference :264-395): a regular grid of ceil(extent / scale) points per RoI, rotated by theta about the box
+        centre, each point the reference's 8-corner blend (not a trilinear interpolation; kept as it is), zero outside the map; then adaptive
+        max-pool ('pooling') or a trilinear resize ('interpolation') -- one HIP launch per level over all RoIs of a scene (csrc/roipool.hip).
+        Like the reference, the RoI extents are enlarged IN PLACE (its ``enlarge_roi`` writes through the view it is given), so the caller's
         RoIs -- and the proposals decoded from them afterwards -- are the enlarged ones."""
         out = []
-        fns = [(a, b, c) for a in (torch.floor, torch.ceil) for b in (torch.floor, torch.ceil) for c in (torch.floor, torch.ceil)]
         for f, r in zip(features, rois):
             flat = r.reshape(-1, r.shape[-1])              # a view: the in-place enlargement below reaches the caller's tensor
-            lv = flat[..., 0].long()
             flat[..., 4:7] = flat[..., 4:7] * (1 + self.enlarge_scale)
-            boxes = flat[..., 1:]
-            pooled = [None] * flat.shape[0]
-            for level in range(len(f)):
-                sel = torch.nonzero(lv == level).view(-1)
-                if sel.numel() == 0:
-                    continue
-                fm = f[level].float()
-                dims = fm.shape
-                lr = boxes[sel].float()
-                sc = float(self.spatial_scale[level])
-                gsz = torch.ceil(lr[:, 3:6] / sc).long().clamp_min(1)
-                mx = [int(v) for v in gsz.max(dim=0).values]
-                grid = torch.stack(torch.meshgrid(*[torch.arange(m, device=lr.device) for m in mx], indexing="ij"), dim=0).reshape(3, -1).float()
-                pos = grid[None].repeat(lr.shape[0], 1, 1) - (gsz[..., None].float() - 1) / 2.0
-                th = lr[:, 6]
-                zero, one = torch.zeros_like(th), torch.ones_like(th)
-                rot = torch.stack([torch.stack([torch.cos(th), -torch.sin(th), zero], dim=1),
-                                   torch.stack([torch.sin(th), torch.cos(th), zero], dim=1),
-                                   torch.stack([zero, zero, one], dim=1)], dim=1)
-                pos = rot @ pos + lr[:, :3, None] / sc                                          # [n, 3, G]
-                p = pos.permute(1, 0, 2).reshape(3, -1)
-                inside = ((p[0] >= 0) & (p[0] <= dims[1] - 1) & (p[1] >= 0) & (p[1] <= dims[2] - 1) & (p[2] >= 0) & (p[2] <= dims[3] - 1))
-                acc = 0.
-                for fa, fb, fc in fns:
-                    q = [fa(p[0]), fb(p[1]), fc(p[2])]
-                    idx = [q[d].clamp(0, dims[d + 1] - 1).long() for d in range(3)]
-                    w = (p[0] - q[0]).abs() * (p[1] - q[1]).abs() * (p[2] - q[2]).abs()
-                    acc = acc + fm[:, idx[0], idx[1], idx[2]] * (1. - w[None])
-                acc = acc * inside[None] / 8
-                acc = acc.reshape(dims[0], lr.shape[0], *mx).permute(1, 0, 2, 3, 4)
-                for k, j in enumerate(sel.tolist()):
-                    g = [int(v) for v in gsz[k]]
-                    crop = acc[k][:, :g[0], :g[1], :g[2]]
-                    if self.feature_extracting_type == "pooling":
-                        pooled[j] = self._adaptive_max_pool(crop)
-                    else:
-                        pooled[j] = F.interpolate(crop[None], size=tuple(self.output_size), mode="trilinear", align_corners=True)[0]
-            out.append(torch.stack(pooled) if pooled else f[0].new_zeros((0, f[0].shape[0], *self.output_size)))
+            if flat.shape[0] == 0:
+                out.append(f[0].new_zeros((0, f[0].shape[0], *self.output_size), dtype=torch.float32))
+                continue
+            out.append(ops.RoiPoolFn.apply(self.feature_extracting_type, flat[..., 1:].detach().float().contiguous(), flat[..., 0].int(),
+                                           self.spatial_scale, self.output_size, *f))
         return out
 
 

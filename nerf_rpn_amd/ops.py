@@ -2077,3 +2077,58 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, betas, eps, wd, step, grad_scale
     """``zero_grad``: the kernel clears the gradient it has just consumed (no separate fill of the arena)."""
     call("adamw_step_zero_grad" if zero_grad else "adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), float(grad_scale), float(max_norm),
          float(lr), float(betas[0]), float(betas[1]), float(eps), float(wd), int(step), _p(shadow), _s())
+
+
+# ======================================================================================================================
+# ROIPool without the RoIAlign op (the reference CLI's default second-stage pooling, detector.py:264-438) -- csrc/roipool.hip
+# ======================================================================================================================
+class RoiPoolFn(torch.autograd.Function):
+    """Per-RoI pyramid features of ONE scene: ``levels`` = the scene's maps, logical [C, X, Y, Z] (channels-last memory is consumed as is);
+    ``meta`` = i32 [R, 6] crops (kind 'aabb') or f32 [R, 7] enlarged boxes ('pooling' / 'interpolation'); ``level_of`` i32 [R];
+    ``scales`` = input voxels per level voxel.  -> f32 [R, C, o0, o1, o2] (a channels-last-backed view).  One launch per level, forward and
+    backward; no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, kind, meta, level_of, scales, output_size, *levels):
+        o0, o1, o2 = (int(v) for v in output_size)
+        R = int(meta.shape[0])
+        cls = [as_channels_last(f[None])[0] for f in levels]          # [X, Y, Z, C]
+        C = int(cls[0].shape[-1])
+        dev = cls[0].device
+        out = torch.zeros((R, o0, o1, o2, C), dtype=torch.float32, device=dev)
+        arg = torch.full((R, o0, o1, o2, C), -1, dtype=torch.int32, device=dev) if kind != "interpolation" else None
+        meta, level_of = meta.contiguous(), level_of.contiguous()
+        _chk(meta, level_of, *cls)
+        for l, f in enumerate(cls):
+            X, Y, Z = (int(v) for v in f.shape[:3])
+            if kind == "aabb":
+                call("roipool_aabb_fwd", _p(f), X, Y, Z, C, _p(meta), _p(level_of), l, R, o0, o1, o2, _p(out), _p(arg), _dt(f), _s())
+            else:
+                call("roipool_obb_fwd", _p(f), X, Y, Z, C, _p(meta), _p(level_of), l, R, float(scales[l]), 1 if kind == "interpolation" else 0,
+                     o0, o1, o2, _p(out), _p(arg), _dt(f), _s())
+        ctx.save_for_backward(meta, level_of, *([arg] if arg is not None else []))
+        ctx.info = (kind, [float(v) for v in scales], (o0, o1, o2), [(tuple(f.shape), f.dtype) for f in cls])
+        return out.permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        kind, scales, (o0, o1, o2), shapes = ctx.info
+        meta, level_of, *rest = ctx.saved_tensors
+        arg = rest[0] if rest else None
+        R = int(meta.shape[0])
+        g = g.permute(0, 2, 3, 4, 1).contiguous().float()
+        grads = []
+        for l, ((X, Y, Z, C), dt) in enumerate(shapes):
+            if not ctx.needs_input_grad[5 + l]:
+                grads.append(None)
+                continue
+            df = torch.empty((X, Y, Z, C), dtype=dt, device=g.device)
+            ws = torch.empty(query("roipool_bwd_workspace_bytes", X, Y, Z, C), dtype=torch.uint8, device=g.device)
+            code = F32 if dt == torch.float32 else BF16
+            if kind == "aabb":
+                call("roipool_aabb_bwd", _p(g), _p(arg), _p(meta), _p(level_of), l, R, X, Y, Z, C, o0, o1, o2, _p(df), _p(ws), code, _s())
+            else:
+                call("roipool_obb_bwd", _p(g), _p(arg), _p(meta), _p(level_of), l, R, scales[l], 1 if kind == "interpolation" else 0, X, Y, Z, C,
+                     o0, o1, o2, _p(df), _p(ws), code, _s())
+            grads.append(df.permute(3, 0, 1, 2))
+        return (None, None, None, None, None, *grads)

@@ -46,10 +46,11 @@ def test_roipool_samples_the_box_it_is_given(dev):
     assert good.shape == (1, 4, 3, 3, 3) and good.min().item() > 0.95 and bad.mean().item() < 0.8
 
 
-def test_roipool_torch_paths_on_device(golden, dev):
-    """The reference's default pooling (use_cuda=False) on device tensors against the reference's CPU outputs: the same arithmetic, but the
-    device's sin / cos / division may round the last bit differently, which can move a sample point across an integer -- so not bit-exact
-    here (it is on the CPU: tests/test_harness_cpu.py): >= 99.9 % of the values within 1e-5, every value finite."""
+def test_roipool_default_paths_as_hip_kernels_match_the_reference(golden, dev):
+    """Round 5 (f3): the reference's default pooling (use_cuda=False) runs on csrc/roipool.hip.  Against the reference's own CPU outputs
+    (roipool.npz): AABB crops + max are integer / comparison work -- EXACT; the rotated paths evaluate sin / cos / divisions on the device, whose
+    last bit can move a sample point across an integer: >= 99.9 % of the values within 1e-5, every value finite; the caller's OBB RoIs come
+    back enlarged in place.  Dispatch as the reference (detector.py:239-245): axis-aligned RoIs take normal_forward whatever use_cuda says."""
     from nerf_rpn_amd.model.detector import ROIPool
     g = golden("roipool")
     feats = [[T(g[f"feat{k}_{l}"], dev) for l in range(3)] for k in range(2)]
@@ -59,10 +60,71 @@ def test_roipool_torch_paths_on_device(golden, dev):
         out = torch.stack(ROIPool([3, 3, 3], scales, 0.2, True, kind, use_cuda=False)(feats, rois)).cpu()
         ref = T(g["obb_" + kind])
         close = ((out - ref).abs() <= 1e-5 + 1e-5 * ref.abs()).float().mean().item()
-        assert close >= 0.999 and torch.isfinite(out).all(), (kind, close)
+        assert out.shape == ref.shape and close >= 0.999 and torch.isfinite(out).all(), (kind, close)
         assert torch.allclose(rois.cpu(), T(g["obb_rois_after_" + kind]), rtol=1e-6)
-    out = torch.stack(ROIPool([2, 2, 2], scales, 0.2, False, use_cuda=False)(feats, [r for r in T(g["aabb_rois"], dev)])).cpu()
-    assert torch.equal(out, T(g["aabb_pooling"]))                # integer crops + max: exact
+    for kw in ({"use_cuda": False}, {}, {"use_cuda": True}):
+        out = torch.stack(ROIPool([2, 2, 2], scales, 0.2, False, **kw)(feats, [r for r in T(g["aabb_rois"], dev)])).cpu()
+        assert torch.equal(out, T(g["aabb_pooling"])), kw            # integer crops + max: exact
+
+
+@pytest.mark.parametrize("kind,dtype", [("aabb", torch.float32), ("pooling", torch.float32), ("interpolation", torch.float32), ("aabb", torch.bfloat16),
+                                        ("pooling", torch.bfloat16)])
+def test_roipool_kernels_forward_and_backward_match_the_oracle(kind, dtype, dev):
+    """csrc/roipool.hip against oracle/roipool.py (the torch restatement that is bit-exact against the reference, run here on the CPU) on
+    random RoIs over a 3-level pyramid with 32 channels, RoIs reaching over the borders, crops clipped by the map, RoIs smaller than a voxel:
+    pooled features and -- through autograd on both sides -- the gradient of every level.  AABB: exact features, gradients to 1e-6 (fixed-point
+    scatter, 2^-44); rotated: 99.9 % within 1e-5 (a sample point within an ulp of an integer may take the other corner set).  bf16 maps: the
+    oracle sees the same bf16-rounded values.  Two runs give bit-identical gradients."""
+    from nerf_rpn_amd.model.detector import ROIPool
+    from oracle.roipool import ROIPoolOracle
+    gen = torch.Generator().manual_seed(5)
+    C, scales, R = 32, [4, 8, 16], 40
+    feats = [torch.randn(C, 72 // s, 64 // s, 48 // s, generator=gen) for s in scales]
+    if dtype == torch.bfloat16:
+        feats = [f.bfloat16().float() for f in feats]
+    lv = torch.randint(0, 3, (R, 1), generator=gen).float()
+    if kind == "aabb":
+        lo = torch.rand(R, 3, generator=gen) * torch.tensor([50., 44., 30.]) + 1
+        hi = lo + torch.rand(R, 3, generator=gen) * torch.tensor([40., 30., 24.]) + 0.5          # some reach past the map: the slice clips them
+        rois = torch.cat([lv, lo, hi], dim=1)
+        rot, out_size = False, [2, 3, 2]
+    else:
+        ctr = torch.rand(R, 3, generator=gen) * torch.tensor([72., 64., 48.])
+        ext = torch.rand(R, 3, generator=gen) * 30 + 0.5
+        ext[:4] = torch.rand(4, 3, generator=gen) * 2 + 0.3                                     # smaller than one level voxel
+        th = (torch.rand(R, 1, generator=gen) - 0.5) * 3.0
+        rois = torch.cat([lv, ctr, ext, th], dim=1)
+        rot, out_size = True, [3, 2, 3]
+    fe = kind if kind != "aabb" else "pooling"
+    # oracle (CPU, autograd through torch ops)
+    fo = [f.clone().requires_grad_(True) for f in feats]
+    ro = rois.clone()
+    oo = ROIPoolOracle(out_size, scales, 0.2, rot, fe)([fo], ro[None] if rot else [ro])[0]
+    w = torch.randn(oo.shape, generator=gen)
+    (oo * w).sum().backward()
+    outs = []
+    for rep in range(2):
+        fh = [f.to(dev).to(dtype).requires_grad_(True) for f in feats]
+        rh = rois.clone().to(dev)
+        oh = ROIPool(out_size, scales, 0.2, rot, fe, use_cuda=False)([fh], rh[None] if rot else [rh])[0]
+        assert oh.dtype == torch.float32 and tuple(oh.shape) == tuple(oo.shape)
+        (oh * w.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((oh.detach().cpu(), [f.grad.float().cpu() for f in fh]))
+        if rot:
+            assert torch.allclose(rh.cpu(), ro, rtol=1e-6)          # enlarged in place, like the oracle's / the reference's
+    assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))       # deterministic
+    oh, gh = outs[0]
+    if kind == "aabb":
+        assert torch.equal(oh, oo.detach())
+    else:
+        close = ((oh - oo.detach()).abs() <= 1e-5 + 1e-5 * oo.detach().abs()).float().mean().item()
+        assert close >= 0.999, (kind, close)
+    for l, (a, b) in enumerate(zip(gh, fo)):
+        ref = b.grad
+        tol = (1e-6 if dtype == torch.float32 else 1e-2) * max(1.0, ref.abs().max().item())
+        frac = ((a - ref).abs() <= tol).float().mean().item()
+        assert frac >= (1.0 if kind == "aabb" else 0.999), (kind, l, frac, (a - ref).abs().max().item())
 
 
 def test_roipool_reference_op_quirks(dev):

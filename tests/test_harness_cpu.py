@@ -108,27 +108,25 @@ def test_ngp_box_export_matches_reference(tmp_path):
 
 
 def test_roipool_torch_paths_match_reference(golden):
-    """ROIPool(use_cuda=False) -- the reference CLI's default pooling -- against outputs of the reference itself
-    (tests/golden/make_golden.py::gen_roipool): bit-exact features for OBB 'pooling' / 'interpolation' and AABB crops, and the caller's OBB
-    RoIs come back enlarged in place exactly as the reference leaves them (detector.py:195-201, 281)."""
+    """The oracle's restatement of ROIPool(use_cuda=False) -- the reference CLI's default pooling (oracle/roipool.py) -- against outputs of the
+    reference itself (tests/golden/make_golden.py::gen_roipool): bit-exact features for OBB 'pooling' / 'interpolation' and AABB crops, and the
+    caller's OBB RoIs come back enlarged in place exactly as the reference leaves them (detector.py:195-201, 281).  The product path is
+    csrc/roipool.hip (tests/test_gpu_detector.py holds it to the same vectors and to this oracle)."""
     from nerf_rpn_amd.model.detector import ROIPool
+    from oracle.roipool import ROIPoolOracle
     g = golden("roipool")
     T = lambda k: torch.from_numpy(g[k])
     feats = [[T(f"feat{k}_{l}") for l in range(3)] for k in range(2)]
     scales = [int(v) for v in g["scales"]]
     for kind in ("pooling", "interpolation"):
         rois = T("obb_rois").clone()
-        out = torch.stack(ROIPool([3, 3, 3], scales, 0.2, True, kind, use_cuda=False)(feats, rois))
+        out = torch.stack(ROIPoolOracle([3, 3, 3], scales, 0.2, True, kind)(feats, rois))
         assert torch.equal(out, T("obb_" + kind)), kind
         assert torch.equal(rois, T("obb_rois_after_" + kind)) and not torch.equal(rois, T("obb_rois"))
     aabb = T("aabb_rois")
-    out = torch.stack(ROIPool([2, 2, 2], scales, 0.2, False, use_cuda=False)(feats, [r for r in aabb]))
+    out = torch.stack(ROIPoolOracle([2, 2, 2], scales, 0.2, False)(feats, [r for r in aabb]))
     assert torch.equal(out, T("aabb_pooling")) and torch.equal(aabb, T("aabb_rois"))
     with pytest.raises(NameError):
         ROIPool([2, 2, 2], scales, 0.2, True, "nearest", use_cuda=False)
-    # dispatch as the reference (detector.py:239-245, ADVICE r3): axis-aligned RoIs take normal_forward whatever use_cuda says, and the
-    # constructor default is the reference's use_cuda=False; the theta = 0 kernel path for AABBs is an explicit opt-in
+    # the constructor default is the reference's use_cuda=False; the theta = 0 kernel path for AABBs is an explicit opt-in (ADVICE r3)
     assert ROIPool([2, 2, 2], scales, 0.2, False).use_cuda is False and ROIPool([2, 2, 2], scales, 0.2, False).aabb_use_kernel is False
-    for kw in ({}, {"use_cuda": True}):
-        out = torch.stack(ROIPool([2, 2, 2], scales, 0.2, False, **kw)(feats, [r for r in aabb]))
-        assert torch.equal(out, T("aabb_pooling")), kw
