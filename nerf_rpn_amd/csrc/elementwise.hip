@@ -889,21 +889,29 @@ __global__ void colsum_partial_kernel(const float *__restrict__ x, long long row
     partial[(long long)blockIdx.x * c + ch] = (a0 + a1) + (a2 + a3);
   }
 }
+// finish: block = (64 channels, 16 slab lanes), fp64 accumulation in slab order per lane, lanes summed in order (the first version walked all
+// slabs with ONE thread per channel: 139 us per call, 3.3 ms of a bf16x3 step)
 __global__ void colsum_finish_kernel(const float *__restrict__ partial, int nslabs, int c, float *__restrict__ out, int accumulate) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  __shared__ double red[16][64];
+  const int ch = blockIdx.x * 64 + threadIdx.x;
   double s = 0.0;
-  for (int k = 0; k < nslabs; ++k) s += (double)partial[(long long)k * c + ch];
-  out[ch] = accumulate ? out[ch] + (float)s : (float)s;
+  if (ch < c)
+    for (int k = threadIdx.y; k < nslabs; k += 16) s += (double)partial[(long long)k * c + ch];
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y != 0 || ch >= c) return;
+  double t = 0.0;
+  for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+  out[ch] = accumulate ? out[ch] + (float)t : (float)t;
 }
-static inline int colsum_slab(long long rows) { const long long s = (rows + 511) / 512; return (int)(s < 32 ? 32 : s); }
+static inline int colsum_slab(long long rows) { const long long s = (rows + 1023) / 1024; return (int)(s < 16 ? 16 : s); }
 extern "C" size_t nrpn_column_sum_workspace_bytes(int64_t rows, int c) { return (size_t)(cdiv64(rows, colsum_slab(rows)) * c * 4); }
 extern "C" int nrpn_column_sum_f32(const float *x, int64_t rows, int c, float *out, int accumulate, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(x && out && workspace && rows > 0 && c > 0, "column_sum: bad arguments");
   const int slab = colsum_slab(rows), nslabs = (int)cdiv64(rows, slab);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nslabs, (c + 255) / 256), dim3(256), 0, st, x, (long long)rows, c, slab, (float *)workspace);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((c + 255) / 256), dim3(256), 0, st, (const float *)workspace, nslabs, c, out, accumulate);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nslabs, c, out, accumulate);
   NRPN_LAUNCH_CHECK("column_sum");
   return NRPN_OK;
 }

@@ -750,9 +750,20 @@ def _x3_weights(pack, weights, wp, wpd):
 
 
 def column_sum_f32(t, out=None, accumulate=False):
-    """f32 [rows, C] -> f32 [C] column sums (nrpn_column_sum_f32: deterministic, any C); ``out`` += when ``accumulate``."""
+    """f32 [rows, C] -> f32 [C] column sums, deterministic; ``out`` += when ``accumulate``.  Shapes the BatchNorm statistics reduction takes
+    (C % 4 == 0, C / 4 dividing 256: every conv width of the VGG / ResNet paths) go through it -- 4-channel lanes over ~1000 row slabs, fp64
+    finish: mean * rows -- the rest (e.g. C = 96) through nrpn_column_sum_f32."""
     t = t.contiguous()
     rows, c = t.shape
+    tile = min(c, 1024)
+    if c % 4 == 0 and 256 % (tile // 4) == 0 and c % tile == 0:
+        mean, var = torch.empty(c, dtype=torch.float32, device=t.device), torch.empty(c, dtype=torch.float32, device=t.device)
+        ws = torch.empty(query("bn_workspace_bytes", rows, c), dtype=torch.uint8, device=t.device)
+        call("bn_stats", _p(t), rows, c, F32, _p(mean), _p(var), 0, 0, 0.1, _p(ws), _s())
+        res = mean * float(rows)
+        if out is None:
+            return res
+        return out.add_(res) if accumulate else out.copy_(res)
     if out is None:
         out = torch.empty(c, dtype=torch.float32, device=t.device)
     ws = torch.empty(query("column_sum_workspace_bytes", rows, c), dtype=torch.uint8, device=t.device)
