@@ -370,43 +370,54 @@ def secondary_workloads(dtype, dev, xs, gts, make, steps=12):
     from nerf_rpn_amd import ops as _o
     from nerf_rpn_amd.engine import FlatTrainer
     out = {}
+    def measure(m, tr, g, fcos, warm):
+        st = make(m, tr, xs, g, fcos)
+        for _ in range(warm):                  # eager: 3 warm-ups; graph: 2 eager warm-ups + the capture + replays
+            st()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            loss = st()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t1) / steps
+        cnt = [0]
+        orig = _o.call
+
+        def counting(nm, *a):
+            cnt[0] += 1
+            return orig(nm, *a)
+        _o.call = counting
+        enq = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            st()
+            enq.append(time.perf_counter() - th)
+        torch.cuda.synchronize()
+        _o.call = orig
+        enq.sort()
+        return {"ms_per_step": round(ms, 3), "scenes_per_s": round(1e3 / ms, 2), "steps": steps, "trunk_hip_graph": bool(m.use_graph),
+                "host_enqueue_ms_per_step": round(1e3 * enq[len(enq) // 2], 3), "c_abi_calls_per_step": round(cnt[0] / 4, 1),
+                "final_loss": round(float(loss.detach()), 5)}
+
     for name in ("resnet_rpn", "swin_rpn", "swin_fcos"):
         backbone, head = name.split("_")
         fcos = head == "fcos"
         try:
             m = build_fcos(dtype, dev, "swin0" if backbone == "swin" else backbone) if fcos else build_model(dtype, dev, backbone)
             m.use_graph = backbone == "swin"
-            tr = FlatTrainer(m, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, total_steps=steps + 32)
+            tr = FlatTrainer(m, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, total_steps=4 * steps + 64)
             g = [t.to(dev) for t in gts] if fcos else gts
-            st = make(m, tr, xs, g, fcos)
-            for _ in range(5):                  # 2 eager warm-ups + the capture + replays
-                st()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(steps):
-                loss = st()
-            torch.cuda.synchronize()
-            ms = 1e3 * (time.perf_counter() - t1) / steps
-            cnt = [0]
-            orig = _o.call
-
-            def counting(nm, *a):
-                cnt[0] += 1
-                return orig(nm, *a)
-            _o.call = counting
-            enq = []
-            for _ in range(4):
-                torch.cuda.synchronize()
-                th = time.perf_counter()
-                st()
-                enq.append(time.perf_counter() - th)
-            torch.cuda.synchronize()
-            _o.call = orig
-            enq.sort()
-            out[name] = {"ms_per_step": round(ms, 3), "scenes_per_s": round(1e3 / ms, 2), "steps": steps, "trunk_hip_graph": bool(m.use_graph),
-                         "host_enqueue_ms_per_step": round(1e3 * enq[len(enq) // 2], 3), "c_abi_calls_per_step": round(cnt[0] / 4, 1),
-                         "final_loss": round(float(loss), 5)}
-            del m, tr, st
+            res = measure(m, tr, g, fcos, 5 if m.use_graph else 3)
+            if not m.use_graph and res["host_enqueue_ms_per_step"] >= 0.9 * res["ms_per_step"]:
+                # the eager step sits on the host's enqueue rate on this box (ResNet-50: ~500 C-ABI calls per step): the trunk as captured HIP
+                # graphs (bit-identical, graphs.py) is the configuration for such a host -- both are reported, `ms_per_step` is the better one
+                m.use_graph = True
+                captured = measure(m, tr, g, fcos, 5)
+                res = {**(captured if captured["ms_per_step"] < res["ms_per_step"] else res), "eager": res, "captured_trunk": captured,
+                       "note": "eager step host-bound on this box (enqueue >= 0.9 x step): also measured with the trunk as captured HIP graphs"}
+            out[name] = res
+            del m, tr
         except Exception as e:                  # a secondary workload must never take the headline line down with it
             out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         torch.cuda.empty_cache()
@@ -698,7 +709,7 @@ def main():
                 l3 = s32()
             torch.cuda.synchronize()
             extras["bf16x3_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / 8, 3)
-            extras["bf16x3_final_loss"] = round(float(l3), 5)
+            extras["bf16x3_final_loss"] = round(float(l3.detach()), 5)
         finally:
             _o3.SPLIT3[0] = False
         del m32, tr32, s32

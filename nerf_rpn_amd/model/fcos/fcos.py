@@ -164,14 +164,17 @@ class FCOSOverNeRF(nn.Module):
         from ... import graphs as _graphs
         self.use_graph = _graphs.ENABLED[0]     # training: backbone + FPN forward / backward as two captured HIP graphs (needs an engine.FlatTrainer)
         self._trunk = None
+        self.bf16x3 = False
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dtype):
         if isinstance(dtype, str):       # "bf16x3": see NeRFRegionProposalNetwork.set_compute_dtype
             if dtype not in ("bf16x3", "fp32", "bf16"):
                 raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
-            ops.SPLIT3[0] = dtype == "bf16x3"
+            self.bf16x3 = dtype == "bf16x3"
             dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+        else:
+            self.bf16x3 = False
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
         self.compute_dtype = dtype
@@ -184,6 +187,14 @@ class FCOSOverNeRF(nn.Module):
                       value=0) for m in meshes]
 
     def forward(self, meshes, targets=None, objectness_output_paths=None):
+        prev = ops.SPLIT3[0]        # bf16x3 is a property of this model: see NeRFRegionProposalNetwork.forward
+        ops.SPLIT3[0] = prev or self.bf16x3
+        try:
+            return self._forward_impl(meshes, targets, objectness_output_paths)
+        finally:
+            ops.SPLIT3[0] = prev
+
+    def _forward_impl(self, meshes, targets=None, objectness_output_paths=None):
         if self.training:
             if targets is None:
                 torch._assert(False, "targets should not be none when in training mode")

@@ -47,17 +47,20 @@ class NeRFRegionProposalNetwork(nn.Module):
         from .. import graphs as _graphs
         self.use_graph = _graphs.ENABLED[0]     # training: backbone + FPN forward / backward as two captured HIP graphs (needs an engine.FlatTrainer)
         self._trunk = None
+        self.bf16x3 = False
         self.set_compute_dtype(kwargs.get("compute_dtype", torch.float32))
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (exact fp32 MFMA chains: the parity mode), torch.bfloat16 (throughput) or "bf16x3": fp32 activations / weights /
-        gradients with the 3x3x3 convolutions evaluated as three bf16 MFMA products of split operands (ops.SPLIT3: a process-wide switch,
-        like torch's allow_tf32 -- fp32 results to fp32 accumulation error at a fraction of the fp32 MFMA time)."""
+        gradients with the 3x3x3 convolutions evaluated as three bf16 MFMA products of split operands (fp32 results to fp32 accumulation
+        error at a fraction of the fp32 MFMA time; a property of this model -- ops.SPLIT3 / NRPN_BF16X3=1 is the process-wide form)."""
         if isinstance(dtype, str):
             if dtype not in ("bf16x3", "fp32", "bf16"):
                 raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
-            ops.SPLIT3[0] = dtype == "bf16x3"
+            self.bf16x3 = dtype == "bf16x3"
             dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+        else:
+            self.bf16x3 = False
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
         self.compute_dtype = dtype
@@ -87,6 +90,16 @@ class NeRFRegionProposalNetwork(nn.Module):
                                      f" Found invalid box {bb} for target at index {target_idx}.")
 
     def forward(self, meshes, targets=None, objectness_output_paths=None):
+        # bf16x3 is a property of THIS model: the process-wide switch of the conv functions (ops.SPLIT3) is raised for the duration of its
+        # forward pass only (backward passes follow what their forward recorded), so an fp32 and a bf16x3 model can live in one process
+        prev = ops.SPLIT3[0]
+        ops.SPLIT3[0] = prev or self.bf16x3
+        try:
+            return self._forward_impl(meshes, targets, objectness_output_paths)
+        finally:
+            ops.SPLIT3[0] = prev
+
+    def _forward_impl(self, meshes, targets=None, objectness_output_paths=None):
         if self.training:
             if targets is None:
                 torch._assert(False, "targets should not be none when in training mode")

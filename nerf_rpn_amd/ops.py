@@ -706,9 +706,10 @@ class PackedWeight:
 # bf16x3: the parity-grade fast mode (round 5).  fp32 activations / weights / gradients everywhere; the dense and row-list 3x3x3
 # convolutions -- 95 % of the step's FLOPs -- multiply SPLIT operands (hi = bf16(x), lo = bf16(x - hi)) on the bf16 MFMA kernels:
 # x * w ~ hi*whi + hi*wlo + lo*whi, fp32 accumulation, fp32 rows out (csrc/elementwise.hip: split_bf16x3_kernel).  The K axis is tripled,
-# the kernels are the bf16 ones unchanged.  A process-wide switch in the spirit of torch.backends.cuda.matmul.allow_tf32: it decides HOW an
-# fp32 convolution is computed, not what it returns (to fp32 accumulation error).  NeRFRegionProposalNetwork.set_compute_dtype("bf16x3"),
-# run_rpn.py --dtype bf16x3, NRPN_BF16X3=1.
+# the kernels are the bf16 ones unchanged.  SPLIT3 decides HOW an fp32 convolution is computed, not what it returns (to fp32 accumulation
+# error) -- in the spirit of torch.backends.cuda.matmul.allow_tf32.  A model raises it for the duration of its own forward pass
+# (NeRFRegionProposalNetwork.set_compute_dtype("bf16x3"), run_rpn.py --dtype bf16x3; backward passes follow what their forward recorded);
+# NRPN_BF16X3=1 turns it on for the whole process.
 # ======================================================================================================================
 SPLIT3 = [_os.environ.get("NRPN_BF16X3", "0") == "1"]
 _ACT_I, _W_I = 0b100, 0b010          # interleaved [rows][3C]: activations (hi | hi | lo), weights (hi | lo | hi)

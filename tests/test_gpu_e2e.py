@@ -57,12 +57,10 @@ def _eval_case(name, golden, dev, mode):
     g = golden(name)
     m = build(bool(g["rotated"]), int(g["resolution"]), dev, pre=int(g["pre"]), backbone=str(g.get("backbone", "vgg"))).eval()
     xs = [scene(s, 100 + i).to(dev) for i, s in enumerate(g["shapes"])]
-    try:
-        m.set_compute_dtype(mode)
-        with torch.no_grad():
-            (feats, props, lvls), losses, scores = m(xs)
-    finally:
-        ops.SPLIT3[0] = False
+    m.set_compute_dtype(mode)
+    with torch.no_grad():
+        (feats, props, lvls), losses, scores = m(xs)
+    assert ops.SPLIT3[0] is False and m.bf16x3 == (mode == "bf16x3")      # the switch is up only inside a bf16x3 model's forward
     assert losses == {}
     size = tuple(max(int(x.shape[d]) for x in xs) for d in (1, 2, 3))        # batched scenes are padded to the per-axis maximum
     assert_eval_matches(name, g, feats, props, lvls, scores, len(xs), dev, m.rpn.last_aux, [size] * len(xs), mode)
