@@ -460,8 +460,8 @@ def main():
     ap.add_argument("--exchange", default=None, choices=["auto", "allreduce", "rs_ag", "a2a_bf16"],
                     help="gradient exchange of the trainer (N > 1); default auto = the fastest fp32 mode of the comm-only measurement at start-up")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="backbone + FPN forward / backward as captured HIP graphs (nerf_rpn_amd/graphs.py): auto = for the Swin-S backbone, whose "
-                         "eager step is bound by the host's enqueue rate; the VGG19 step (the BASELINE metric) and the ResNet-50 step are GPU-bound and stay eager")
+                    help="backbone + FPN forward / backward as captured HIP graphs (nerf_rpn_amd/graphs.py): auto = for the Swin-S and ResNet-50 backbones, "
+                         "whose eager steps are bound by the host's enqueue rate; the VGG19 step (the BASELINE metric) is GPU-bound and stays eager")
     ap.add_argument("--model", default="vgg_rpn", choices=["vgg_rpn", "resnet_rpn", "swin_rpn", "swin_fcos", "vgg_fcos"],
                     help="vgg_rpn = the BASELINE.json metric (default); the others are secondary workloads for profiling")
     args = ap.parse_args()
@@ -513,7 +513,9 @@ def main():
     backbone, head = args.model.split("_")
     fcos = head == "fcos"
     model = build_fcos(dtype, dev, "swin0" if backbone == "swin" else backbone) if fcos else build_model(dtype, dev, backbone)
-    use_graph = args.graph == "on" or (args.graph == "auto" and backbone == "swin")     # ResNet-50 measured: 12.4-14.2 ms eager, 13.0-13.6 captured
+    # auto: the backbones whose eager step sits on the host's enqueue rate (round 5, same box: ResNet-50+RPN 13.0 ms eager with 13.1 ms of
+    # enqueue -> 10.6 ms captured; Swin-S 23.6 -> 15-16 ms); the VGG19 step is GPU-bound and 4-6 % SLOWER captured (9.17 / 9.47 vs 9.73 / 9.83)
+    use_graph = args.graph == "on" or (args.graph == "auto" and backbone in ("swin", "resnet"))
     if os.environ.get("NRPN_GRAPH") in ("0", "1"):
         use_graph = os.environ["NRPN_GRAPH"] == "1"
     model.use_graph = use_graph
