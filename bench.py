@@ -407,7 +407,7 @@ def secondary_workloads(dtype, dev, xs, gts, make, steps=12):
             m = build_fcos(dtype, dev, "swin0" if backbone == "swin" else backbone) if fcos else build_model(dtype, dev, backbone)
             m.use_graph = backbone == "swin"
             tr = FlatTrainer(m, lr=1e-4, weight_decay=0.01, clip_grad_norm=0.1, total_steps=4 * steps + 64)
-            g = [t.to(dev) for t in gts] if fcos else gts
+            g = gts           # host tensors, as the reference's loader yields them (both model families upload them on their target stream)
             res = measure(m, tr, g, fcos, 5 if m.use_graph else 3)
             if not m.use_graph and res["host_enqueue_ms_per_step"] >= 0.9 * res["ms_per_step"]:
                 # the eager step sits on the host's enqueue rate on this box (ResNet-50: ~500 C-ABI calls per step): the trunk as captured HIP
@@ -536,7 +536,7 @@ def main():
 
     # the scene grids are resident in HBM; the ground-truth boxes (NUM_GT x 7 floats) are handed over as host tensors, as the reference's
     # loader does -- the RPN uploads them on its target-preparation stream (nerf_rpn.py forward)
-    gts = [sc[1] if fcos else sc[1].cpu() for sc in scenes]
+    gts = [sc[1].cpu() for sc in scenes]
 
     def make_step(model_, trainer_, xs_, gts_):
         def step():

@@ -110,12 +110,15 @@ class FCOSModule(nn.Module):
                                                   proj2d_loss_weight=args.proj2d_loss_weight)
         self.fpn_strides, self.world_size = fpn_strides, world_size
 
-    def forward(self, grid_sizes, features, targets=None, objectness_output_paths=None):
+    def forward(self, grid_sizes, features, targets=None, objectness_output_paths=None, per_level=None, prepared=None):
+        """``per_level``: the head's per-level (logits, reg, centerness) when the caller already ran it (FCOSOverNeRF with the trunk AND the
+        head inside one captured HIP graph)."""
         dt = features[0].dtype
         feats = [hip_nn.as_ndhwc(f, dt) for f in features]
         n = feats[0].shape[0]
         geom = ops.FcosGeometry(n, [f.shape[1:4] for f in feats], self.fpn_strides[:len(feats)])
-        per_level = self.head.forward_flat(feats)
+        if per_level is None:
+            per_level = self.head.forward_flat(feats)
         logits = torch.cat([p[0] for p in per_level])
         reg = torch.cat([p[1] for p in per_level])
         ctr = torch.cat([p[2] for p in per_level])
@@ -123,7 +126,7 @@ class FCOSModule(nn.Module):
         if objectness_output_paths is not None:
             self.output_objectness(geom, logits, ctr, grid_sizes, objectness_output_paths)
         if self.training:
-            loss_cls, loss_reg, loss_ctr = self.loss_evaluator(geom, logits, reg, ctr, targets, pad_sizes)
+            loss_cls, loss_reg, loss_ctr = self.loss_evaluator(geom, logits, reg, ctr, targets, pad_sizes, prepared)
             return None, None, {"loss_cls": loss_cls, "loss_reg": loss_reg, "loss_centerness": loss_ctr}
         boxes, scores = self.box_selector_test(geom, logits.detach(), reg.detach(), ctr.detach(), grid_sizes, pad_sizes)
         return boxes, scores, {}
@@ -150,6 +153,33 @@ class FCOSModule(nn.Module):
             np.savez_compressed(output_paths[i], **all_levels)
 
 
+class _TrunkAndHead:
+    """backbone + FPN + the FCOS head towers as ONE callable with static shapes and no host decisions -- what graphs.GraphedBackbone captures
+    for the FCOS model (round 5: the head's ~150 launches per step were the eager part that kept the Swin-S + FCOS step on the host's
+    enqueue rate).  Returns the feature maps followed by the per-level (logits, reg, centerness) triples."""
+
+    def __init__(self, backbone, head):
+        self.backbone, self.head = backbone, head
+
+    @property
+    def training(self):
+        return self.backbone.training and self.head.training
+
+    @property
+    def compute_dtype(self):
+        return self.backbone.compute_dtype
+
+    def parameters(self):
+        yield from self.backbone.parameters()
+        yield from self.head.parameters()
+
+    def __call__(self, x):
+        feats = list(self.backbone(x))
+        cl = [hip_nn.as_ndhwc(f, feats[0].dtype) for f in feats]
+        per = self.head.forward_flat(cl)
+        return (*feats, *[t for triple in per for t in triple])
+
+
 class FCOSOverNeRF(nn.Module):
     """Backbone + FCOS head (reference fcos.py:289-386); ``compute_dtype`` as in NeRFRegionProposalNetwork."""
 
@@ -164,6 +194,7 @@ class FCOSOverNeRF(nn.Module):
         from ... import graphs as _graphs
         self.use_graph = _graphs.ENABLED[0]     # training: backbone + FPN forward / backward as two captured HIP graphs (needs an engine.FlatTrainer)
         self._trunk = None
+        self._prep_stream = None          # side stream of the target preparation (forward)
         self.bf16x3 = False
         self.set_compute_dtype(compute_dtype)
 
@@ -214,12 +245,41 @@ class FCOSOverNeRF(nn.Module):
         if len(meshes) > 1:
             meshes = self.transform(meshes)
         stacked = ops.stack_scenes(meshes)
+        prepared = None
+        if self.training and stacked.is_cuda and hasattr(self.backbone, "feature_grids"):
+            # Target assignment, the positive-location list and the loss normalisers hold every host synchronisation of an FCOS step and
+            # depend on the ground truth only: they are issued BEFORE the backbone, on their own stream when the boxes arrive as host
+            # tensors (what the reference's loader yields), so the host never waits for the head's outputs in the middle of the step
+            # (round 5: the step was forward + [sync] + loss / backward enqueue in series).
+            dev = stacked.device
+            n = int(stacked.shape[0])
+            grids = [tuple(int(v) for v in g) for g in self.backbone.feature_grids(tuple(int(v) for v in stacked.shape[-3:]))]
+            fm = self.fcos_module
+            geom = ops.FcosGeometry(n, grids, fm.fpn_strides[:len(grids)])
+            pad_sizes = sizes if n > 1 else None
+            main = torch.cuda.current_stream(dev)
+            if self._prep_stream is None:
+                self._prep_stream = torch.cuda.Stream(device=dev)
+            if any(t.is_cuda for t in targets):
+                self._prep_stream.wait_stream(main)           # device boxes may still have producers on the main stream
+            with torch.cuda.stream(self._prep_stream):
+                dev_targets = [t.to(dev, non_blocking=True) for t in targets]
+                prepared = fm.loss_evaluator.prepare(geom, dev_targets, pad_sizes, dev)
+            main.wait_stream(self._prep_stream)
+            for v in list(prepared.values()) + dev_targets:
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(main)
+            targets = dev_targets
+        per_level = None
         if self.use_graph and self.training and stacked.is_cuda and torch.is_grad_enabled():
             if self._trunk is None:
                 from ...graphs import GraphedBackbone
-                self._trunk = GraphedBackbone(self.backbone)
-            features = list(self._trunk(stacked))       # backbone + FPN as captured HIP graphs (graphs.py); eager until captured
+                self._trunk = GraphedBackbone(_TrunkAndHead(self.backbone, self.fcos_module.head))
+            outs = list(self._trunk(stacked))           # backbone + FPN + head towers as captured HIP graphs (graphs.py); eager until captured
+            L = len(outs) // 4
+            features = outs[:L]
+            per_level = [tuple(outs[L + 3 * l:L + 3 * l + 3]) for l in range(L)]
         else:
             features = list(self.backbone(stacked))
-        boxes, scores, losses = self.fcos_module(sizes, features, targets, objectness_output_paths)
+        boxes, scores, losses = self.fcos_module(sizes, features, targets, objectness_output_paths, per_level, prepared)
         return boxes, losses, scores

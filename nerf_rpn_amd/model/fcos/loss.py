@@ -141,13 +141,24 @@ class FCOSLossComputation(object):
         factor = loss.shape[0] // weights.shape[0]
         return (loss * weights[:, None].repeat(factor, 1)).sum() / (factor * loss.shape[1])
 
-    def __call__(self, geom, logits, reg, ctr, targets, pad_sizes):
-        """logits / ctr [total], reg [total, 6|8] flattened (level, scene, voxel) -> (cls_loss, reg_loss, centerness_loss)."""
-        labels, reg_targets, num_pos = self.prepare_targets(geom, targets, pad_sizes, logits.device)
+    def prepare(self, geom, targets, pad_sizes, device):
+        """Everything of the loss that does not depend on the network's outputs -- target assignment, the positive-location list, the centerness
+        targets and the two normalisers -- and with it EVERY host synchronisation of an FCOS training step (``nonzero`` + two ``.item()``).
+        FCOSOverNeRF runs it BEFORE the backbone on its own stream (round 5): the forward, the rest of the loss and the backward are then
+        enqueued without a synchronisation, instead of the host waiting for the head's outputs in the middle of the step."""
+        labels, reg_targets, num_pos = self.prepare_targets(geom, targets, pad_sizes, device)
         pos_inds = torch.nonzero(labels > 0).squeeze(1)
-        reg_p, rt_p, ctr_p = reg[pos_inds], reg_targets[pos_inds], ctr[pos_inds]
+        rt_p = reg_targets[pos_inds]
         ctr_t = self.compute_centerness_targets(rt_p) if pos_inds.numel() else None
         num_pos_avg, norm = self.normalisers(num_pos, ctr_t.sum() if ctr_t is not None else None)
+        return {"labels": labels, "reg_targets": reg_targets, "pos": pos_inds, "rt_p": rt_p, "ctr_t": ctr_t, "num_pos_avg": num_pos_avg, "norm": norm}
+
+    def __call__(self, geom, logits, reg, ctr, targets, pad_sizes, prepared=None):
+        """logits / ctr [total], reg [total, 6|8] flattened (level, scene, voxel) -> (cls_loss, reg_loss, centerness_loss)."""
+        pr = prepared if prepared is not None else self.prepare(geom, targets, pad_sizes, logits.device)
+        labels, reg_targets, pos_inds, rt_p, ctr_t = pr["labels"], pr["reg_targets"], pr["pos"], pr["rt_p"], pr["ctr_t"]
+        num_pos_avg, norm = pr["num_pos_avg"], pr["norm"]
+        reg_p, ctr_p = reg[pos_inds], ctr[pos_inds]
         cls_loss = ops.FocalLossFn.apply(logits, labels, 0.25) / num_pos_avg
         self.last_aux = {"labels": labels, "reg_targets": reg_targets, "pos": pos_inds}
         if pos_inds.numel() == 0:

@@ -1848,6 +1848,7 @@ class FcosHeadOutFn(torch.autograd.Function):
              _p(logits), _p(reg), _p(ctr), _s())
         ctx.save_for_backward(box_out, sc)
         ctx.meta = (wrows, rows, float(stride_mul), int(norm_reg), reg_dim, int(ctr_on_reg), cls_out.shape)
+        ctx.sink = _sink(scale)
         return logits, reg, ctr
 
     @staticmethod
@@ -1862,6 +1863,10 @@ class FcosHeadOutFn(torch.autograd.Function):
         dc = d_ctr.contiguous() if d_ctr is not None else None
         call("fcos_head_out_bwd_f32", _p(box_out), wrows, _p(sc), stride_mul, norm_reg, reg_dim, ctr_on_reg, rows, _p(dl), _p(dr), _p(dc),
              _p(d_cls), _p(d_box), _p(d_scale), _s())
+        if ctx.sink is not None:        # straight into the trainer's arena: a gradient handed back to autograd would be accumulated outside a
+            ctx.sink.slot.add_(d_scale[:1].view_as(ctx.sink.slot))      # captured backward (graphs.py) and replays would miss it
+            ctx.sink.notify()
+            return d_cls, d_box, None, None, None, None, None
         return d_cls, d_box, d_scale[:1], None, None, None, None
 
 
