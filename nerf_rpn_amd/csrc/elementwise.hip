@@ -151,39 +151,51 @@ static inline bool chan_v8(int dtype, int c, const void *a, const void *b, const
          ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
 }
 
-// finalize: block = (64 channels, 16 partial-lanes); fp64 accumulation of the fp32 block partials
+// finalize: block = (16 channels, 64 partial-lanes); fp64 accumulation of the fp32 block partials in a fixed order (lane l takes rows l, l + 64,
+// ...; the 64 lane sums are added in lane order in two levels).  Round 5: 16 channels per block instead of 64 -- these kernels are pure
+// latency (500-1000 partial rows of 2 C floats read by C / 64 = 1-8 workgroups took 7.7 us, 34 times per step); four times the workgroups
+// and four times the lanes per channel.
+constexpr int kFinCh = 16, kFinLanes = 64;
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nblocks, int c, int ch, double &s, double &q) {
-  __shared__ double rs[16][64], rq[16][64];
+  __shared__ double rs[kFinLanes][kFinCh], rq[kFinLanes][kFinCh];
+  __shared__ double rs2[4][kFinCh], rq2[4][kFinCh];
   double a = 0.0, b = 0.0;
   if (ch < c) {
-    // four independent chains so four partial rows are in flight per thread (the loop is latency-, not bandwidth-bound)
-    double a4[4] = {0.0, 0.0, 0.0, 0.0}, b4[4] = {0.0, 0.0, 0.0, 0.0};
+    // two independent chains per thread (the loop is latency-, not bandwidth-bound)
+    double a2[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0};
     int blk = threadIdx.y;
-    for (; blk + 48 < nblocks; blk += 64) {
+    for (; blk + kFinLanes < nblocks; blk += 2 * kFinLanes) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a4[u] += (double)partial[(long long)(blk + 16 * u) * 2 * c + ch];
-        b4[u] += (double)partial[(long long)(blk + 16 * u) * 2 * c + c + ch];
+      for (int u = 0; u < 2; ++u) {
+        a2[u] += (double)partial[(long long)(blk + kFinLanes * u) * 2 * c + ch];
+        b2[u] += (double)partial[(long long)(blk + kFinLanes * u) * 2 * c + c + ch];
       }
     }
-    for (; blk < nblocks; blk += 16) {
-      a4[0] += (double)partial[(long long)blk * 2 * c + ch];
-      b4[0] += (double)partial[(long long)blk * 2 * c + c + ch];
+    for (; blk < nblocks; blk += kFinLanes) {
+      a2[0] += (double)partial[(long long)blk * 2 * c + ch];
+      b2[0] += (double)partial[(long long)blk * 2 * c + c + ch];
     }
-    a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-    b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    a = a2[0] + a2[1];
+    b = b2[0] + b2[1];
   }
   rs[threadIdx.y][threadIdx.x] = a;
   rq[threadIdx.y][threadIdx.x] = b;
   __syncthreads();
+  if (threadIdx.y < 4) {
+    double t = 0.0, u = 0.0;
+    for (int k = 0; k < kFinLanes / 4; ++k) { t += rs[threadIdx.y * (kFinLanes / 4) + k][threadIdx.x]; u += rq[threadIdx.y * (kFinLanes / 4) + k][threadIdx.x]; }
+    rs2[threadIdx.y][threadIdx.x] = t;
+    rq2[threadIdx.y][threadIdx.x] = u;
+  }
+  __syncthreads();
   s = 0.0; q = 0.0;
   if (threadIdx.y == 0)
-    for (int k = 0; k < 16; ++k) { s += rs[k][threadIdx.x]; q += rq[k][threadIdx.x]; }
+    for (int k = 0; k < 4; ++k) { s += rs2[k][threadIdx.x]; q += rq2[k][threadIdx.x]; }
 }
 
 __global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int nblocks, long long rows, int c, float *__restrict__ mean,
                                          float *__restrict__ var, float *__restrict__ rmean, float *__restrict__ rvar, float momentum) {
-  const int ch = blockIdx.x * 64 + threadIdx.x;
+  const int ch = blockIdx.x * kFinCh + threadIdx.x;
   double s, q;
   reduce_partials(partial, nblocks, c, ch, s, q);
   if (threadIdx.y != 0 || ch >= c) return;
@@ -201,7 +213,7 @@ __global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int 
 
 __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblocks, int c, float *__restrict__ dbeta,
                                        float *__restrict__ dgamma, float *__restrict__ acc_beta, float *__restrict__ acc_gamma) {
-  const int ch = blockIdx.x * 64 + threadIdx.x;
+  const int ch = blockIdx.x * kFinCh + threadIdx.x;
   double s, q;
   reduce_partials(partial, nblocks, c, ch, s, q);
   if (threadIdx.y != 0 || ch >= c) return;
@@ -235,7 +247,7 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
                                          (const T *)nullptr, (long long)rows, c, (const float *)nullptr, (const float *)nullptr, 0.f, 0,
                                          (float *)workspace, kSlab));
   }
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinCh, kFinLanes), 0, st, (const float *)workspace, nb, (long long)rows, c, mean,
                      var, running_mean, running_var, momentum);
   NRPN_LAUNCH_CHECK("bn_stats");
   return NRPN_OK;
@@ -246,7 +258,7 @@ extern "C" int nrpn_bn_stats(const void *x, int64_t rows, int c, int dtype, floa
 extern "C" int nrpn_bn_stats_finalize(const float *partials, int nparts, int64_t rows, int c, float *mean, float *var, float *running_mean,
                                       float *running_var, float momentum, nrpn_stream_t stream) {
   NRPN_REQUIRE(partials && mean && var && nparts > 0 && rows > 0 && c > 0, "bn_stats_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, as_stream(stream), partials, nparts, (long long)rows, c,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinCh, kFinLanes), 0, as_stream(stream), partials, nparts, (long long)rows, c,
                      mean, var, running_mean, running_var, momentum);
   NRPN_LAUNCH_CHECK("bn_stats_finalize");
   return NRPN_OK;
@@ -440,7 +452,7 @@ extern "C" int nrpn_bn_backward(const void *x, const void *y, const void *dy, vo
     DISPATCH_T(dtype, hipLaunchKernelGGL((chan_partial_kernel<T, 1, 4>), dim3(nb, (c + 1023) / 1024), dim3(256), 0, st, (const T *)x, (const T *)y, (const T *)dy,
                                          (long long)rows, c, mean, var, eps, relu, (float *)workspace, kSlab, gamma, beta));
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinCh, kFinLanes), 0, st, (const float *)workspace, nb, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
   int fv = bn_fast_v(c, dtype);
   if (fv == 8 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15))
     fv = 0;                                                                                                // 16-byte accesses

@@ -2,12 +2,12 @@
 # Final measurement of round 5: the bench line, PMC passes (the bench's `traffic` field is tied to them), kernel-stats runs (bf16 step in its measured
 # configuration + single stream, bf16x3 step), smoke, then the whole GPU suite.  Most important first, every step under its own timeout.
 cd "$(dirname "$0")/.."
-O=gpurun_out/r5f
+O=${OUT:-gpurun_out/r5f}
 mkdir -p $O
 root=$PWD
 export TMPDIR=/tmp
-timeout 300 bash tools/pmc_conv.sh $O/pmc > $O/pmc.log 2>&1; tail -2 $O/pmc.log | cut -c1-200
-cp $O/pmc/pmc_summary.json profiles/r05_pmc_conv_256x256_40c.json
+if [ "${SKIP_PMC:-0}" != "1" ]; then timeout 300 bash tools/pmc_conv.sh $O/pmc > $O/pmc.log 2>&1; tail -2 $O/pmc.log | cut -c1-200; cp $O/pmc/pmc_summary.json profiles/r05_pmc_conv_256x256_40c.json; fi
+
 timeout 500 python bench.py > $O/bench.log 2> $O/bench.err; grep '^{' $O/bench.log > $O/bench_n1.json; python tools/bench_line.py r5f < $O/bench_n1.json | cut -c1-300
 python -c "import json; d=json.load(open('$O/bench_n1.json')); print({k: d.get(k) for k in ('ms_per_step','value','fp32_ms_per_step','bf16x3_ms_per_step','dense_head_ms_per_step')}, d['roofline']['traffic'], d['roofline']['frac'], {k: v.get('ms_per_step') for k, v in d['secondary'].items()})"
 (cd /tmp && timeout 90 rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o p --output-format csv -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe --no-extras > $root/$O/prof_bench2.log 2>&1)
