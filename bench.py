@@ -459,7 +459,7 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="per-rank batch of the TIMED region (1 = the BASELINE metric; 2 = the reference's train.sh setting)")
     ap.add_argument("--exchange", default=None, choices=["auto", "allreduce", "rs_ag", "a2a_bf16"],
                     help="gradient exchange of the trainer (N > 1); default auto = the fastest fp32 mode of the comm-only measurement at start-up")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "fwd"],
                     help="backbone + FPN forward / backward as captured HIP graphs (nerf_rpn_amd/graphs.py): auto = for the Swin-S and ResNet-50 backbones, "
                          "whose eager steps are bound by the host's enqueue rate; the VGG19 step (the BASELINE metric) is GPU-bound and stays eager")
     ap.add_argument("--model", default="vgg_rpn", choices=["vgg_rpn", "resnet_rpn", "swin_rpn", "swin_fcos", "vgg_fcos"],
@@ -516,6 +516,8 @@ def main():
     # auto: the backbones whose eager step sits on the host's enqueue rate (round 5, same box: ResNet-50+RPN 13.0 ms eager with 13.1 ms of
     # enqueue -> 10.6 ms captured; Swin-S 23.6 -> 15-16 ms); the VGG19 step is GPU-bound and 4-6 % SLOWER captured (9.17 / 9.47 vs 9.73 / 9.83)
     use_graph = args.graph == "on" or (args.graph == "auto" and backbone in ("swin", "resnet"))
+    if args.graph == "fwd":
+        use_graph = "fwd"       # forward captured, backward eager (graphs.GraphedBackbone backward="eager")
     if os.environ.get("NRPN_GRAPH") in ("0", "1"):
         use_graph = os.environ["NRPN_GRAPH"] == "1"
     model.use_graph = use_graph
@@ -756,7 +758,7 @@ def main():
                        "backend": (dist.get_backend() if dist_on else "single process")},
             "per_rank_ms_per_step": per_rank_ms,
             **({"gradient_exchange": exch} if exch else {}),
-            "weight_packs_per_step": packs_per_step, "wgrad_side_stream": side_stream, "trunk_hip_graph": bool(use_graph), **({"tuning_knobs": knobs} if knobs else {}),
+            "weight_packs_per_step": packs_per_step, "wgrad_side_stream": side_stream, "trunk_hip_graph": (use_graph if isinstance(use_graph, str) else bool(use_graph)), **({"tuning_knobs": knobs} if knobs else {}),
             "final_loss": round(final_loss, 5),
             **({"host": host} if host else {}),
             **({"rpn_head_cone": {**cone, "note": "training: the RPN head is evaluated on the receptive-field cones of the sampled anchors only "

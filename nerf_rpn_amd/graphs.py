@@ -65,6 +65,15 @@ class _GraphedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         cap = ctx.cap
+        if cap.bwd is None:
+            # forward-only capture: the backward runs EAGERLY through the autograd graph that was recorded while the forward was captured --
+            # its saved activations are the static buffers every replay rewrites -- kept alive across steps with retain_graph.  The kernels,
+            # their order and their streams (weight gradients on the side stream) are those of the eager step: only the forward's enqueue
+            # cost is gone.  Re-entrant autograd, as torch.utils.checkpoint does it.
+            sel = [(o, g) for o, g in zip(cap.outs, gs) if g is not None]
+            torch.autograd.backward([o for o, _ in sel], [g for _, g in sel], retain_graph=True)
+            cap.backward_done = True
+            return None, None
         for sg, g in zip(cap.gouts, gs):
             if g is None:
                 sg.zero_()
@@ -81,7 +90,13 @@ class _GraphedFn(torch.autograd.Function):
 class GraphedBackbone:
     """``backbone(x)`` through captured forward / backward graphs when training with gradients on a CUDA tensor; eager otherwise."""
 
-    def __init__(self, backbone, warmup=2, max_shapes=4):
+    def __init__(self, backbone, warmup=2, max_shapes=4, backward="graph"):
+        """backward = "graph": forward and backward captured (one launch each); "eager": only the forward is captured, the backward runs
+        eagerly on the recorded autograd graph (for GPU-bound steps whose backward relies on the weight-gradient stream's overlap, which a
+        captured backward does not reproduce: VGG19 -- measured 4-6 % slower fully captured)."""
+        if backward not in ("graph", "eager"):
+            raise ValueError("backward must be 'graph' or 'eager'")
+        self.backward_mode = backward
         self.backbone = backbone
         self.warmup = int(warmup)
         self.max_shapes = int(max_shapes)     # every captured input shape pins its own activation pool: scenes of further shapes run eagerly
@@ -127,7 +142,7 @@ class GraphedBackbone:
             self.eager_fallbacks += 1
             return bb(x)
         if cap.static_x.data_ptr() != x.data_ptr():
-            cap.static_x.copy_(x)
+            cap.static_x.data.copy_(x)       # (.data: the refill must not bump the version of a tensor the recorded autograd graph saved)
         return _GraphedFn.apply(cap, cap.dummy)
 
     def _sinks_everywhere(self):
@@ -143,15 +158,15 @@ class GraphedBackbone:
         cap = _Captured()
         cap.node, cap.backward_done, cap.on_backward = None, True, None
         trainer = getattr(next(iter(bb.parameters())), "_nrpn_trainer", None)
-        if trainer is not None and trainer() is not None:
-            cap.on_backward = trainer().trunk_gradients_ready(list(bb.parameters()))
+        if trainer is not None and trainer() is not None and self.backward_mode == "graph":
+            cap.on_backward = trainer().trunk_gradients_ready(list(bb.parameters()))      # (an eager backward notifies the trainer itself)
         cap.static_x = x.detach().clone()
         cap.dummy = torch.zeros(1, device=x.device, requires_grad=True)
         ops.wgrad_stream_join()
         ops.weights_changed()            # once-per-update packs inside the trunk (stem, non-arena weights) become part of the graph
         torch.cuda.synchronize()
         cap.pool = torch.cuda.graph_pool_handle()
-        cap.fwd, cap.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        cap.fwd, cap.bwd = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.backward_mode == "graph" else None)
         CAPTURING[0] = True
         try:
             with torch.cuda.graph(cap.fwd, pool=cap.pool):
@@ -162,8 +177,9 @@ class GraphedBackbone:
             live = [o for o in outs if o.requires_grad]
             if len(live) != len(outs):
                 raise RuntimeError("GraphedBackbone: every trunk output must require a gradient (is the backbone frozen?)")
-            with torch.cuda.graph(cap.bwd, pool=cap.pool):
-                torch.autograd.backward(outs, cap.gouts)
+            if cap.bwd is not None:
+                with torch.cuda.graph(cap.bwd, pool=cap.pool):
+                    torch.autograd.backward(outs, cap.gouts)
         finally:
             CAPTURING[0] = False
         torch.cuda.synchronize()

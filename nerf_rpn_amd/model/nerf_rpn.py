@@ -45,7 +45,8 @@ class NeRFRegionProposalNetwork(nn.Module):
             score_thresh=rpn_score_thresh, iou_batch_size=iou_batch_size, rotated_bbox=rotated_bbox, reg_loss_type=reg_loss_type)
         self._prep_stream = None          # side stream of the target preparation when the ground truth arrives as host tensors (forward)
         from .. import graphs as _graphs
-        self.use_graph = _graphs.ENABLED[0]     # training: backbone + FPN forward / backward as two captured HIP graphs (needs an engine.FlatTrainer)
+        self.use_graph = _graphs.ENABLED[0]     # training: backbone + FPN forward / backward as two captured HIP graphs (needs an engine.FlatTrainer);
+                                                # "fwd": only the forward is captured, the backward stays eager (graphs.GraphedBackbone)
         self._trunk = None
         self.bf16x3 = False
         self.set_compute_dtype(kwargs.get("compute_dtype", torch.float32))
@@ -153,7 +154,7 @@ class NeRFRegionProposalNetwork(nn.Module):
         if self.use_graph and self.training and mesh_tensors.is_cuda and torch.is_grad_enabled():
             if self._trunk is None:
                 from ..graphs import GraphedBackbone
-                self._trunk = GraphedBackbone(self.backbone)
+                self._trunk = GraphedBackbone(self.backbone, backward="eager" if self.use_graph == "fwd" else "graph")
             features = list(self._trunk(mesh_tensors))       # backbone + FPN as captured HIP graphs (graphs.py); eager until captured
         else:
             features = list(self.backbone(mesh_tensors))

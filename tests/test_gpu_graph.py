@@ -136,3 +136,20 @@ def test_a_second_trainer_invalidates_the_captures_and_a_second_forward_runs_eag
         assert float(b.abs().max()) > 0 and torch.equal(a, b), (i, (a - b).abs().max().item())
     assert graph[4] == 1                              # the second forward of the pair ran eagerly
     assert torch.equal(eager[3], graph[3]), (eager[3] - graph[3]).abs().max().item()
+
+
+@pytest.mark.parametrize("backbone,dtype", [("vgg", torch.bfloat16), ("vgg", torch.float32), ("resnet", torch.bfloat16)])
+def test_forward_only_capture_with_eager_backward_is_bit_identical(backbone, dtype, golden, dev):
+    """use_graph = "fwd" (round 5): only the trunk's forward is captured; its backward runs eagerly, every step, on the autograd graph recorded
+    during the capture (retain_graph; saved activations = the static buffers each replay rewrites) -- the eager step's kernels, order and
+    streams (weight gradients on the side stream), without the forward's enqueue cost.  Losses, the gradient arena of every step, the weights
+    and the BatchNorm buffers equal the eager run bit for bit over 6 steps with three different scenes in turn."""
+    eager = _run(dev, golden, False, backbone, dtype)
+    fwd = _run(dev, golden, "fwd", backbone, dtype)
+    assert eager[4] == 0 and fwd[4] == 1
+    assert eager[0] == fwd[0], (eager[0], fwd[0])
+    for i, (a, b) in enumerate(zip(eager[1], fwd[1])):
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+    assert torch.equal(eager[2], fwd[2])
+    for k, v in eager[3].items():
+        assert torch.equal(v, fwd[3][k]), k
