@@ -182,9 +182,10 @@ class FlatTrainer:
                 self.exchange = best[0]
                 self._build_buckets(best[1] << 20)
                 if (dist.get_rank(self.group) == 0) and os.environ.get("NRPN_QUIET") != "1":
+                    import sys
                     print(f"[nerf_rpn_amd] gradient exchange: {self.exchange} with {best[1]} MiB buckets "
                           f"(comm-only ms: { {f'{m}@{b}': v for (m, b), v in sorted(self.exchange_table.items())} }); pin with "
-                          f"NRPN_GRAD_EXCHANGE={self.exchange} NRPN_GRAD_BUCKET_MIB={best[1]}", flush=True)
+                          f"NRPN_GRAD_EXCHANGE={self.exchange} NRPN_GRAD_BUCKET_MIB={best[1]}", file=sys.stderr, flush=True)      # (stderr: bench.py's stdout is ONE JSON line)
             else:
                 self.exchange = "allreduce"
         elif self.exchanging and os.environ.get("NRPN_GRAD_BUCKET_MIB"):
