@@ -2092,8 +2092,13 @@ __device__ __forceinline__ f4 wg_frag(const char *tile, int ctile0, int kbase, i
   }
 }
 
-template <typename T, int MODE, bool TR, bool ROWS = false>
+// PACK2 (round 5, MODE 0 dense k3 only): layers with Cin <= 64 fill a quarter (Cout 64) or half (Cout 128) of the 128 x 128 tile and ran at
+// 150 / 290 TFLOP/s.  A workgroup then owns a PAIR of taps: the B tile's 128 columns hold [tap 2t: <= 64 channels | tap 2t + 1: <= 64 channels]
+// -- one shared dY tile, two shifted X rows per voxel row -- so the wave column wn IS the tap of the pair; 14 workgroups per (tile, slice)
+// instead of 27 (tap 27 does not exist: its half reads zeros and is not stored).
+template <typename T, int MODE, bool TR, bool ROWS = false, bool PACK2 = false>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
+  static_assert(!PACK2 || (MODE == 0 && !ROWS), "PACK2 is a dense MODE 0 form");
   constexpr int KV = WgCfg<T>::KV, RS = WgCfg<T>::RS;
   constexpr int TILE = KV * RS;
   constexpr int PIECES_ROW = 128 * (int)sizeof(T) / 16;       // 16-byte pieces per 128-channel row: 16 (bf16) / 32 (fp32)
@@ -2105,16 +2110,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   // 1-D grid, voxel slice slowest: id = ((slice * taps + tap) * ntn + ntile) * ntm + mtile.  All workgroups of a slice read the
   // same dY / X rows, and the XCD remap keeps a slice on one XCD's L2.
-  const unsigned ntm = (p.wrows + 127) / 128, ntn = p.ntiles_n, tps = (MODE == 0) ? p.taps : 1;
+  const unsigned ntm = (p.wrows + 127) / 128, ntn = p.ntiles_n, tps = PACK2 ? 14u : ((MODE == 0) ? (unsigned)p.taps : 1u);
   unsigned id = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (int)(id % ntm) * 128;   // cout tile
   id /= ntm;
-  const int n0 = (int)(id % ntn) * 128;   // cin tile (MODE 0) / k tile (MODE 1)
+  const int n0 = (int)(id % ntn) * 128;   // cin tile (MODE 0) / k tile (MODE 1); PACK2: 0
   id /= ntn;
-  const int tap = (int)(id % tps);
+  const int tap = PACK2 ? 2 * (int)(id % tps) : (int)(id % tps);      // PACK2: the pair's first tap; the second is tap + 1 (< 27 or absent)
   const int slice = (int)(id / tps);
   int dx = 0, dy = 0, dz = 0;
   if (MODE == 0 && p.taps == 27) { dx = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dz = tap % 3 - 1; }
+  const bool tap1_ok = PACK2 && tap + 1 < 27;
 
   const long long chunks = (p.M + KV - 1) / KV;
   const long long per = (chunks + p.ksplit - 1) / p.ksplit;
@@ -2134,15 +2140,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   // byte shift of this workgroup's tap inside each segment's own grid (classic layout: one entry); the mask word of a voxel
   // carries its segment id in bits 27..31
   __shared__ int seg_shift[kMaxSeg];
+  __shared__ int seg_shift1[PACK2 ? kMaxSeg : 1];       // PACK2: the pair's second tap
   if (MODE == 0 && tid < kMaxSeg) {
     int Y = p.Y, Z = p.Z;
 #pragma unroll
     for (int q = 0; q < kMaxSeg; ++q)
       if (q == tid && q < p.segs.n) { Y = p.segs.Y[q]; Z = p.segs.Z[q]; }
     seg_shift[tid] = (int)((((long long)dx * Y + dy) * Z + dz) * p.Cin * (long long)sizeof(T));
+    if (PACK2) {
+      const int t1 = tap + 1, dx1 = t1 / 9 - 1, dy1 = (t1 / 3) % 3 - 1, dz1 = t1 % 3 - 1;
+      seg_shift1[tid] = (int)((((long long)dx1 * Y + dy1) * Z + dz1) * p.Cin * (long long)sizeof(T));
+    }
   }
   __syncthreads();
   unsigned a_voff[PIECES], b_voff[PIECES], m_voff[PIECES], m_next[PIECES];
+  bool b_half[PIECES];           // PACK2: this thread's B piece i belongs to the pair's second tap
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) b_half[i] = false;
   unsigned r_vox[PIECES];        // ROWS: voxel id of the row this piece belongs to in the NEXT chunk (fetched with its tap word)
   typedef __attribute__((ext_vector_type(2))) unsigned int rowpair;
   const bool use_mask = MODE == 0 && p.taps == 27;
@@ -2151,7 +2165,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
     const int pc = tid + 256 * i;
     const int row = pc / PIECES_ROW, col = (pc % PIECES_ROW) ^ ((row & 3) << 2);   // logical column of physical slot pc % PIECES_ROW
     const long long v = c_begin * KV + row;
-    const int ca = m0 + col * (16 / (int)sizeof(T)), cb = n0 + col * (16 / (int)sizeof(T));
+    const int ca = m0 + col * (16 / (int)sizeof(T));
+    // PACK2: logical pieces [0, PIECES_ROW / 2) of a B row belong to the pair's first tap, the rest to the second; both start at channel 0
+    const int cb = PACK2 ? (col % (PIECES_ROW / 2)) * (16 / (int)sizeof(T)) : n0 + col * (16 / (int)sizeof(T));
+    if (PACK2) b_half[i] = col >= PIECES_ROW / 2;
     r_vox[i] = 0;
     if (MODE == 0 && ROWS) {     // only the column part is loop invariant; the row part comes from the list, chunk by chunk
       a_voff[i] = ca < p.Cout ? (unsigned)(ca * (int)sizeof(T)) : kOOB;
@@ -2255,8 +2272,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
         continue;
       }
       lds_dma16(dyr, A + dst, a_voff[i]);
-      const bool in = (m_next[i] >> tap) & 1u;
-      lds_dma16(xr, B + dst, (in && b_voff[i] != kOOB) ? b_voff[i] + (unsigned)seg_shift[m_next[i] >> 27] : kOOB);
+      bool in = (m_next[i] >> tap) & 1u;
+      unsigned shift = (unsigned)seg_shift[m_next[i] >> 27];
+      if (PACK2 && b_half[i]) {
+        in = tap1_ok && ((m_next[i] >> (tap + 1)) & 1u);
+        shift = (unsigned)seg_shift1[m_next[i] >> 27];
+      }
+      lds_dma16(xr, B + dst, (in && b_voff[i] != kOOB) ? b_voff[i] + shift : kOOB);
       a_voff[i] = a_voff[i] == kOOB ? kOOB : a_voff[i] + a_step;
       b_voff[i] = b_voff[i] == kOOB ? kOOB : b_voff[i] + b_step;
       m_voff[i] += KV * 4;
@@ -2285,7 +2307,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool do_bias = p.gbias != nullptr && n0 == 0 && tap == ((MODE == 0 && p.taps == 27) ? 13 : 0);
+  const bool do_bias = p.gbias != nullptr && n0 == 0 && tap == (PACK2 ? 12 : ((MODE == 0 && p.taps == 27) ? 13 : 0));      // PACK2: the pair (12, 13)
   float bias_acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (MODE == 0) issue_dma(0);
   else { load_chunk(c_begin); store_chunk(0); }
@@ -2344,8 +2366,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
   const int fr = lane & 31;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int col = n0 + (wn * 2 + j) * 32 + fr;
+    int col = n0 + (wn * 2 + j) * 32 + fr;
     const int ncols = (MODE == 0) ? p.Cin : p.kpad;
+    int otap = tap;
+    if (PACK2) {        // tile columns [0, 64) = the pair's first tap, [64, 128) = its second: wave column wn IS the tap of the pair
+      otap = tap + (col >> 6);
+      col &= 63;
+      if (otap >= 27) continue;
+    }
     if (col >= ncols) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -2354,7 +2382,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
         const int row = m0 + (wm * 2 + i) * 32 + frag_row(r, lane);
         if (row < p.wrows) {   // plain store into this slice's partial gradient (summed by nrpn_unpack_*_wgrad): no atomics, no memset
           float *dst = p.gw + slice * p.slice_stride +
-                       ((MODE == 0) ? ((long long)tap * p.wrows + row) * p.Cin + col : (long long)row * p.kpad + col);
+                       ((MODE == 0) ? ((long long)otap * p.wrows + row) * p.Cin + col : (long long)row * p.kpad + col);
           *dst = acc[i][j][r];
         }
       }
@@ -2367,8 +2395,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 // bytes pulled through the CU's vector-memory path per MFMA (the 128x128 tile moves 32 KB per 16 MFMAs per wave and saturates
 // it).  One workgroup = (cout tile, cin tile, tap, voxel slice); fp32 atomics into the packed gradient.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool ROWS>
+// PACK2 (round 5, dense k3, Cin == 128, Cout >= 256: layers.5.0 of VGG19): the two B sub-tiles hold the SAME 128 input channels of a PAIR of
+// taps (sub-tile t = tap 2s + t) instead of channels [0, 128) / [128, 256) of one tap -- the layer ran on the 128 x 128 kernel at 580 TFLOP/s
+// because half of a 256-column tile would have been empty.  14 workgroups per (tile, slice); tile columns [128 t, 128 t + 128) = tap 2s + t.
+template <bool ROWS, bool PACK2 = false>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs p) {
+  static_assert(!(ROWS && PACK2), "PACK2 is a dense form");
   typedef bf16s T;
   constexpr int KV = 64, RS = 256, SUB = KV * RS;            // 16 KB sub-tile
   constexpr int PIECES_ROW = 16, KSUB = 16, TM = 4, TN = 2;
@@ -2376,16 +2408,17 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
-  const unsigned ntm = (p.wrows + 255) / 256, ntn = p.ntiles_n, tps = p.taps;
+  const unsigned ntm = (p.wrows + 255) / 256, ntn = p.ntiles_n, tps = PACK2 ? 14u : (unsigned)p.taps;
   unsigned id = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (int)(id % ntm) * 256;
   id /= ntm;
   const int n0 = (int)(id % ntn) * 256;
   id /= ntn;
-  const int tap = (int)(id % tps);
+  const int tap = PACK2 ? 2 * (int)(id % tps) : (int)(id % tps);       // PACK2: the pair's first tap
   const int slice = (int)(id / tps);
   int dx = 0, dy = 0, dz = 0;
   if (p.taps == 27) { dx = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dz = tap % 3 - 1; }
+  const bool tap1_ok = PACK2 && tap + 1 < 27;
   const long long chunks = (p.M + KV - 1) / KV;
   const long long per = (chunks + p.ksplit - 1) / p.ksplit;
   const long long c_begin = slice * per, c_end = min(chunks, c_begin + per);
@@ -2394,12 +2427,17 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dyr = make_rsrc(p.dy, p.dy_bytes);
   const __amdgpu_buffer_rsrc_t mr = ROWS ? make_rsrc(p.rows, (unsigned)(p.M * 8)) : make_rsrc(p.vmask, (unsigned)(p.M * 4));
   __shared__ int seg_shift[kMaxSeg];            // byte shift of this tap inside each segment's grid (see conv_wgrad_kernel)
+  __shared__ int seg_shift1[PACK2 ? kMaxSeg : 1];       // PACK2: the pair's second tap
   if (tid < kMaxSeg) {
     int Y = p.Y, Z = p.Z;
 #pragma unroll
     for (int q = 0; q < kMaxSeg; ++q)
       if (q == tid && q < p.segs.n) { Y = p.segs.Y[q]; Z = p.segs.Z[q]; }
     seg_shift[tid] = (int)((((long long)dx * Y + dy) * Z + dz) * p.Cin * 2);
+    if (PACK2) {
+      const int t1 = tap + 1, dx1 = t1 / 9 - 1, dy1 = (t1 / 3) % 3 - 1, dz1 = t1 % 3 - 1;
+      seg_shift1[tid] = (int)((((long long)dx1 * Y + dy1) * Z + dz1) * p.Cin * 2);
+    }
   }
   __syncthreads();
   const bool use_mask = p.taps == 27;
@@ -2414,7 +2452,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
     const long long v = c_begin * KV + row;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int ca = m0 + 128 * t + col * 8, cb = n0 + 128 * t + col * 8;
+      const int ca = m0 + 128 * t + col * 8, cb = PACK2 ? col * 8 : n0 + 128 * t + col * 8;       // PACK2: both B sub-tiles start at channel 0
       if (ROWS) {     // only the column part is loop invariant; the row part comes from the list, chunk by chunk
         a_voff[t][i] = ca < p.Cout ? (unsigned)(ca * 2) : kOOB;
         b_voff[t][i] = cb < p.Cin ? (unsigned)(cb * 2) : kOOB;
@@ -2456,10 +2494,14 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
         r_vox[i] = rp[0]; m_next[i] = rp[1];
         continue;
       }
-      const bool in = (m_next[i] >> tap) & 1u;
-      const unsigned tsh = (unsigned)seg_shift[m_next[i] >> 27];
+      const bool in0 = (m_next[i] >> tap) & 1u;
+      const unsigned tsh0 = (unsigned)seg_shift[m_next[i] >> 27];
+      const bool in1 = PACK2 ? (tap1_ok && ((m_next[i] >> (tap + 1)) & 1u)) : in0;
+      const unsigned tsh1 = PACK2 ? (unsigned)seg_shift1[m_next[i] >> 27] : tsh0;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        const bool in = t ? in1 : in0;
+        const unsigned tsh = t ? tsh1 : tsh0;
         lds_dma16(dyr, base + t * SUB + dst, a_voff[t][i]);
         lds_dma16(xr, base + (2 + t) * SUB + dst, (in && b_voff[t][i] != kOOB) ? b_voff[t][i] + tsh : kOOB);
         a_voff[t][i] = a_voff[t][i] == kOOB ? kOOB : a_voff[t][i] + a_step;
@@ -2479,7 +2521,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool do_bias = p.gbias != nullptr && n0 == 0 && tap == (p.taps == 27 ? 13 : 0);
+  const bool do_bias = p.gbias != nullptr && n0 == 0 && tap == (PACK2 ? 12 : (p.taps == 27 ? 13 : 0));       // PACK2: the pair (12, 13)
   float bias_acc[2][8];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -2572,14 +2614,20 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_big_kernel(const WgradArgs 
   const int fr = elane & 31;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + fr;
+    int col = n0 + wn * 64 + j * 32 + fr;
+    int otap = tap;
+    if (PACK2) {        // tile columns [0, 128) = the pair's first tap, [128, 256) = its second
+      otap = tap + (col >> 7);
+      col &= 127;
+      if (otap >= 27) continue;
+    }
     if (col >= p.Cin) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 128 + i * 32 + frag_row(r, elane);
-        if (row < p.wrows) p.gw[slice * p.slice_stride + ((long long)tap * p.wrows + row) * p.Cin + col] = acc[i][j][r];
+        if (row < p.wrows) p.gw[slice * p.slice_stride + ((long long)otap * p.wrows + row) * p.Cin + col] = acc[i][j][r];
       }
   }
 }
@@ -2860,18 +2908,23 @@ extern "C" int nrpn_set_wgrad_big_tile(int on) { g_wgrad_big = on ? 1 : 0; retur
 
 // How the voxel axis is cut: every (tile, tap, slice) workgroup writes one partial gradient; the slices are summed by the
 // unpack kernels.  `ksplit` is trimmed so that no slice is empty (every partial is fully written).
+// two taps per workgroup (conv_wgrad_kernel<..., PACK2>): dense k3 layers whose input row fits half a B-tile row (Cin <= 64)
+static std::atomic<int> g_wgrad_pack2{1};
+extern "C" int nrpn_set_wgrad_pack2(int on) { g_wgrad_pack2 = on ? 1 : 0; return NRPN_OK; }
+static bool wgrad_pack2(int cin, int taps, int mode) { return g_wgrad_pack2.load(std::memory_order_relaxed) && mode == 0 && taps == 27 && cin <= 64; }
 struct WgPlan { int ksplit; bool big; };
 static WgPlan wgrad_plan(long long M, int wrows, int ncols, int taps, int elem_bytes, int mode, int cout, int cin) {
   WgPlan pl{1, false};
   const int kv = elem_bytes == 4 ? 32 : 64;
   const long long chunks = (M + kv - 1) / kv;
   long long ks = 1;
-  if (mode == 0 && elem_bytes == 2 && g_wgrad_big && g_wgrad_tr_mode != 0 && cout >= 256 && cin >= 256) {
+  const bool big_pack2 = g_wgrad_pack2.load(std::memory_order_relaxed) && taps == 27 && cin == 128;      // conv_wgrad_big_kernel<false, PACK2>
+  if (mode == 0 && elem_bytes == 2 && g_wgrad_big && g_wgrad_tr_mode != 0 && cout >= 256 && (cin >= 256 || big_pack2)) {
     // 256x256 tiles, one 128 KB-LDS workgroup per CU: pick the slice count with the lowest modelled time
     //   t(k) = MFMA time / (fill of whole rounds of 256 CUs) + (k + 1) partial-gradient passes through HBM,
     // e.g. 256->256 @40^3: 27 tiles x 9 slices = 243 workgroups (95 % of a round) instead of 8 (84 %); 512->512 @20^3 stays at 2
     // slices because each extra slice costs another 28 MB partial.
-    const int tiles = ((wrows + 255) / 256) * ((cin + 255) / 256) * taps;
+    const int tiles = ((wrows + 255) / 256) * ((cin + 255) / 256) * ((big_pack2 && cin == 128) ? 14 : taps);
     const double flops = 2.0 * (double)M * wrows * cin * taps;
     const double part_bytes = 4.0 * (double)taps * wrows * cin;
     double best = 1e30;
@@ -2885,7 +2938,7 @@ static WgPlan wgrad_plan(long long M, int wrows, int ncols, int taps, int elem_b
     }
   }
   if (!pl.big) {
-    const int tiles = ((wrows + 127) / 128) * ((ncols + 127) / 128) * taps;
+    const int tiles = ((wrows + 127) / 128) * ((ncols + 127) / 128) * (wgrad_pack2(cin, taps, mode) ? 14 : taps);
     ks = (1024 + tiles - 1) / tiles;
     if (ks > chunks / 16) ks = chunks / 16;     // >= 16 chunks per workgroup so the 128x128 epilogue stays amortised
     if (ks < 1) ks = 1;
@@ -2907,6 +2960,16 @@ static int launch_wgrad(WgradArgs a, int ntiles_n, hipStream_t st) {
       NRPN_LDS((conv_wgrad_kernel<T, 0, true, true>), (int)lds);
       hipLaunchKernelGGL((conv_wgrad_kernel<T, 0, true, true>), grid, dim3(256), lds, st, a);
       NRPN_LAUNCH_CHECK("conv_wgrad_rows");
+      return NRPN_OK;
+    }
+  }
+  if constexpr (MODE == 0) {
+    if (tr && !a.rows && wgrad_pack2(a.Cin, a.taps, 0)) {        // two taps per workgroup: 14 instead of 27 workgroups per (tile, slice)
+      grid = dim3((unsigned)(((a.wrows + 127) / 128) * 14 * a.ksplit));
+      a.ntiles_n = 1;
+      NRPN_LDS((conv_wgrad_kernel<T, 0, true, false, true>), (int)lds);
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, 0, true, false, true>), grid, dim3(256), lds, st, a);
+      NRPN_LAUNCH_CHECK("conv_wgrad_pack2");
       return NRPN_OK;
     }
   }
@@ -2971,6 +3034,11 @@ static int conv3d_wgrad_impl(const void *x, const void *dy, float *gw_packed, fl
     if (a.rows) {
       NRPN_LDS(conv_wgrad_big_kernel<true>, (int)lds);
       hipLaunchKernelGGL(conv_wgrad_big_kernel<true>, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);
+    } else if (cin == 128 && a.taps == 27) {          // wgrad_plan only says `big` for Cin 128 when the pair form is on
+      const int tiles2 = ((wrows + 255) / 256) * 14;
+      a.ntiles_n = 1;
+      NRPN_LDS((conv_wgrad_big_kernel<false, true>), (int)lds);
+      hipLaunchKernelGGL((conv_wgrad_big_kernel<false, true>), dim3((unsigned)(tiles2 * a.ksplit)), dim3(512), lds, st, a);
     } else {
       NRPN_LDS(conv_wgrad_big_kernel<false>, (int)lds);
       hipLaunchKernelGGL(conv_wgrad_big_kernel<false>, dim3((unsigned)(tiles * a.ksplit)), dim3(512), lds, st, a);

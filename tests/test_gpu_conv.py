@@ -690,3 +690,47 @@ def test_bf16x3_conv_is_fp32_grade(n, grid, cin, cout, relu, dev):
         print(f"[bf16x3] {cin}->{cout}@{grid} {k}: fp32 kernel {e32:.2e}, bf16x3 {e3:.2e} vs torch fp32; bf16x3 vs fp32 kernel {e:.2e}")
         assert e3 < 3e-5, (k, e3, e32)
         assert e < 3e-5, (k, e)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,grid,cin,cout", [(1, (12, 10, 9), 64, 64), (2, (9, 8, 7), 64, 128), (1, (8, 8, 6), 32, 96), (1, (24, 22, 20), 128, 256),
+                                             (2, (20, 16, 17), 128, 320)])
+def test_wgrad_two_taps_per_workgroup(n, grid, cin, cout, dtype, dev):
+    """conv_wgrad_kernel<..., PACK2> (round 5): dense 3x3x3 layers with Cin <= 64 -- a workgroup owns a PAIR of taps, the B tile holds
+    [tap 2t | tap 2t + 1], 14 workgroups per (tile, slice), the 27th tap's partner absent -- and conv_wgrad_big_kernel<false, PACK2> for bf16
+    layers with Cin == 128, Cout >= 256 (the two 128-channel B sub-tiles = the two taps of a pair; nrpn_conv3d_wgrad_plan says 256x256).  Weight and bias gradients against torch fp32 on the
+    CPU (the tolerance of test_conv_forward_backward) and against the one-tap-per-workgroup form of the same kernel (nrpn_set_wgrad_pack2(0)):
+    the same products in another slice grouping."""
+    from nerf_rpn_amd import lib
+    from nerf_rpn_amd.model import hip_nn
+    if dtype == torch.bfloat16 and (cin * 2) % 64:
+        pytest.skip("Cin*2 must be a multiple of 64 bytes")
+    torch.manual_seed(cin + cout)
+    conv = nn.Conv3d(cin, cout, 3, padding=1)
+    x = torch.randn(n, cin, *grid)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        conv.weight.data = conv.weight.data.bfloat16().float()
+    y = conv(x)
+    gy = torch.randn_like(y)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    y.backward(gy)
+    got = {}
+    code = lib.BF16 if dtype == torch.bfloat16 else lib.F32
+    if cin == 128:
+        assert lib.query("conv3d_wgrad_plan", n, *grid, cin, cout, cout, 3, code) == (1 if dtype == torch.bfloat16 else 0)
+    try:
+        for on in (1, 0):
+            lib.call("set_wgrad_pack2", on)
+            h = nn.Conv3d(cin, cout, 3, padding=1).to(dev)
+            h.load_state_dict(conv.state_dict())
+            hip_nn.conv3d(h, cl(x).to(dev).to(dtype)).backward(cl(gy).to(dev).to(dtype))
+            torch.cuda.synchronize()
+            got[on] = (h.weight.grad.cpu(), h.bias.grad.cpu())
+    finally:
+        lib.call("set_wgrad_pack2", 1)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for on in (1, 0):
+        assert relerr(got[on][0], conv.weight.grad) < tol and relerr(got[on][1], conv.bias.grad) < tol, (on, relerr(got[on][0], conv.weight.grad))
+    assert relerr(got[1][0], got[0][0]) < 2e-5 and relerr(got[1][1], got[0][1]) < 2e-5
