@@ -35,6 +35,10 @@ int nrpn_set_wgrad_big_tile(int on);
 /* 128x128 wgrad kernel, dense 3x3x3 layers with Cin <= 64: 1 (default) = a workgroup owns a PAIR of taps (B tile = [tap 2t | tap 2t + 1], one shared
  * dY tile, 14 workgroups per (tile, slice)), 0 = one tap per workgroup (the tile a quarter / half full) */
 int nrpn_set_wgrad_pack2(int on);
+/* gradient sum of squares (nrpn_grad_sumsq), A/B only: form 0 (default) = one contiguous range per block, four 16-byte loads in flight per lane;
+ * 1 = the same ranges with eight loads in flight; 2 = grid-stride with eight loads in flight.  grid = blocks launched (64 .. 2048; default 1024).
+ * The result is deterministic for a given (form, grid); different settings add the fp32 partials in a different order. */
+int nrpn_set_sumsq_form(int form, int grid);
 /* bf16 wgrad operand fetch: 1 (default) = ds_read_b64_tr_b16 transpose reads, 0 = scalar 16-bit LDS gathers. */
 int nrpn_set_wgrad_transpose_read(int on);
 /* row-list conv (nrpn_conv3d_fwd_rows): 1 = lists of >= 96 tiles of 256 rows run the 256x256 tile (measured 0.4 % slower: kept for A/B), 0 (default) = 128-row tiles */

@@ -1043,31 +1043,61 @@ extern "C" int nrpn_a2a_reduce_bf16(const void *recv, const float *local, int ra
 }
 
 // =====================================================================================================================
-// Deterministic sum of squares: kSumsqBlocks fixed-size partials (each a fixed-order tree), and the block that takes the last
-// ticket adds the partials in index order -- the result does not depend on which block finishes last.
-// buf: [0] result, [1] ticket counter (u32, zeroed by the launcher), [2 .. 2 + kSumsqBlocks) partials.
-constexpr int kSumsqBlocks = 1024;
+// Deterministic sum of squares: one fixed-order partial per block, added in index order by sumsq_finish_kernel.
+// buf: [0] result, [1] unused (was a ticket counter), [2 .. 2 + kSumsqBlocks) partials.
+constexpr int kSumsqBlocks = 2048;       // capacity of the partials buffer; the launched grid is g_sumsq_grid (<= this)
+static int g_sumsq_grid = 1024, g_sumsq_form = 0;   // tools switch nrpn_set_sumsq_form: A/B only, defaults are the measured best
+
+// FORM 0: each block owns one contiguous range (four 16-byte loads in flight per lane).  FORM 1: same ranges, eight loads in flight.
+// FORM 2: grid-stride -- at any instant the whole grid reads one moving window (what adamw_kernel does), eight loads in flight.
+template <int FORM>
 __global__ void __launch_bounds__(256) sumsq_kernel(const float *__restrict__ g, long long count, float scale, float *__restrict__ buf) {
   __shared__ float sh[256];
-  __shared__ bool last;
   const long long n4 = count / 4;
-  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
-  const long long b0 = (long long)blockIdx.x * per, b1 = min(n4, b0 + per);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   const f4 *g4 = reinterpret_cast<const f4 *>(g);
-  long long i = b0 + threadIdx.x;
-  for (; i + 768 < b1; i += 1024) {       // four independent 16-byte loads in flight per lane
-    const f4 a = g4[i], b = g4[i + 256], c = g4[i + 512], d = g4[i + 768];
+  auto acc4 = [&](const f4 &a, const f4 &b, const f4 &c, const f4 &d) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float ta = a[k] * scale, tb = b[k] * scale, tc = c[k] * scale, td = d[k] * scale;
       s0 += ta * ta; s1 += tb * tb; s2 += tc * tc; s3 += td * td;
     }
-  }
-  for (; i < b1; i += 256) {
-    const f4 a = g4[i];
+  };
+  if constexpr (FORM == 2) {
+    const long long S = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * S < n4; i += 8 * S) {
+      const f4 a = g4[i], b = g4[i + S], c = g4[i + 2 * S], d = g4[i + 3 * S];
+      const f4 a2 = g4[i + 4 * S], b2 = g4[i + 5 * S], c2 = g4[i + 6 * S], d2 = g4[i + 7 * S];
+      acc4(a, b, c, d);
+      acc4(a2, b2, c2, d2);
+    }
+    for (; i < n4; i += S) {
+      const f4 a = g4[i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const float ta = a[k] * scale; s0 += ta * ta; }
+      for (int k = 0; k < 4; ++k) { const float ta = a[k] * scale; s0 += ta * ta; }
+    }
+  } else {
+    const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long b0 = (long long)blockIdx.x * per, b1 = min(n4, b0 + per);
+    long long i = b0 + threadIdx.x;
+    if constexpr (FORM == 1) {
+      for (; i + 1792 < b1; i += 2048) {
+        const f4 a = g4[i], b = g4[i + 256], c = g4[i + 512], d = g4[i + 768];
+        const f4 a2 = g4[i + 1024], b2 = g4[i + 1280], c2 = g4[i + 1536], d2 = g4[i + 1792];
+        acc4(a, b, c, d);
+        acc4(a2, b2, c2, d2);
+      }
+    }
+    for (; i + 768 < b1; i += 1024) {       // four independent 16-byte loads in flight per lane
+      const f4 a = g4[i], b = g4[i + 256], c = g4[i + 512], d = g4[i + 768];
+      acc4(a, b, c, d);
+    }
+    for (; i < b1; i += 256) {
+      const f4 a = g4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float ta = a[k] * scale; s0 += ta * ta; }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(count - n4 * 4)) { const float t = g[n4 * 4 + threadIdx.x] * scale; s1 += t * t; }
   sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
@@ -1076,16 +1106,16 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float *__restrict__ g,
     if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    buf[2 + blockIdx.x] = sh[0];
-    __threadfence();
-    last = atomicAdd(reinterpret_cast<unsigned *>(buf + 1), 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
+  if (threadIdx.x == 0) buf[2 + blockIdx.x] = sh[0];
+}
+
+// Adds the per-block partials in index order (one block, fixed tree).  Round 5: this used to be the tail of sumsq_kernel behind a ticket counter
+// (threadfence + atomicAdd per block); measured, the ticket cost ~50 ns PER BLOCK, serialised (61 / 86 / 138 us at 512 / 1024 / 2048 blocks whatever
+// the read pattern: a device-scope release on gfx950 writes back the XCD's L2) -- more than the 37 us the 299 MB read takes.  A second launch is ~3 us.
+__global__ void __launch_bounds__(256) sumsq_finish_kernel(float *__restrict__ buf, int parts) {
+  __shared__ float sh[256];
   float t = 0.f;
-  for (int k = threadIdx.x; k < (int)gridDim.x; k += 256) t += buf[2 + k];
+  for (int k = threadIdx.x; k < parts; k += 256) t += buf[2 + k];
   sh[threadIdx.x] = t;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
@@ -1095,14 +1125,24 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float *__restrict__ g,
   if (threadIdx.x == 0) buf[0] = sh[0];
 }
 
+extern "C" int nrpn_set_sumsq_form(int form, int grid) {
+  NRPN_REQUIRE(form >= 0 && form <= 2 && grid >= 64 && grid <= kSumsqBlocks, "set_sumsq_form: form in 0..2, grid in 64..2048");
+  g_sumsq_form = form;
+  g_sumsq_grid = grid;
+  return NRPN_OK;
+}
+
 extern "C" int nrpn_grad_sumsq_floats(void) { return 2 + kSumsqBlocks; }
 
 extern "C" int nrpn_grad_sumsq(const float *grad, int64_t count, float grad_scale, float *sumsq, nrpn_stream_t stream) {
   NRPN_REQUIRE(grad && sumsq && count > 0, "grad_sumsq: bad args");
   NRPN_REQUIRE((reinterpret_cast<uintptr_t>(grad) & 15) == 0, "grad_sumsq: the gradient arena must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  NRPN_HIP(hipMemsetAsync(sumsq, 0, 8, st));
-  hipLaunchKernelGGL(sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, st, grad, (long long)count, grad_scale, sumsq);
+  const dim3 grid(g_sumsq_grid);
+  if (g_sumsq_form == 2) hipLaunchKernelGGL(sumsq_kernel<2>, grid, dim3(256), 0, st, grad, (long long)count, grad_scale, sumsq);
+  else if (g_sumsq_form == 1) hipLaunchKernelGGL(sumsq_kernel<1>, grid, dim3(256), 0, st, grad, (long long)count, grad_scale, sumsq);
+  else hipLaunchKernelGGL(sumsq_kernel<0>, grid, dim3(256), 0, st, grad, (long long)count, grad_scale, sumsq);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, sumsq, g_sumsq_grid);
   NRPN_LAUNCH_CHECK("grad_sumsq");
   return NRPN_OK;
 }
