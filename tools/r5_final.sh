@@ -15,8 +15,10 @@ cp $(find /tmp/prof2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 (cd /tmp && NRPN_WGRAD_STREAM=0 timeout 90 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe --no-extras > $root/$O/prof_bench.log 2>&1)
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats_single_stream.csv
 python tools/prof_summary.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) $O/kernel_summary_single_stream.json 13
+if [ "${SKIP_X3:-0}" != "1" ]; then
 (cd /tmp && NRPN_BF16X3=1 timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/prof3 -o p --output-format csv -- python $root/bench.py --dtype f32 --steps 4 --warmup 2 --no-cpu-baseline --no-probe --no-extras > $root/$O/prof_x3.log 2>&1)
 cp $(find /tmp/prof3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bf16x3.csv
+fi
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 NRPN_PARITY_LOG=$PWD/$O/parity_measured.json timeout 1500 python -m pytest tests -q -m gpu --durations=10 -p no:cacheprovider > $O/t_all.log 2>&1
 tail -25 $O/t_all.log
