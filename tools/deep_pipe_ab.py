@@ -6,6 +6,8 @@ import torch
 import torch.nn.functional as F
 from nerf_rpn_amd import lib, ops
 
+if not hasattr(lib.load(), 'nrpn_set_conv_deep_pipe'):
+    sys.exit('this A/B needs the experimental switch nrpn_set_conv_deep_pipe: git apply tools/patches/r5_deep_pipe_ksliced.patch && make -C nerf_rpn_amd/csrc')
 dev = torch.device('cuda:0')
 dtype = torch.bfloat16
 out = []

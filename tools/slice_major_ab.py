@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 from nerf_rpn_amd import lib, ops
 
+if not hasattr(lib.load(), 'nrpn_set_conv_slice_major'):
+    sys.exit('this A/B needs the experimental switch nrpn_set_conv_slice_major: git apply tools/patches/r5_slice_major_xcd_order.patch && make -C nerf_rpn_amd/csrc')
 dev = torch.device('cuda:0')
 dtype = torch.bfloat16
 out = []
