@@ -175,3 +175,18 @@ def test_swin_b_of_the_reference_cli_is_rejected_like_the_reference_rejects_it()
     with pytest.raises(ValueError, match="not divisible"):
         SwinTransformer_FPN(patch_size=[4, 4, 4], embed_dim=128, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=[4, 4, 4],
                             stochastic_depth_prob=0.1, expand_dim=True)
+
+
+def test_recorded_experiment_patches_still_apply():
+    """tools/patches/*.patch are measured-but-not-merged experiments that profiles/ and DESIGN cite (with the A/B script that needs each): they
+    must keep applying to the kernel sources they were cut from, or the record is not reproducible."""
+    import glob
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    patches = sorted(glob.glob(os.path.join(root, "tools", "patches", "*.patch")))
+    assert patches, "tools/patches is cited by profiles/README.md"
+    if shutil.which("git") is None:
+        pytest.skip("git not available")
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", p], cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, f"{os.path.basename(p)} no longer applies: {r.stderr[:400]}"
