@@ -727,9 +727,11 @@ def split3(src, ipattern=None, nplanes=0, ppattern=0):
     return inter, planes
 
 
-def _x3_ok(x, ksize, segs, rows_total):
-    # ragged voxel lists (the dense head over all pyramid levels) only without autograd: their weight gradient has no batch axis to stack on
-    return (SPLIT3[0] and x.dtype == torch.float32 and ksize == 3 and (segs is None or not torch.is_grad_enabled())
+def _x3_ok(x, ksize, segs, rows_total, differentiable):
+    # ragged voxel lists (the dense head over all pyramid levels) only when nothing is differentiated: their weight gradient has no batch
+    # axis to stack on and the split dgrad launch knows no segments.  `differentiable` is decided from the operands -- inside
+    # autograd.Function.forward grad mode is always off, so torch.is_grad_enabled() says nothing there
+    return (SPLIT3[0] and x.dtype == torch.float32 and ksize == 3 and (segs is None or not differentiable)
             and x.shape[-1] % 32 == 0 and rows_total % 32 == 0)
 
 
@@ -887,7 +889,7 @@ class ConvFn(torch.autograd.Function):
                     pack.bias, pack.bias_key = torch.cat(parts), bkey
                 bias = pack.bias
         out_dtype = torch.float32 if out_f32 else x.dtype
-        x3 = _x3_ok(x, ksize, segs, rows_total)
+        x3 = _x3_ok(x, ksize, segs, rows_total, any(ctx.needs_input_grad))
         xin = x
         if x3:      # bf16x3: split operands on the bf16 MFMA kernels, fp32 rows out; BatchNorm statistics then come from their own pass
             wp, wpd = _x3_weights(pack, weights, wp, wpd)
@@ -930,6 +932,8 @@ class ConvFn(torch.autograd.Function):
         dx = None
         x3 = getattr(ctx, "x3", False)
         dyp = None
+        if x3 and segs is not None:
+            raise lib.NrpnError("bf16x3 backward of a ragged conv: the split dgrad / wgrad launches take no segments")
         if x3:
             # bf16x3: one pass over dy writes the interleaved operand of the dgrad launch and the planes of the wgrad launch
             dys, dyp = split3(dy, _ACT_I if ctx.needs_input_grad[0] else None, 3, _DY_P)

@@ -695,6 +695,51 @@ def gen_fullsize2():
         save(name, **arrs)
 
 
+def gen_headouts():
+    """Raw RPN head outputs of the full-size ResNet-50 / Swin-S eval fixtures: the reference's objectness logits and box deltas
+    BEFORE decode / top-k / NMS, so that the HIP forward can be held to north_star's literal 1e-4 on them (and the decoded-box errors of those
+    cases tied to -- or separated from -- the delta errors).  Same scenes / weights as gen_fullsize2 (seed 310); own files, the fixtures
+    of gen_fullsize2 are not rewritten.  Stored: 65 536 evenly spaced anchors' logits + deltas, and the logits / deltas of the reference's
+    per-level top-k candidates (the rows decode reads)."""
+    print("full-size head outputs, ResNet-50 / Swin-S")
+    only = os.environ.get("GOLDEN_ONLY")
+    cases = [("eval_resnet_obb_200x200x130", (200, 200, 130), True, {"backbone": "resnet"}),
+             ("eval_swin_obb_160x120x64", (160, 120, 64), True, {"backbone": "swin"}),
+             ("eval_swin_obb_200x200x130", (200, 200, 130), True, {"backbone": "swin"})]
+    for name, shape, rot, kw in cases:
+        if only and only not in name:
+            continue
+        ref = build_ref(rot, 160, **kw).eval()
+        x = scene(shape, 310)
+        rec = {}
+        o_concat, o_topn = R_rpn.concat_box_prediction_layers, R_rpn.RegionProposalNetwork._get_top_n_idx
+
+        def concat(box_cls, box_reg, nd):
+            out = o_concat(box_cls, box_reg, nd)
+            rec["logits"], rec["deltas"] = out[0].detach().reshape(-1).clone(), out[1].detach().clone()
+            return out
+
+        def topn(self, objectness, num_anchors_per_level):
+            r = o_topn(self, objectness, num_anchors_per_level)
+            rec["topk_idx"], rec["per_level"] = r[0].clone(), list(num_anchors_per_level)
+            return r
+        R_rpn.concat_box_prediction_layers, R_rpn.RegionProposalNetwork._get_top_n_idx = concat, topn
+        try:
+            with torch.no_grad():
+                (feats, props, lvls), _, scores = ref([x.clone()])
+        finally:
+            R_rpn.concat_box_prediction_layers, R_rpn.RegionProposalNetwork._get_top_n_idx = o_concat, o_topn
+        # the run must be the one the proposal fixture was taken from
+        old = dict(np.load(os.path.join(HERE, name + ".npz")))
+        assert np.array_equal(old["proposals0"], props[0].numpy()) and np.array_equal(old["scores0"], scores[0].numpy()), name
+        logits, deltas, idx = rec["logits"], rec["deltas"].reshape(logits_n := rec["logits"].numel(), -1), rec["topk_idx"].reshape(-1)
+        sidx, sval = subsample(logits, 65536)
+        print(f"   {name}: {logits_n} anchors, |logit| max {logits.abs().max():.4f}, |delta| max {deltas.abs().max():.4f}, {idx.numel()} candidates")
+        save("headout_" + name, shape=list(shape), seed=310, per_level=rec["per_level"], sample_idx=sidx, sample_logits=sval,
+             sample_deltas=deltas[sidx], topk_idx=idx, topk_logits=logits[idx], topk_deltas=deltas[idx],
+             logit_absmax=logits.abs().max(), delta_absmax=deltas.abs().max())
+
+
 def gen_train():
     print("end-to-end train")
     cases = [("train_obb_160_cfg1", True, "smooth_l1", [(160, 160, 160)]),   # BASELINE configs[1] at its full size: the bench workload

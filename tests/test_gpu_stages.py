@@ -177,3 +177,36 @@ def test_whole_postprocess_on_the_reference_logits(golden, dev):
                 continue
         unmatched.append(i)
     assert not unmatched, (len(unmatched), unmatched[:10])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_hip_forward_logits_and_deltas_within_the_north_star_tolerance(mode, golden, dev):
+    """north_star's literal check at BASELINE configs[1] size (VERDICT r5 "weak" #1): the HIP forward -- device ingest, VGG19-EF + FPN, RPN
+    head -- on the fixture's scene and weights must return the reference's raw objectness LOGIT of every one of the 950 625 anchors within
+    1e-4 and the box-regression deltas of the reference's 9 125 top-k candidates within 1e-4 (absolute; reference rpn.py:485-500,
+    anchor.py:177-213).  Both parity-grade arithmetic modes; the measured worst errors go to tests/parity_log."""
+    import parity_log
+    from nerf_rpn_amd import ops
+    from test_gpu_e2e import build
+    from test_gpu_fullsize import _ingest
+    g = golden(NAME)
+    ge = dict(shape=g["shape"], seed=g["seed"], normalize_density=True)
+    m = build(True, 160, dev).eval()
+    try:
+        m.set_compute_dtype(mode)
+        with torch.no_grad():
+            m([_ingest(ge, dev, torch.float32)])
+    finally:
+        ops.SPLIT3[0] = False
+    aux = m.rpn.last_aux
+    logits = aux["logits"].float().reshape(-1).cpu()
+    ref = T(g["logits"])
+    assert logits.shape == ref.shape
+    err_l = (logits - ref).abs().max().item()
+    parity_log.record(f"{NAME}/{mode}", "logit", err_l, 1e-4)
+    idx = T(g["topk_idx"]).long()
+    deltas = aux["deltas"].float().reshape(-1, 8).cpu()[idx]
+    err_d = (deltas - T(g["topk_deltas"])).abs().max().item()
+    parity_log.record(f"{NAME}/{mode}", "delta", err_d, 1e-4)
+    assert err_l <= 1e-4, (mode, "logits", err_l, float(ref.abs().max()))
+    assert err_d <= 1e-4, (mode, "deltas", err_d, float(T(g["topk_deltas"]).abs().max()))
