@@ -89,7 +89,14 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
         if (q == seg && q < p.segs.n) { gY = p.segs.Y[q]; gZ = p.segs.Z[q]; }
       ox = oy = oz = 0;
     } else if (MODE == 0) {
-      locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
+      if (p.segs.n == 0) {       // classic layout: multiply-shift divisions (M < 2^31 is checked by the launcher)
+        const unsigned u = (unsigned)vv, sc = fastdiv(u, p.dvs), local = u - sc * (unsigned)(p.X * p.Y * p.Z), t1 = fastdiv(local, p.dvz);
+        oz = (int)(local - t1 * (unsigned)p.Z);
+        ox = (int)fastdiv(t1, p.dvy);
+        oy = (int)(t1 - (unsigned)ox * (unsigned)p.Y);
+      } else {
+        locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
+      }
     } else {
       oz = (int)(vv % p.OZ);
       const long long t1 = vv / p.OZ;
@@ -107,16 +114,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 1) conv_igemm_kernel(cons
     if (MODE == 0 && ROWS) {
       m = p.taps == 27 ? (row_word & 0x7FFFFFFu) : (a_ok[i] ? 1u : 0u);
     } else if (MODE == 0 && a_ok[i]) {
-      if (p.taps == 27) {
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-          const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
-          const bool in = (unsigned)(ox + dx) < (unsigned)gX && (unsigned)(oy + dy) < (unsigned)gY && (unsigned)(oz + dz) < (unsigned)gZ;
-          m |= in ? (1u << t) : 0u;
-        }
-      } else {
-        m = 1u;
-      }
+      m = p.taps == 27 ? tap_mask27(ox, oy, oz, gX, gY, gZ) : 1u;
     }
     a_mask[i] = m;
   }
@@ -674,6 +672,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
       for (int q = 0; q < kMaxSeg; ++q)
         if (q == seg && q < p.segs.n) { gY = p.segs.Y[q]; gZ = p.segs.Z[q]; }
       ox = oy = oz = 0;
+    } else if (p.segs.n == 0) {    // classic layout: multiply-shift divisions (conv_common.cuh FastDiv)
+      const unsigned u = (unsigned)vv, sc = fastdiv(u, p.dvs), local = u - sc * (unsigned)(p.X * p.Y * p.Z), t1 = fastdiv(local, p.dvz);
+      oz = (int)(local - t1 * (unsigned)p.Z);
+      ox = (int)fastdiv(t1, p.dvy);
+      oy = (int)(t1 - (unsigned)ox * (unsigned)p.Y);
     } else {
       locate_voxel(p.segs, vv, p.X, p.Y, p.Z, ox, oy, oz, gX, gY, gZ);
     }
@@ -683,16 +686,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_big_kernel(const ConvArgs p
     if (ROWS) {
       m = p.taps == 27 ? (row_word & 0x7FFFFFFu) : (ok ? 1u : 0u);
     } else if (ok) {
-      if (p.taps == 27) {
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-          const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
-          const bool in = (unsigned)(ox + dx) < (unsigned)gX && (unsigned)(oy + dy) < (unsigned)gY && (unsigned)(oz + dz) < (unsigned)gZ;
-          m |= in ? (1u << t) : 0u;
-        }
-      } else {
-        m = 1u;
-      }
+      m = p.taps == 27 ? tap_mask27(ox, oy, oz, gX, gY, gZ) : 1u;
     }
     a_mask[i] = m;
     a_voff[i] = (unsigned)(vv * p.Cin * 2) + ((ls ^ ((r >> 1) & (PPR - 1))) << 4);
@@ -1537,6 +1531,8 @@ static int conv3d_fwd_impl(const void *x, const void *wp, const float *bias, con
   a.M = M;
   a.X = gx; a.Y = gy; a.Z = gz; a.OX = gx; a.OY = gy; a.OZ = gz;   // classic layout: the kernel splits v into (batch, x, y, z) with these
   if (segs) a.segs = *segs;
+  a.dvz = make_fastdiv((unsigned)gz); a.dvy = make_fastdiv((unsigned)gy);
+  a.dvs = make_fastdiv((unsigned)min((long long)gx * gy * gz, (1ll << 31) - 1));      // a scene of >= 2^31 voxels does not pass the 2 GiB check below
   a.Cin = cin; a.Cout = cout; a.wrows = wrows; a.taps = ksize == 3 ? 27 : 1; a.stride = 1;
   a.flags = flags & 3;
   NRPN_REQUIRE(a.M * cin * es < (1ll << 31) && (long long)a.taps * wrows * cin * es < (1ll << 31),

@@ -341,6 +341,41 @@ def test_ragged_conv_equals_per_grid_convs(grids, cin, cout, dtype, dev):
     assert relerr(conv.bias.grad.cpu(), ref[3].cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+def test_ragged_conv_under_bf16x3_keeps_its_gradients(dev):
+    """with the bf16x3 mode raised, a DIFFERENTIATED ragged conv must not take the split-operand path (its dgrad / wgrad
+    launches know no segments: the ragged list would be read as one dense grid) -- the decision is made from the operands' requires_grad,
+    not from grad mode (always off inside autograd.Function.forward).  Gradients must equal the fp32 ragged path's; without autograd the
+    ragged forward may use the split operands and must agree with fp32 to the mode's tolerance."""
+    from nerf_rpn_amd import ops
+    from nerf_rpn_amd.model import hip_nn
+    torch.manual_seed(4)
+    grids, cin, cout = [(12, 10, 9), (6, 5, 5), (3, 3, 3)], 256, 256
+    conv = nn.Conv3d(cin, cout, 3, padding=1).to(dev)
+    feats = [torch.randn(1, *g, cin, device=dev) for g in grids]
+    gys = [torch.randn(1, *g, cout, device=dev) for g in grids]
+
+    def run():
+        conv.zero_grad()
+        xr = [f.clone().requires_grad_(True) for f in feats]
+        rag, segs = hip_nn.ragged_cat(xr)
+        yr = hip_nn.ragged_split(hip_nn.conv3d(conv, rag, relu=True, segs=segs), feats)
+        torch.autograd.backward(yr, gys)
+        return [y.detach().clone() for y in yr], [x.grad.clone() for x in xr], conv.weight.grad.clone(), conv.bias.grad.clone()
+    ref = run()
+    ops.SPLIT3[0] = True
+    try:
+        got = run()
+        with torch.no_grad():
+            rag, segs = hip_nn.ragged_cat(feats)
+            y_ng = hip_nn.ragged_split(hip_nn.conv3d(conv, rag, relu=True, segs=segs), feats)
+    finally:
+        ops.SPLIT3[0] = False
+    for a, b in zip(got[0] + got[1] + [got[2], got[3]], ref[0] + ref[1] + [ref[2], ref[3]]):
+        assert torch.equal(a, b)                  # the differentiated ragged conv ran the fp32 kernels: same bits
+    for a, b in zip(y_ng, ref[0]):
+        assert relerr(a.cpu(), b.cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("cin,cout,grid,rows_expected", [
     (64, 64, (1, 40, 40, 21), True),       # 128-row kernel, 64-column tiles (four row groups per tile), ragged last tile
     (128, 128, (2, 30, 30, 21), True),     # 128-row kernel, 128-column tiles, two scenes, ragged last tile

@@ -163,9 +163,10 @@ def test_fullsize_other_backbones_fp32_match_reference(name, golden, dev):
 
 
 HEADOUT_CASES = ["eval_resnet_obb_200x200x130", "eval_swin_obb_160x120x64", "eval_swin_obb_200x200x130"]
-# north_star: "box regressions and objectness within 1e-4 fp32".  The raw head outputs of these random-weight nets reach |logit| 2.6-5.5 and
-# |delta| 2.9-6.0 (the VGG19 fixture: 0.34 / 0.29, held to 1e-4 ABSOLUTE in test_gpu_stages.py), so the tolerance is 1e-4 of
-# max(1, |reference value|): relative where the value exceeds one, absolute below.
+# north_star: "box regressions and objectness within 1e-4 fp32" -- ABSOLUTE, although the raw head outputs of these random-weight nets reach
+# |logit| 2.6-5.5 and |delta| 2.9-6.0 (the VGG19 fixture: 0.34 / 0.29, test_gpu_stages.py).  Measured on an MI355X (round 6): 1.1e-5 / 1.2e-5
+# (ResNet-50 200x200x130), 2.0e-5 / 2.2e-5 (Swin-S 160x120x64), 2.2e-5 / 2.5e-5 (Swin-S 200x200x130): the 1.3e-3 .. 1.6e-2 voxel errors of
+# the DECODED boxes of those cases are the decode (exp of a size delta times an anchor of up to 80 voxels), not the regression.
 HEADOUT_TOL = 1e-4
 
 
@@ -174,7 +175,7 @@ def test_fullsize_other_backbones_head_outputs_within_the_north_star_tolerance(n
     """VERDICT r5 "weak" #1: the decoded-box errors of the full-size ResNet-50 / Swin-S fixtures (1.3e-3 .. 1.6e-2 voxel) were never tied to the
     quantities north_star bounds.  The fixture `headout_<case>` (make_golden.py::gen_headouts) holds the reference's raw objectness logits and
     box deltas BEFORE decode / top-k / NMS -- 65 536 evenly spaced anchors and the reference's own top-k candidates; the fp32 HIP forward must
-    return them within 1e-4 (of max(1, |value|)).  The measured worst errors are logged (tests/parity_log)."""
+    return them within 1e-4 (absolute).  The measured worst errors are logged (tests/parity_log)."""
     import parity_log
     g, h = golden(name), golden("headout_" + name)
     bbk, rot = str(g["backbone"]), bool(g["rotated"])
@@ -190,9 +191,9 @@ def test_fullsize_other_backbones_head_outputs_within_the_north_star_tolerance(n
     for tag in ("sample", "topk"):
         idx = T(h[tag + "_idx"]).long()
         for kind, got, ref in (("logit", logits[idx], T(h[tag + "_logits"])), ("delta", deltas[idx], T(h[tag + "_deltas"]))):
-            err = ((got - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+            err = (got - ref).abs().max().item()
             worst[kind] = max(worst.get(kind, 0.0), err)
-            print(f"[headout] {name} {tag} {kind}: max err {err:.3e} (abs {(got - ref).abs().max().item():.3e}, |ref| max {ref.abs().max().item():.3f})")
+            print(f"[headout] {name} {tag} {kind}: max abs err {err:.3e} (|ref| max {ref.abs().max().item():.3f})")
     for kind, err in worst.items():
         parity_log.record(f"{name}/fp32", kind, err, HEADOUT_TOL)
     assert worst["logit"] <= HEADOUT_TOL and worst["delta"] <= HEADOUT_TOL, (name, worst)
