@@ -1,0 +1,3 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+for d in 0 1 2 4 6; do NRPN_FUSED_DBG=$d timeout 120 python tools/r6_probe_fused.py 2>&1 | grep dbg; done
