@@ -442,7 +442,8 @@ int nrpn_layernorm_fwd(const void *x, void *y, const float *gamma, const float *
                        int c, float eps, int dtype, nrpn_stream_t stream);
 size_t nrpn_layernorm_workspace_bytes(int64_t rows, int c);
 int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *mean, const float *rstd,
-                       float *dgamma, float *dbeta, int64_t rows, int c, int dtype, void *workspace, nrpn_stream_t stream);
+                       float *dgamma, float *dbeta, int64_t rows, int c, int dtype, int accumulate_params, void *workspace,
+                       nrpn_stream_t stream);   /* accumulate_params != 0: dgamma / dbeta += (e.g. slots of a flat gradient arena) instead of = */
 /* exact (erf) GELU; backward != 0: out = dy * gelu'(x) */
 int nrpn_gelu(const void *x, const void *dy, void *out, int64_t count, int backward, int dtype, nrpn_stream_t stream);
 /* y = (a ? a : 0) + scale[n] * b : residual join with the StochasticDepth("row") factor (scale == NULL: 1) */
@@ -467,7 +468,7 @@ int nrpn_window_attn_fwd(const void *qkv, const float *qkv_bias, const float *bi
 size_t nrpn_window_attn_bwd_workspace_bytes(int n, int gx, int gy, int gz, int heads);
 int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index,
                          const void *dout, void *dqkv, float *dtable, float *dbias_pad, int n, int gx, int gy, int gz, int c,
-                         int heads, int shift, int dtype, void *workspace, nrpn_stream_t stream);
+                         int heads, int shift, int dtype, int accumulate_table, void *workspace, nrpn_stream_t stream);   /* != 0: dtable += */
 
 /* ------------------------------------------------------------------------------------------------
  * FCOS variant of the path.  [a23]  (model/fcos/fcos.py, inference.py, loss.py, utils.py)
@@ -483,7 +484,7 @@ int nrpn_groupnorm_fwd(const void *x, void *y, const float *gamma, const float *
                        int64_t rows, int c, int groups, float eps, int relu, int dtype, void *workspace, nrpn_stream_t stream);
 int nrpn_groupnorm_bwd(const void *x, const void *y, const void *dy, void *dx, const float *gamma, const float *mean,
                        const float *rstd, float *dgamma, float *dbeta, int n, int64_t rows, int c, int groups, int relu, int dtype,
-                       void *workspace, nrpn_stream_t stream);
+                       int accumulate_params, void *workspace, nrpn_stream_t stream);   /* accumulate_params != 0: dgamma / dbeta += */
 /* Head epilogue for one level (fcos.py:104-128).  cls_out / box_out: f32 [rows, wrows] outputs of the fused 3x3x3 GEMMs
  * (cls_out col 0 = cls_logits, col 1 = centerness when !ctr_on_reg; box_out cols 0..reg_dim-1 = bbox_pred, col reg_dim =
  * centerness when ctr_on_reg).  reg = norm_reg ? [relu(scale*raw[:6]) * stride_mul, scale*raw[6:]] : exp(scale*raw).

@@ -49,6 +49,8 @@ int nrpn_set_rows_tail_split(int on);
 int nrpn_set_bn_fast(int on);
 /* BatchNorm channel reductions (statistics / backward sums), bf16: 1 = 8 channels per lane (16-byte loads), 0 (default) = 4 -- measured slower with 8 */
 int nrpn_set_bn_reduce_v8(int on);
+/* max-pool forward / backward: 1 (default) = multiply-shift index arithmetic + compile-time stride, 0 = the general kernels (A/B, same bits) */
+int nrpn_set_pool_fast(int on);
 /* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
 int nrpn_set_window_attn_mfma(int on);
 

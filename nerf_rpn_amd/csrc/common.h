@@ -29,6 +29,26 @@ int nrpn_fail(int code, const char *fmt, ...);
     if (e_ != hipSuccess) return nrpn_fail(NRPN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// Division by a launch-invariant divisor without the division (round 6): the loaders' prologue decomposed every tile row's voxel index with
+// three 64-bit divisions and built its 27-bit tap mask with 27 x 3 compares -- ~1 600 dynamic VALU instructions per wave before the first load
+// was issued (tools/isa_audit.py: 5 500 static instructions ahead of the first buffer_load), ~3 us of every launch of these kernels and a
+// third of the 10^3 / 5^3 / 1x1x1 launches.  For n < 2^31 and 1 <= d < 2^31: with l = ceil(log2 d), m = ceil(2^(31 + l) / d) < 2^32 and
+// n / d == (n * m) >> (31 + l) exactly (Granlund & Montgomery, N = 31).  d == 1 has no 32-bit m: the kernel keeps n.
+struct FastDiv {
+  unsigned m, sh, d;      // q = d == 1 ? n : mulhi(n, m) >> sh
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f{0u, 0u, d};
+  if (d <= 1) return f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                                     // ceil(log2 d), >= 1
+  f.m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+  f.sh = l - 1;                                                    // (n * m) >> (31 + l) = mulhi(n, m) >> (l - 1)
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv &f) { return f.d == 1 ? n : (__umulhi(n, f.m) >> f.sh); }
+
+
 // Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute belongs to the device the call is made on, so the cache
 // is keyed on both (a process-wide "done" flag would leave a second device of the same process at the 64 KB default).  Thread-safe.
 int nrpn_ensure_dynamic_lds(const void *kernel, int bytes);

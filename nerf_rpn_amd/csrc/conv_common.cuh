@@ -92,25 +92,8 @@ __device__ __forceinline__ int locate_voxel(const Segs &s, long long v, int cX, 
   return seg;
 }
 
-// Division by a launch-invariant divisor without the division (round 6): the loaders' prologue decomposed every tile row's voxel index with
-// three 64-bit divisions and built its 27-bit tap mask with 27 x 3 compares -- ~1 600 dynamic VALU instructions per wave before the first load
-// was issued (tools/isa_audit.py: 5 500 static instructions ahead of the first buffer_load), ~3 us of every launch of these kernels and a
-// third of the 10^3 / 5^3 / 1x1x1 launches.  For n < 2^31 and 1 <= d < 2^31: with l = ceil(log2 d), m = ceil(2^(31 + l) / d) < 2^32 and
-// n / d == (n * m) >> (31 + l) exactly (Granlund & Montgomery, N = 31).  d == 1 has no 32-bit m: the kernel keeps n.
-struct FastDiv {
-  unsigned m, sh, d;      // q = d == 1 ? n : mulhi(n, m) >> sh
-};
-static inline FastDiv make_fastdiv(unsigned d) {
-  FastDiv f{0u, 0u, d};
-  if (d <= 1) return f;
-  unsigned l = 0;
-  while ((1ull << l) < d) ++l;                                     // ceil(log2 d), >= 1
-  f.m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
-  f.sh = l - 1;                                                    // (n * m) >> (31 + l) = mulhi(n, m) >> (l - 1)
-  return f;
-}
-__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv &f) { return f.d == 1 ? n : (__umulhi(n, f.m) >> f.sh); }
-
+// FastDiv / make_fastdiv / fastdiv: common.h (division by a launch-invariant divisor as a multiply-shift; the loaders' prologue uses it for the
+// voxel decomposition -- ~1 600 dynamic VALU instructions per wave before the first load with three 64-bit divisions per tile row).
 // 27-bit in-bounds mask of the 3x3x3 taps of voxel (x, y, z) in an X x Y x Z grid, bit t = (dx+1) * 9 + (dy+1) * 3 + (dz+1): three 3-bit axis
 // masks combined with shifts instead of 27 x 3 compares
 __device__ __forceinline__ unsigned tap_mask27(int x, int y, int z, int X, int Y, int Z) {

@@ -563,6 +563,96 @@ __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, i
   }
 }
 
+// Round 6: the 32-bit forms above still spent most of their time dividing -- four runtime udivs per lane for the voxel decomposition and, in
+// the backward, a runtime `% s` and `/ s` per axis and per candidate window: ~200 VALU instructions per lane against 8 - 27 loads, VALU-bound at
+// 0.18 - 0.31 of the HBM rate.  The fast forms take the divisors as multiply-shift pairs (common.h FastDiv) and the stride as
+// a template argument (1 or 2: shifts and masks); results are those of the general kernels, bit for bit (same scan order, same first-maximum rule).
+struct PoolDiv { FastDiv ct, z, y, x; };
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) maxpool_fwd_fast_kernel(const T *__restrict__ x, T *__restrict__ y, int8_t *__restrict__ arg, unsigned total,
+                                                               int gx, int gy, int gz, int ox, int oy, int oz, int c, int k, int s, int p, PoolDiv dv) {
+  for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+    const unsigned vox = fastdiv(g, dv.ct);
+    const int cg = (int)(g - vox * dv.ct.d) * V;
+    const unsigned t1 = fastdiv(vox, dv.z), t2 = fastdiv(t1, dv.y), b = fastdiv(t2, dv.x);
+    const int z = (int)(vox - t1 * dv.z.d), yy = (int)(t1 - t2 * dv.y.d), xx = (int)(t2 - b * dv.x.d);
+    float best[V];
+    int bi[V];
+    bool first = true;
+    const int a0 = max(0, p - xx * s), a1 = min(k, gx + p - xx * s);
+    const int b0 = max(0, p - yy * s), b1 = min(k, gy + p - yy * s);
+    const int d0 = max(0, p - z * s), d1 = min(k, gz + p - z * s);
+    const T *xb = x + (long long)b * gx * gy * gz * c + cg;
+    for (int a = a0; a < a1; ++a) {
+      const int ix = xx * s - p + a;
+      for (int bq = b0; bq < b1; ++bq) {
+        const int iy = yy * s - p + bq;
+        const T *row = xb + (long long)((ix * gy + iy) * gz + (z * s - p)) * c;
+        const int code0 = (a * k + bq) * k;
+        for (int d = d0; d < d1; ++d) {
+          float xv[V];
+          vecv<T, V>::ld(row + (long long)d * c, xv);
+#pragma unroll
+          for (int q = 0; q < V; ++q)
+            if (first || xv[q] > best[q]) { best[q] = xv[q]; bi[q] = code0 + d; }
+          first = false;
+        }
+      }
+    }
+    if (first) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+    }
+    const long long o = (long long)vox * c + cg;
+    vecv<T, V>::st(y + o, best);
+    if (arg) {
+      typename argpack<V>::type pk = 0;
+#pragma unroll
+      for (int q = 0; q < V; ++q) pk |= (typename argpack<V>::type)(unsigned char)bi[q] << (8 * q);
+      *reinterpret_cast<typename argpack<V>::type *>(arg + o) = pk;
+    }
+  }
+}
+
+// S = stride (1 or 2).  Per axis the candidate windows of coordinate x are those with offset a = (x + p) mod S, + S, ... < k
+template <typename T, int V, int S>
+__global__ void __launch_bounds__(256) maxpool_bwd_fast_kernel(const T *__restrict__ dy, const int8_t *__restrict__ arg, T *__restrict__ dx, unsigned total,
+                                                               int ox, int oy, int oz, int c, int k, int p, PoolDiv dv) {
+  for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+    const unsigned vox = fastdiv(g, dv.ct);
+    const int cg = (int)(g - vox * dv.ct.d) * V;
+    const unsigned t1 = fastdiv(vox, dv.z), t2 = fastdiv(t1, dv.y), b = fastdiv(t2, dv.x);
+    const int z = (int)(vox - t1 * dv.z.d), yy = (int)(t1 - t2 * dv.y.d), xx = (int)(t2 - b * dv.x.d);
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    const long long ob = (long long)b * ox * oy * oz;
+    for (int a = (xx + p) & (S - 1); a < k; a += S) {
+      const int tx = xx + p - a, wx = S == 2 ? tx >> 1 : tx;
+      if (tx < 0 || wx >= ox) continue;
+      for (int bq = (yy + p) & (S - 1); bq < k; bq += S) {
+        const int ty = yy + p - bq, wy = S == 2 ? ty >> 1 : ty;
+        if (ty < 0 || wy >= oy) continue;
+        const long long orow = (ob + (long long)(wx * oy + wy) * oz) * c + cg;
+        const int code0 = (a * k + bq) * k;
+        for (int d = (z + p) & (S - 1); d < k; d += S) {
+          const int tz = z + p - d, wz = S == 2 ? tz >> 1 : tz;
+          if (tz < 0 || wz >= oz) continue;
+          const long long o = orow + (long long)wz * c;
+          float gv[V];
+          vecv<T, V>::ld(dy + o, gv);
+          const typename argpack<V>::type pk = *reinterpret_cast<const typename argpack<V>::type *>(arg + o);
+          const int code = code0 + d;
+#pragma unroll
+          for (int q = 0; q < V; ++q) acc[q] += ((int)((pk >> (8 * q)) & 0xff) == code) ? gv[q] : 0.f;
+        }
+      }
+    }
+    vecv<T, V>::st(dx + (long long)vox * c + cg, acc);
+  }
+}
+
 // gather form: every input voxel sums the dy of the windows whose argmax points at it (no atomics, deterministic).  Per axis the
 // windows containing coordinate x are those with offset a = (x + p) mod s, + s, + 2s, ... < k: at most ceil(k / s) candidates,
 // enumerated directly (8 for the 3/2/1 pool instead of testing all 27 offsets).
@@ -605,6 +695,9 @@ __global__ void maxpool_bwd_kernel(const T *__restrict__ dy, const int8_t *__res
   }
 }
 
+static std::atomic<int> g_pool_fast{1};      // tools-only A/B switch (nerfrpn_tools.h): 0 = the general index arithmetic
+extern "C" int nrpn_set_pool_fast(int on) { g_pool_fast = on ? 1 : 0; return NRPN_OK; }
+
 extern "C" int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n, int gx, int gy, int gz, int c, int k, int s, int p,
                                   int ceil_mode, int dtype, nrpn_stream_t stream) {
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_fwd: bad sizes");
@@ -613,7 +706,15 @@ extern "C" int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n,
   const bool small = (long long)n * gx * gy * gz * c < (1ll << 31);      // 32-bit index arithmetic (every real shape); 64-bit beyond
 #define NRPN_POOL_FWD(T_, V_, I_) hipLaunchKernelGGL((maxpool_fwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
                                                      (const T_ *)x, (T_ *)y, argmax, n, gx, gy, gz, ox, oy, oz, c, k, s, p)
-  if (dtype == NRPN_BF16 && c % 8 == 0) {
+  if (small && g_pool_fast.load(std::memory_order_relaxed)) {
+    const int v = (dtype == NRPN_BF16 && c % 8 == 0) ? 8 : 4;
+    const long long total = (long long)n * ox * oy * oz * (c / v);
+    const PoolDiv dv{make_fastdiv((unsigned)(c / v)), make_fastdiv((unsigned)oz), make_fastdiv((unsigned)oy), make_fastdiv((unsigned)ox)};
+#define NRPN_POOL_FWDF(T_, V_) hipLaunchKernelGGL((maxpool_fwd_fast_kernel<T_, V_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                  (const T_ *)x, (T_ *)y, argmax, (unsigned)total, gx, gy, gz, ox, oy, oz, c, k, s, p, dv)
+    if (v == 8) NRPN_POOL_FWDF(bf16s, 8); else { DISPATCH_T(dtype, NRPN_POOL_FWDF(T, 4)); }
+#undef NRPN_POOL_FWDF
+  } else if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * ox * oy * oz * (c / 8);
     if (small) NRPN_POOL_FWD(bf16s, 8, unsigned); else NRPN_POOL_FWD(bf16s, 8, long long);
   } else {
@@ -633,7 +734,17 @@ extern "C" int nrpn_maxpool3d_bwd(const void *dy, const int8_t *argmax, void *dx
   const bool small = (long long)n * gx * gy * gz * c < (1ll << 31);
 #define NRPN_POOL_BWD(T_, V_, I_) hipLaunchKernelGGL((maxpool_bwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
                                                      (const T_ *)dy, argmax, (T_ *)dx, n, gx, gy, gz, ox, oy, oz, c, k, s, p)
-  if (dtype == NRPN_BF16 && c % 8 == 0) {
+  if (small && (s == 1 || s == 2) && g_pool_fast.load(std::memory_order_relaxed)) {
+    const int v = (dtype == NRPN_BF16 && c % 8 == 0) ? 8 : 4;
+    const long long total = (long long)n * gx * gy * gz * (c / v);
+    const PoolDiv dv{make_fastdiv((unsigned)(c / v)), make_fastdiv((unsigned)gz), make_fastdiv((unsigned)gy), make_fastdiv((unsigned)gx)};
+#define NRPN_POOL_BWDF(T_, V_, S_) hipLaunchKernelGGL((maxpool_bwd_fast_kernel<T_, V_, S_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                      (const T_ *)dy, argmax, (T_ *)dx, (unsigned)total, ox, oy, oz, c, k, p, dv)
+    if (v == 8) { if (s == 2) NRPN_POOL_BWDF(bf16s, 8, 2); else NRPN_POOL_BWDF(bf16s, 8, 1); }
+    else if (s == 2) { DISPATCH_T(dtype, NRPN_POOL_BWDF(T, 4, 2)); }
+    else { DISPATCH_T(dtype, NRPN_POOL_BWDF(T, 4, 1)); }
+#undef NRPN_POOL_BWDF
+  } else if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * gx * gy * gz * (c / 8);
     if (small) NRPN_POOL_BWD(bf16s, 8, unsigned); else NRPN_POOL_BWD(bf16s, 8, long long);
   } else {

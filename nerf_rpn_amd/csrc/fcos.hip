@@ -166,7 +166,7 @@ __global__ void gn_finalize_bwd_kernel(const float *__restrict__ ws, const float
 }
 
 __global__ void gn_param_grad_kernel(const float *__restrict__ ws, const float *__restrict__ mean, const float *__restrict__ rstd,
-                                     float *__restrict__ dgamma, float *__restrict__ dbeta, int n, int c, int groups) {
+                                     float *__restrict__ dgamma, float *__restrict__ dbeta, int n, int c, int groups, int acc) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   const int g = ch / (c / groups);
@@ -176,8 +176,8 @@ __global__ void gn_param_grad_kernel(const float *__restrict__ ws, const float *
     dg += (s1 - mean[s * groups + g] * s0) * rstd[s * groups + g];
     db += s0;
   }
-  dgamma[ch] = dg;
-  dbeta[ch] = db;
+  dgamma[ch] = acc ? dgamma[ch] + dg : dg;       // acc: added to the gradient-arena slots instead of a torch add per parameter
+  dbeta[ch] = acc ? dbeta[ch] + db : db;
 }
 
 template <typename T>
@@ -232,7 +232,7 @@ extern "C" int nrpn_groupnorm_fwd(const void *x, void *y, const float *gamma, co
 
 extern "C" int nrpn_groupnorm_bwd(const void *x, const void *y, const void *dy, void *dx, const float *gamma, const float *mean,
                                   const float *rstd, float *dgamma, float *dbeta, int n, int64_t rows, int c, int groups, int relu, int dtype,
-                                  void *workspace, nrpn_stream_t stream) {
+                                  int accumulate_params, void *workspace, nrpn_stream_t stream) {
   NRPN_REQUIRE(x && dy && dx && gamma && mean && rstd && dgamma && dbeta && workspace && (!relu || y) && n > 0 && rows > 0 && c > 0 &&
                    groups > 0 && c % groups == 0, "groupnorm_bwd: bad args");
   hipStream_t st = as_stream(stream);
@@ -247,7 +247,8 @@ extern "C" int nrpn_groupnorm_bwd(const void *x, const void *y, const void *dy, 
   const int ng = n * groups;
   hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, ws, mean, rstd, gamma, coef, ng, c, groups,
                      (float)((double)rows * (c / groups)));
-  hipLaunchKernelGGL(gn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, st, ws, mean, rstd, dgamma, dbeta, n, c, groups);
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, st, ws, mean, rstd, dgamma, dbeta, n, c, groups,
+                     accumulate_params ? 1 : 0);
   const long long total = (long long)n * rows * c;
   DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(ew_blocks(total / 4)), dim3(256), 0, st, (const T *)x, (const T *)y,
                                        (const T *)dy, (T *)dx, mean, rstd, gamma, coef, (long long)rows, c, groups, total, relu));

@@ -35,7 +35,7 @@ int nrpn_ensure_dynamic_lds(const void *kernel, int bytes) {
   have = bytes;
   return NRPN_OK;
 }
-extern "C" int nrpn_abi_version(void) { return 2; }
+extern "C" int nrpn_abi_version(void) { return 3; }
 
 extern "C" int nrpn_check_device(int ordinal) {
   hipDeviceProp_t p;

@@ -142,8 +142,9 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T *__restrict_
 }
 
 // dgamma[c], dbeta[c] = sum over the block partials; block = (64 channels, 16 partial lanes)
+// acc != 0: the sums are ADDED to dgamma / dbeta (the trainer's gradient-arena slots: no torch add per parameter afterwards)
 __global__ void layernorm_param_kernel(const float *__restrict__ partial, int nblocks, int c, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta) {
+                                       float *__restrict__ dbeta, int acc) {
   __shared__ float rs[16][64], rq[16][64];
   const int ch = blockIdx.x * 64 + threadIdx.x;
   float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -164,8 +165,8 @@ __global__ void layernorm_param_kernel(const float *__restrict__ partial, int nb
   if (threadIdx.y == 0 && ch < c) {
     float s = 0.f, q = 0.f;
     for (int k = 0; k < 16; ++k) { s += rs[k][threadIdx.x]; q += rq[k][threadIdx.x]; }
-    dgamma[ch] = s;
-    dbeta[ch] = q;
+    dgamma[ch] = acc ? dgamma[ch] + s : s;
+    dbeta[ch] = acc ? dbeta[ch] + q : q;
   }
 }
 
@@ -184,7 +185,8 @@ extern "C" int nrpn_layernorm_fwd(const void *x, void *y, const float *gamma, co
 }
 
 extern "C" int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *mean, const float *rstd,
-                                  float *dgamma, float *dbeta, int64_t rows, int c, int dtype, void *workspace, nrpn_stream_t stream) {
+                                  float *dgamma, float *dbeta, int64_t rows, int c, int dtype, int accumulate_params, void *workspace,
+                                  nrpn_stream_t stream) {
   NRPN_REQUIRE(x && dy && dx && gamma && mean && rstd && dgamma && dbeta && workspace && rows > 0 && c > 0 && c <= 64 * 48,
                "layernorm_bwd: bad args (C <= 3072, workspace = nrpn_layernorm_workspace_bytes)");
   hipStream_t st = as_stream(stream);
@@ -194,7 +196,8 @@ extern "C" int nrpn_layernorm_bwd(const void *x, const void *dy, void *dx, const
     (const T *)dy, (T *)dx, gamma, mean, rstd, partial, (long long)rows, c))
   if (c <= 64 * 4) { NRPN_LNB(4); } else if (c <= 64 * 12) { NRPN_LNB(12); } else if (c <= 64 * 24) { NRPN_LNB(24); } else { NRPN_LNB(48); }
 #undef NRPN_LNB
-  hipLaunchKernelGGL(layernorm_param_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)partial, blocks, c, dgamma, dbeta);
+  hipLaunchKernelGGL(layernorm_param_kernel, dim3((c + 63) / 64), dim3(64, 16), 0, st, (const float *)partial, blocks, c, dgamma, dbeta,
+                     accumulate_params ? 1 : 0);
   NRPN_LAUNCH_CHECK("layernorm_bwd");
   return NRPN_OK;
 }
@@ -821,7 +824,7 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16s *_
 }
 
 // dtable[k][head] = sum over the windows' partial tables; block = (64 table entries, 16 window lanes), grid = (6, heads)
-__global__ void attn_table_reduce_kernel(const float *__restrict__ tabws, float *__restrict__ dtable, int windows, int heads) {
+__global__ void attn_table_reduce_kernel(const float *__restrict__ tabws, float *__restrict__ dtable, int windows, int heads, int acc) {
   __shared__ float red[16][64];
   const int head = blockIdx.y, k = blockIdx.x * 64 + threadIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -837,7 +840,7 @@ __global__ void attn_table_reduce_kernel(const float *__restrict__ tabws, float 
   if (threadIdx.y == 0 && k < 343) {
     float sum = 0.f;
     for (int q = 0; q < 16; ++q) sum += red[q][threadIdx.x];
-    dtable[k * heads + head] = sum;
+    dtable[k * heads + head] = acc ? dtable[k * heads + head] + sum : sum;      // acc: straight into the gradient-arena slot
   }
 }
 
@@ -895,7 +898,7 @@ extern "C" size_t nrpn_window_attn_bwd_workspace_bytes(int n, int gx, int gy, in
 
 extern "C" int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, const float *bias_table, const int32_t *rel_index, const void *dout,
                                     void *dqkv, float *dtable, float *dbias_pad, int n, int gx, int gy, int gz, int c, int heads, int shift,
-                                    int dtype, void *workspace, nrpn_stream_t stream) {
+                                    int dtype, int accumulate_table, void *workspace, nrpn_stream_t stream) {
   AttnGeom g;
   if (int rc = fill_geom(g, n, gx, gy, gz, c, heads, shift)) return rc;
   NRPN_REQUIRE(qkv && bias_table && rel_index && dout && dqkv && dtable && workspace, "window_attn_bwd: null pointer");
@@ -911,7 +914,8 @@ extern "C" int nrpn_window_attn_bwd(const void *qkv, const float *qkv_bias, cons
     DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_bwd_kernel<T>, grid, dim3(64), 0, st, (const T *)qkv, qkv_bias, bias_table, rel_index,
                                          (const T *)dout, (T *)dqkv, tabws, dbias_pad, g));
   }
-  hipLaunchKernelGGL(attn_table_reduce_kernel, dim3(6, heads), dim3(64, 16), 0, st, (const float *)tabws, dtable, windows, heads);
+  hipLaunchKernelGGL(attn_table_reduce_kernel, dim3(6, heads), dim3(64, 16), 0, st, (const float *)tabws, dtable, windows, heads,
+                     accumulate_table ? 1 : 0);
   if (dbias_pad) hipLaunchKernelGGL(attn_pad_reduce_kernel, dim3(heads), dim3(64, 16), 0, st, (const float *)tabws, dbias_pad, windows, heads, c);
   NRPN_LAUNCH_CHECK("window_attn_bwd");
   return NRPN_OK;

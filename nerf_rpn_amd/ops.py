@@ -1635,6 +1635,12 @@ def patchify(x, patch):
     return y
 
 
+def _slots_direct(gs, bs, c):
+    """Both parameter gradients of a normalisation layer go to fp32 arena slots of c contiguous elements: the kernels may add in place."""
+    return (gs is not None and bs is not None and gs.slot.dtype == torch.float32 and bs.slot.dtype == torch.float32
+            and gs.slot.numel() == c and bs.slot.numel() == c and gs.slot.is_contiguous() and bs.slot.is_contiguous())
+
+
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm(C) on the last dimension of a channels-last token tensor."""
 
@@ -1659,11 +1665,17 @@ class LayerNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         c = x.shape[-1]
         dx = torch.empty_like(x)
+        ws = torch.empty(query("layernorm_workspace_bytes", x.numel() // c, c), dtype=torch.uint8, device=x.device)
+        gs, bs = ctx.sinks
+        if _slots_direct(gs, bs, c):
+            # arena training: the parameter-gradient finish adds straight into the two slots (round 6: ~100 torch adds per Swin-S step gone)
+            call("layernorm_bwd", _p(x), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(gs.slot), _p(bs.slot), x.numel() // c, c, _dt(x), 1, _p(ws), _s())
+            gs.notify()
+            bs.notify()
+            return dx, None, None, None
         dg = torch.empty(c, dtype=torch.float32, device=x.device)
         db = torch.empty(c, dtype=torch.float32, device=x.device)
-        ws = torch.empty(query("layernorm_workspace_bytes", x.numel() // c, c), dtype=torch.uint8, device=x.device)
-        call("layernorm_bwd", _p(x), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(dg), _p(db), x.numel() // c, c, _dt(x), _p(ws), _s())
-        gs, bs = ctx.sinks
+        call("layernorm_bwd", _p(x), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(dg), _p(db), x.numel() // c, c, _dt(x), 0, _p(ws), _s())
         if gs is not None:
             gs.slot.add_(dg)
             gs.notify()
@@ -1766,12 +1778,20 @@ class WindowAttnFn(torch.autograd.Function):
         n, gx, gy, gz, c3 = qkv.shape
         c = c3 // 3
         dqkv = torch.empty_like(qkv)
-        dtable = torch.empty_like(t32)
         dpad = torch.empty(c3, dtype=torch.float32, device=qkv.device) if (padded and qb is not None) else None
         ws = torch.empty(query("window_attn_bwd_workspace_bytes", n, gx, gy, gz, heads), dtype=torch.uint8, device=qkv.device)
-        call("window_attn_bwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(dout), _p(dqkv), _p(dtable), _p(dpad), n, gx, gy, gz, c, heads,
-             shift, _dt(qkv), _p(ws), _s())
         bsink, tsink = ctx.sinks
+        if (tsink is not None and dpad is None and tsink.slot.dtype == torch.float32 and tsink.slot.is_contiguous()
+                and tsink.slot.numel() == t32.numel()):
+            # no padded tokens: the relative-position table is this block's only parameter gradient and nothing else writes its slot -- the
+            # table reduction adds into the arena itself (main stream, behind the optimiser's gradient clear), no torch add, no side-stream hop
+            call("window_attn_bwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(dout), _p(dqkv), _p(tsink.slot), 0, n, gx, gy, gz, c, heads,
+                 shift, _dt(qkv), 1, _p(ws), _s())
+            tsink.notify()
+            return dqkv, None, None, None, None, None
+        dtable = torch.empty_like(t32)
+        call("window_attn_bwd", _p(qkv), _p(qb), _p(t32), _p(rel_index), _p(dout), _p(dqkv), _p(dtable), _p(dpad), n, gx, gy, gz, c, heads,
+             shift, _dt(qkv), 0, _p(ws), _s())
         if tsink is not None and (dpad is None or bsink is not None):
             # arena training: both parameter gradients are added to their slots here instead of travelling through autograd's AccumulateGrad
             # (which runs on the stream it was created on and would fall out of a captured backward, graphs.py).  The qkv bias also receives
@@ -1817,12 +1837,18 @@ class GroupNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         n, c = x.shape[0], x.shape[-1]
         dx = torch.empty_like(x)
+        ws = torch.empty(query("groupnorm_workspace_bytes", n, c, groups), dtype=torch.uint8, device=x.device)
+        gs, bs = ctx.sinks
+        if _slots_direct(gs, bs, c):
+            call("groupnorm_bwd", _p(x), _p(y), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(gs.slot), _p(bs.slot), n, x[0].numel() // c, c, groups,
+                 int(relu), _dt(x), 1, _p(ws), _s())
+            gs.notify()
+            bs.notify()
+            return dx, None, None, None, None, None
         dg = torch.empty(c, dtype=torch.float32, device=x.device)
         db = torch.empty(c, dtype=torch.float32, device=x.device)
-        ws = torch.empty(query("groupnorm_workspace_bytes", n, c, groups), dtype=torch.uint8, device=x.device)
         call("groupnorm_bwd", _p(x), _p(y), _p(dy), _p(dx), _p(g32), _p(mean), _p(rstd), _p(dg), _p(db), n, x[0].numel() // c, c, groups,
-             int(relu), _dt(x), _p(ws), _s())
-        gs, bs = ctx.sinks
+             int(relu), _dt(x), 0, _p(ws), _s())
         if gs is not None:
             gs.slot.add_(dg)
             gs.notify()

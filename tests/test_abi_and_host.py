@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if n not in exported]
     assert not missing, missing
     L = lib.load()   # also binds argtypes for every prototype; AttributeError on mismatch
-    assert L.nrpn_abi_version() == 2
+    assert L.nrpn_abi_version() == 3
     assert lib.query("anchor_table_words", 4, 13) == 2 + 32 + 6 * 4 * 13
     assert lib.query("pool_out_size", 40, 2, 2, 0, 1) == 20 and lib.query("pool_out_size", 5, 2, 2, 0, 1) == 3
     assert lib.query("pool_out_size", 80, 3, 2, 1, 0) == 40
