@@ -569,7 +569,11 @@ __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, i
 // a template argument (1 or 2: shifts and masks); results are those of the general kernels, bit for bit (same scan order, same first-maximum rule).
 struct PoolDiv { FastDiv ct, z, y, x; };
 
-template <typename T, int V>
+// K = window size as a template argument (2 or 3; 0 = runtime loops): every load of a lane is then issued before the first comparison -- the
+// runtime-bounded loops with their data-dependent compare chain serialised 27 load latencies per lane (31 us for the 3/2/1 pool of the stem).
+// Out-of-grid window positions read a clamped address and are masked out of the comparison; `first` keeps torch's rule (the first in-grid
+// element is taken whatever its value, later ones only if strictly greater): same bits as the general kernel.
+template <typename T, int V, int K>
 __global__ void __launch_bounds__(256) maxpool_fwd_fast_kernel(const T *__restrict__ x, T *__restrict__ y, int8_t *__restrict__ arg, unsigned total,
                                                                int gx, int gy, int gz, int ox, int oy, int oz, int c, int k, int s, int p, PoolDiv dv) {
   for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
@@ -580,29 +584,72 @@ __global__ void __launch_bounds__(256) maxpool_fwd_fast_kernel(const T *__restri
     float best[V];
     int bi[V];
     bool first = true;
-    const int a0 = max(0, p - xx * s), a1 = min(k, gx + p - xx * s);
-    const int b0 = max(0, p - yy * s), b1 = min(k, gy + p - yy * s);
-    const int d0 = max(0, p - z * s), d1 = min(k, gz + p - z * s);
     const T *xb = x + (long long)b * gx * gy * gz * c + cg;
-    for (int a = a0; a < a1; ++a) {
-      const int ix = xx * s - p + a;
-      for (int bq = b0; bq < b1; ++bq) {
-        const int iy = yy * s - p + bq;
-        const T *row = xb + (long long)((ix * gy + iy) * gz + (z * s - p)) * c;
-        const int code0 = (a * k + bq) * k;
-        for (int d = d0; d < d1; ++d) {
-          float xv[V];
-          vecv<T, V>::ld(row + (long long)d * c, xv);
+    if constexpr (K > 0) {
+      const int x0 = xx * s - p, y0 = yy * s - p, z0 = z * s - p;
+      float xv[K * K * K][V];
 #pragma unroll
-          for (int q = 0; q < V; ++q)
-            if (first || xv[q] > best[q]) { best[q] = xv[q]; bi[q] = code0 + d; }
-          first = false;
-        }
-      }
-    }
-    if (first) {
+      for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int bq = 0; bq < K; ++bq)
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            const int ix = min(max(x0 + a, 0), gx - 1), iy = min(max(y0 + bq, 0), gy - 1), iz = min(max(z0 + d, 0), gz - 1);
+            vecv<T, V>::ld(xb + (long long)((ix * gy + iy) * gz + iz) * c, xv[(a * K + bq) * K + d]);
+          }
 #pragma unroll
       for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+#pragma unroll
+      for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int bq = 0; bq < K; ++bq)
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            const bool in = (unsigned)(x0 + a) < (unsigned)gx && (unsigned)(y0 + bq) < (unsigned)gy && (unsigned)(z0 + d) < (unsigned)gz;
+            const int code = (a * K + bq) * K + d;
+#pragma unroll
+            for (int q = 0; q < V; ++q)
+              if (in && (first || xv[code][q] > best[q])) { best[q] = xv[code][q]; bi[q] = code; }
+            first = first && !in;
+          }
+    } else {
+      const int a0 = max(0, p - xx * s), a1 = min(k, gx + p - xx * s);
+      const int b0 = max(0, p - yy * s), b1 = min(k, gy + p - yy * s);
+      const int d0 = max(0, p - z * s), d1 = min(k, gz + p - z * s);
+      for (int a = a0; a < a1; ++a) {
+        const int ix = xx * s - p + a;
+        for (int bq = b0; bq < b1; ++bq) {
+          const int iy = yy * s - p + bq;
+          const T *row = xb + (long long)((ix * gy + iy) * gz + (z * s - p)) * c;
+          const int code0 = (a * k + bq) * k;
+          if (k == 3) {       // the z run of a 3-wide window as three loads in flight (clamped address, masked compare): 9 latencies per lane, not 27
+            float xv[3][V];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) vecv<T, V>::ld(row + (long long)min(max(d, d0), d1 - 1) * c, xv[d]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const bool in = d >= d0 && d < d1;
+#pragma unroll
+              for (int q = 0; q < V; ++q)
+                if (in && (first || xv[d][q] > best[q])) { best[q] = xv[d][q]; bi[q] = code0 + d; }
+              first = first && !in;
+            }
+            continue;
+          }
+          for (int d = d0; d < d1; ++d) {
+            float xv[V];
+            vecv<T, V>::ld(row + (long long)d * c, xv);
+#pragma unroll
+            for (int q = 0; q < V; ++q)
+              if (first || xv[q] > best[q]) { best[q] = xv[q]; bi[q] = code0 + d; }
+            first = false;
+          }
+        }
+      }
+      if (first) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+      }
     }
     const long long o = (long long)vox * c + cg;
     vecv<T, V>::st(y + o, best);
@@ -615,8 +662,9 @@ __global__ void __launch_bounds__(256) maxpool_fwd_fast_kernel(const T *__restri
   }
 }
 
-// S = stride (1 or 2).  Per axis the candidate windows of coordinate x are those with offset a = (x + p) mod S, + S, ... < k
-template <typename T, int V, int S>
+// S = stride (1 or 2), K = window size (2 or 3: at most NC = ceil(K / S) candidate windows per axis, all NC^3 loads issued up front;
+// 0 = runtime loops).  Per axis the candidate windows of coordinate x are those with offset a = (x + p) mod S, + S, ... < k.
+template <typename T, int V, int S, int K>
 __global__ void __launch_bounds__(256) maxpool_bwd_fast_kernel(const T *__restrict__ dy, const int8_t *__restrict__ arg, T *__restrict__ dx, unsigned total,
                                                                int ox, int oy, int oz, int c, int k, int p, PoolDiv dv) {
   for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
@@ -628,24 +676,60 @@ __global__ void __launch_bounds__(256) maxpool_bwd_fast_kernel(const T *__restri
 #pragma unroll
     for (int q = 0; q < V; ++q) acc[q] = 0.f;
     const long long ob = (long long)b * ox * oy * oz;
-    for (int a = (xx + p) & (S - 1); a < k; a += S) {
-      const int tx = xx + p - a, wx = S == 2 ? tx >> 1 : tx;
-      if (tx < 0 || wx >= ox) continue;
-      for (int bq = (yy + p) & (S - 1); bq < k; bq += S) {
-        const int ty = yy + p - bq, wy = S == 2 ? ty >> 1 : ty;
-        if (ty < 0 || wy >= oy) continue;
-        const long long orow = (ob + (long long)(wx * oy + wy) * oz) * c + cg;
-        const int code0 = (a * k + bq) * k;
-        for (int d = (z + p) & (S - 1); d < k; d += S) {
-          const int tz = z + p - d, wz = S == 2 ? tz >> 1 : tz;
-          if (tz < 0 || wz >= oz) continue;
-          const long long o = orow + (long long)wz * c;
-          float gv[V];
-          vecv<T, V>::ld(dy + o, gv);
-          const typename argpack<V>::type pk = *reinterpret_cast<const typename argpack<V>::type *>(arg + o);
-          const int code = code0 + d;
+    if constexpr (K > 0) {
+      constexpr int NC = (K + S - 1) / S;
+      const int ra = (xx + p) & (S - 1), rb = (yy + p) & (S - 1), rd = (z + p) & (S - 1);
+      float gv[NC * NC * NC][V];
+      typename argpack<V>::type pk[NC * NC * NC];
 #pragma unroll
-          for (int q = 0; q < V; ++q) acc[q] += ((int)((pk >> (8 * q)) & 0xff) == code) ? gv[q] : 0.f;
+      for (int ja = 0; ja < NC; ++ja)
+#pragma unroll
+        for (int jb = 0; jb < NC; ++jb)
+#pragma unroll
+          for (int jd = 0; jd < NC; ++jd) {
+            const int tx = xx + p - (ra + S * ja), ty = yy + p - (rb + S * jb), tz = z + p - (rd + S * jd);
+            const int wx = min(max(S == 2 ? tx >> 1 : tx, 0), ox - 1), wy = min(max(S == 2 ? ty >> 1 : ty, 0), oy - 1),
+                      wz = min(max(S == 2 ? tz >> 1 : tz, 0), oz - 1);
+            const long long o = (ob + (long long)(wx * oy + wy) * oz + wz) * c + cg;
+            vecv<T, V>::ld(dy + o, gv[(ja * NC + jb) * NC + jd]);
+            pk[(ja * NC + jb) * NC + jd] = *reinterpret_cast<const typename argpack<V>::type *>(arg + o);
+          }
+      // the general kernel adds the candidates in ascending (a, b, d) order: keep it (fp32 sums of up to 8 terms)
+#pragma unroll
+      for (int ja = 0; ja < NC; ++ja)
+#pragma unroll
+        for (int jb = 0; jb < NC; ++jb)
+#pragma unroll
+          for (int jd = 0; jd < NC; ++jd) {
+            const int a = ra + S * ja, bq = rb + S * jb, d = rd + S * jd;
+            const int tx = xx + p - a, ty = yy + p - bq, tz = z + p - d;
+            const bool ok = a < K && bq < K && d < K && tx >= 0 && ty >= 0 && tz >= 0 && (S == 2 ? tx >> 1 : tx) < ox &&
+                            (S == 2 ? ty >> 1 : ty) < oy && (S == 2 ? tz >> 1 : tz) < oz;
+            const int code = (a * K + bq) * K + d;
+            const int idx = (ja * NC + jb) * NC + jd;
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += (ok && (int)((pk[idx] >> (8 * q)) & 0xff) == code) ? gv[idx][q] : 0.f;
+          }
+    } else {
+      for (int a = (xx + p) & (S - 1); a < k; a += S) {
+        const int tx = xx + p - a, wx = S == 2 ? tx >> 1 : tx;
+        if (tx < 0 || wx >= ox) continue;
+        for (int bq = (yy + p) & (S - 1); bq < k; bq += S) {
+          const int ty = yy + p - bq, wy = S == 2 ? ty >> 1 : ty;
+          if (ty < 0 || wy >= oy) continue;
+          const long long orow = (ob + (long long)(wx * oy + wy) * oz) * c + cg;
+          const int code0 = (a * k + bq) * k;
+          for (int d = (z + p) & (S - 1); d < k; d += S) {
+            const int tz = z + p - d, wz = S == 2 ? tz >> 1 : tz;
+            if (tz < 0 || wz >= oz) continue;
+            const long long o = orow + (long long)wz * c;
+            float gvv[V];
+            vecv<T, V>::ld(dy + o, gvv);
+            const typename argpack<V>::type pkk = *reinterpret_cast<const typename argpack<V>::type *>(arg + o);
+            const int code = code0 + d;
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += ((int)((pkk >> (8 * q)) & 0xff) == code) ? gvv[q] : 0.f;
+          }
         }
       }
     }
@@ -710,9 +794,11 @@ extern "C" int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n,
     const int v = (dtype == NRPN_BF16 && c % 8 == 0) ? 8 : 4;
     const long long total = (long long)n * ox * oy * oz * (c / v);
     const PoolDiv dv{make_fastdiv((unsigned)(c / v)), make_fastdiv((unsigned)oz), make_fastdiv((unsigned)oy), make_fastdiv((unsigned)ox)};
-#define NRPN_POOL_FWDF(T_, V_) hipLaunchKernelGGL((maxpool_fwd_fast_kernel<T_, V_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
-                                                  (const T_ *)x, (T_ *)y, argmax, (unsigned)total, gx, gy, gz, ox, oy, oz, c, k, s, p, dv)
-    if (v == 8) NRPN_POOL_FWDF(bf16s, 8); else { DISPATCH_T(dtype, NRPN_POOL_FWDF(T, 4)); }
+#define NRPN_POOL_FWDF(T_, V_, K_) hipLaunchKernelGGL((maxpool_fwd_fast_kernel<T_, V_, K_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                      (const T_ *)x, (T_ *)y, argmax, (unsigned)total, gx, gy, gz, ox, oy, oz, c, k, s, p, dv)
+#define NRPN_POOL_FWDK(T_, V_) do { if (k == 2) NRPN_POOL_FWDF(T_, V_, 2); else NRPN_POOL_FWDF(T_, V_, 0); } while (0)   /* k = 3 fully unrolled: 216 registers of loads, measured slower (35.2 vs 31.5 us) */
+    if (v == 8) NRPN_POOL_FWDK(bf16s, 8); else { DISPATCH_T(dtype, NRPN_POOL_FWDK(T, 4)); }
+#undef NRPN_POOL_FWDK
 #undef NRPN_POOL_FWDF
   } else if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * ox * oy * oz * (c / 8);
@@ -738,11 +824,13 @@ extern "C" int nrpn_maxpool3d_bwd(const void *dy, const int8_t *argmax, void *dx
     const int v = (dtype == NRPN_BF16 && c % 8 == 0) ? 8 : 4;
     const long long total = (long long)n * gx * gy * gz * (c / v);
     const PoolDiv dv{make_fastdiv((unsigned)(c / v)), make_fastdiv((unsigned)gz), make_fastdiv((unsigned)gy), make_fastdiv((unsigned)gx)};
-#define NRPN_POOL_BWDF(T_, V_, S_) hipLaunchKernelGGL((maxpool_bwd_fast_kernel<T_, V_, S_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
-                                                      (const T_ *)dy, argmax, (T_ *)dx, (unsigned)total, ox, oy, oz, c, k, p, dv)
-    if (v == 8) { if (s == 2) NRPN_POOL_BWDF(bf16s, 8, 2); else NRPN_POOL_BWDF(bf16s, 8, 1); }
-    else if (s == 2) { DISPATCH_T(dtype, NRPN_POOL_BWDF(T, 4, 2)); }
-    else { DISPATCH_T(dtype, NRPN_POOL_BWDF(T, 4, 1)); }
+#define NRPN_POOL_BWDF(T_, V_, S_, K_) hipLaunchKernelGGL((maxpool_bwd_fast_kernel<T_, V_, S_, K_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                          (const T_ *)dy, argmax, (T_ *)dx, (unsigned)total, ox, oy, oz, c, k, p, dv)
+    // stride 2: the two pools of the VGG / ResNet paths (3/2/1 and 2/2/0) with every load up front; everything else on the runtime loops
+#define NRPN_POOL_BWDK(T_, V_) do { if (s == 2 && k == 2) NRPN_POOL_BWDF(T_, V_, 2, 2); /* (k = 3 unrolled loads all 8 candidates where 3.4 exist on average: 49.5 vs 35.4 us) */ \
+                                    else if (s == 2) NRPN_POOL_BWDF(T_, V_, 2, 0); else NRPN_POOL_BWDF(T_, V_, 1, 0); } while (0)
+    if (v == 8) NRPN_POOL_BWDK(bf16s, 8); else { DISPATCH_T(dtype, NRPN_POOL_BWDK(T, 4)); }
+#undef NRPN_POOL_BWDK
 #undef NRPN_POOL_BWDF
   } else if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * gx * gy * gz * (c / 8);

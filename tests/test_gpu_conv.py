@@ -172,6 +172,29 @@ def test_maxpool(cfg, dtype, ch, dev):
     assert torch.allclose(cf(xh.grad.float().cpu()), xr.grad, atol=1e-5 if dtype == torch.float32 else 3e-2, rtol=0 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("cfg", [(3, 2, 1, False, (16, 15, 13)), (2, 2, 0, True, (9, 8, 5)), (3, 1, 1, False, (7, 8, 9)), (3, 2, 1, False, (40, 40, 40))])
+@pytest.mark.parametrize("dtype,ch", [(torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 36)])
+def test_maxpool_fast_index_arithmetic_is_bit_identical(cfg, dtype, ch, dev):
+    """Round 6: the pools' multiply-shift index arithmetic (+ compile-time stride in the backward) against the general kernels: outputs,
+    argmax codes (through the backward) and input gradients must be the same bits (two scenes, ragged grids, ceil mode, stride 1 and 2)."""
+    from nerf_rpn_amd import lib, ops
+    k, s, p, ceil_mode, grid = cfg
+    torch.manual_seed(0)
+    x = F.relu(torch.randn(2, *grid, ch, device=dev)).to(dtype)
+    out = []
+    for fast in (1, 0):
+        lib.call("set_pool_fast", fast)
+        try:
+            xh = x.clone().requires_grad_(True)
+            yh = ops.MaxPoolFn.apply(xh, k, s, p, ceil_mode)
+            gy = torch.randn(yh.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3)).to(dtype)
+            yh.backward(gy)
+            out.append((yh.detach().clone(), xh.grad.clone()))
+        finally:
+            lib.call("set_pool_fast", 1)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("sizes", [((10, 10, 10), (5, 5, 5)), ((9, 7, 5), (5, 4, 3)), ((33, 20, 7), (17, 10, 4))])
 def test_upsample_add(sizes, dev):
     from nerf_rpn_amd import ops
