@@ -62,7 +62,9 @@ template <> struct vecv<bf16s, 8> {
 // per-channel reductions: slabs of 256 rows per block; thread = (4-channel group, row lane)
 // =====================================================================================================================
 // rows per block of the channel reductions: ~1024 blocks for any tensor (fixed 256-row slabs left 3/4 of the chip idle on the
-// 64000-row maps), at least 64 rows so the finalize kernels read a bounded number of partials
+// 64000-row maps), at least 64 rows so the finalize kernels read a bounded number of partials.  Round 6 sweep of the block target on one
+// MI355X (bn_stats / bn_backward on 256 ch x 64000 rows, us incl. the finish): 512 blocks 11.6 / 41.2, 1024 12.7 / 38.4, 2048 17.6 / 47.8,
+// 4096 25.7 / 60.2 -- more partial rows cost the latency-bound finish more than the reduction gains
 static inline int slab_rows(long long rows) { const long long s = (rows + 1023) / 1024; return (int)(s < 64 ? 64 : s); }
 
 // MODE 0: (sum x, sum x^2)           MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * (y > 0 if relu)
@@ -568,6 +570,8 @@ __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, i
 // 0.18 - 0.31 of the HBM rate.  The fast forms take the divisors as multiply-shift pairs (common.h FastDiv) and the stride as
 // a template argument (1 or 2: shifts and masks); results are those of the general kernels, bit for bit (same scan order, same first-maximum rule).
 struct PoolDiv { FastDiv ct, z, y, x; };
+static std::atomic<int> g_pool_fast{1};      // tools-only A/B switch (nerfrpn_tools.h): 0 = the general index arithmetic (pools, upsample-add)
+extern "C" int nrpn_set_pool_fast(int on) { g_pool_fast = on ? 1 : 0; return NRPN_OK; }
 
 // K = window size as a template argument (2 or 3; 0 = runtime loops): every load of a lane is then issued before the first comparison -- the
 // runtime-bounded loops with their data-dependent compare chain serialised 27 load latencies per lane (31 us for the 3/2/1 pool of the stem).
@@ -779,9 +783,6 @@ __global__ void maxpool_bwd_kernel(const T *__restrict__ dy, const int8_t *__res
   }
 }
 
-static std::atomic<int> g_pool_fast{1};      // tools-only A/B switch (nerfrpn_tools.h): 0 = the general index arithmetic
-extern "C" int nrpn_set_pool_fast(int on) { g_pool_fast = on ? 1 : 0; return NRPN_OK; }
-
 extern "C" int nrpn_maxpool3d_fwd(const void *x, void *y, int8_t *argmax, int n, int gx, int gy, int gz, int c, int k, int s, int p,
                                   int ceil_mode, int dtype, nrpn_stream_t stream) {
   NRPN_REQUIRE(n > 0 && gx > 0 && gy > 0 && gz > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 5 && s >= 1 && p >= 0, "maxpool_fwd: bad sizes");
@@ -921,6 +922,63 @@ __global__ void upsample_add_bwd_kernel(const T *__restrict__ dfine, T *__restri
   }
 }
 
+// Round 6 fast forms (tensors below 2^31 elements): multiply-shift voxel decomposition (PoolDiv) and the per-axis scale in / out computed once
+// on the host (the same correctly rounded fp32 quotient the general kernel forms per lane); the backward of an exact 2x pyramid step (every
+// level pair of the three backbones on 160^3-class grids) sums the 8 children 2x + {0,1} directly -- the general kernel finds them by testing
+// ~35 candidate indices with nearest_src and six 64-bit divisions per lane.  Same bits: same children, same ascending (x, y, z) order.
+__device__ __forceinline__ int nearest_src_s(int dst, int in, float scale) {
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) upsample_add_fwd_fast_kernel(T *__restrict__ fine, const T *__restrict__ coarse, unsigned total, int cx, int cy,
+                                                                    int cz, int c, float sx, float sy, float sz, PoolDiv dv) {
+  for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+    const unsigned vox = fastdiv(g, dv.ct);
+    const int cg = (int)(g - vox * dv.ct.d) * V;
+    const unsigned t1 = fastdiv(vox, dv.z), t2 = fastdiv(t1, dv.y), b = fastdiv(t2, dv.x);
+    const int z = (int)(vox - t1 * dv.z.d), y = (int)(t1 - t2 * dv.y.d), x = (int)(t2 - b * dv.x.d);
+    const long long src = ((((long long)b * cx + nearest_src_s(x, cx, sx)) * cy + nearest_src_s(y, cy, sy)) * cz + nearest_src_s(z, cz, sz)) * (long long)c + cg;
+    const long long dst = (long long)vox * c + cg;
+    float a[V], bq[V];
+    vecv<T, V>::ld(fine + dst, a);
+    vecv<T, V>::ld(coarse + src, bq);
+#pragma unroll
+    for (int k = 0; k < V; ++k) a[k] += bq[k];
+    vecv<T, V>::st(fine + dst, a);
+  }
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) upsample_add_bwd_x2_kernel(const T *__restrict__ dfine, T *__restrict__ dcoarse, unsigned total, int fx, int fy,
+                                                                  int fz, int c, int accumulate, PoolDiv dv) {
+  for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+    const unsigned vox = fastdiv(g, dv.ct);
+    const int cg = (int)(g - vox * dv.ct.d) * V;
+    const unsigned t1 = fastdiv(vox, dv.z), t2 = fastdiv(t1, dv.y), b = fastdiv(t2, dv.x);
+    const int z = (int)(vox - t1 * dv.z.d), y = (int)(t1 - t2 * dv.y.d), x = (int)(t2 - b * dv.x.d);
+    float gv[8][V], acc[V];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      vecv<T, V>::ld(dfine + ((((long long)b * fx + 2 * x + (k >> 2)) * fy + 2 * y + ((k >> 1) & 1)) * fz + 2 * z + (k & 1)) * (long long)c + cg, gv[k]);
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc[q] += gv[k][q];
+    const long long dst = (long long)vox * c + cg;
+    if (accumulate) {
+      float old[V];
+      vecv<T, V>::ld(dcoarse + dst, old);
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc[q] += old[q];
+    }
+    vecv<T, V>::st(dcoarse + dst, acc);
+  }
+}
+
 extern "C" int nrpn_upsample_add_fwd(void *fine, const void *coarse, int n, int fx, int fy, int fz, int cx, int cy, int cz, int c, int dtype,
                                      nrpn_stream_t stream) {
   NRPN_REQUIRE(n > 0 && fx > 0 && fy > 0 && fz > 0 && cx > 0 && cy > 0 && cz > 0 && c % 4 == 0, "upsample_add_fwd: bad sizes");
@@ -928,7 +986,16 @@ extern "C" int nrpn_upsample_add_fwd(void *fine, const void *coarse, int n, int 
   const bool small = (long long)n * fx * fy * fz * c < (1ll << 31);      // 32-bit index arithmetic; bf16 with C % 8 == 0: 16-byte accesses
 #define NRPN_UP_FWD(T_, V_, I_) hipLaunchKernelGGL((upsample_add_fwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
                                                    (T_ *)fine, (const T_ *)coarse, n, fx, fy, fz, cx, cy, cz, c)
-  if (dtype == NRPN_BF16 && c % 8 == 0) {
+  if (small && g_pool_fast.load(std::memory_order_relaxed)) {
+    const int v = (dtype == NRPN_BF16 && c % 8 == 0) ? 8 : 4;
+    const long long total = (long long)n * fx * fy * fz * (c / v);
+    const PoolDiv dv{make_fastdiv((unsigned)(c / v)), make_fastdiv((unsigned)fz), make_fastdiv((unsigned)fy), make_fastdiv((unsigned)fx)};
+    const float sx = (float)cx / (float)fx, sy = (float)cy / (float)fy, sz = (float)cz / (float)fz;
+#define NRPN_UP_FWDF(T_, V_) hipLaunchKernelGGL((upsample_add_fwd_fast_kernel<T_, V_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                (T_ *)fine, (const T_ *)coarse, (unsigned)total, cx, cy, cz, c, sx, sy, sz, dv)
+    if (v == 8) NRPN_UP_FWDF(bf16s, 8); else { DISPATCH_T(dtype, NRPN_UP_FWDF(T, 4)); }
+#undef NRPN_UP_FWDF
+  } else if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * fx * fy * fz * (c / 8);
     if (small) NRPN_UP_FWD(bf16s, 8, unsigned); else NRPN_UP_FWD(bf16s, 8, long long);
   } else {
@@ -947,7 +1014,15 @@ extern "C" int nrpn_upsample_add_bwd(const void *dfine, void *dcoarse, int n, in
   const bool small = (long long)n * fx * fy * fz * c < (1ll << 31);
 #define NRPN_UP_BWD(T_, V_, I_) hipLaunchKernelGGL((upsample_add_bwd_kernel<T_, V_, I_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
                                                    (const T_ *)dfine, (T_ *)dcoarse, n, fx, fy, fz, cx, cy, cz, c, accumulate)
-  if (dtype == NRPN_BF16 && c % 8 == 0) {
+  if (small && fx == 2 * cx && fy == 2 * cy && fz == 2 * cz && g_pool_fast.load(std::memory_order_relaxed)) {
+    const int v = (dtype == NRPN_BF16 && c % 8 == 0) ? 8 : 4;
+    const long long total = (long long)n * cx * cy * cz * (c / v);
+    const PoolDiv dv{make_fastdiv((unsigned)(c / v)), make_fastdiv((unsigned)cz), make_fastdiv((unsigned)cy), make_fastdiv((unsigned)cx)};
+#define NRPN_UP_BWDF(T_, V_) hipLaunchKernelGGL((upsample_add_bwd_x2_kernel<T_, V_>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), \
+                                                (const T_ *)dfine, (T_ *)dcoarse, (unsigned)total, fx, fy, fz, c, accumulate, dv)
+    if (v == 8) NRPN_UP_BWDF(bf16s, 8); else { DISPATCH_T(dtype, NRPN_UP_BWDF(T, 4)); }
+#undef NRPN_UP_BWDF
+  } else if (dtype == NRPN_BF16 && c % 8 == 0) {
     const long long total = (long long)n * cx * cy * cz * (c / 8);
     if (small) NRPN_UP_BWD(bf16s, 8, unsigned); else NRPN_UP_BWD(bf16s, 8, long long);
   } else {

@@ -195,6 +195,29 @@ def test_maxpool_fast_index_arithmetic_is_bit_identical(cfg, dtype, ch, dev):
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("sizes", [((10, 10, 10), (5, 5, 5)), ((40, 40, 40), (20, 20, 20)), ((9, 7, 5), (5, 4, 3))])
+@pytest.mark.parametrize("dtype,ch", [(torch.float32, 32), (torch.bfloat16, 256), (torch.bfloat16, 36)])
+def test_upsample_add_fast_forms_are_bit_identical(sizes, dtype, ch, dev):
+    """Round 6: the top-down add with multiply-shift index arithmetic, and the backward of an exact 2x pyramid step as a direct sum of the 8
+    children, against the general kernels (which also serve the non-2x case here): same bits, two scenes."""
+    from nerf_rpn_amd import lib, ops
+    fine_s, coarse_s = sizes
+    torch.manual_seed(0)
+    fine, coarse = torch.randn(2, *fine_s, ch, device=dev).to(dtype), torch.randn(2, *coarse_s, ch, device=dev).to(dtype)
+    gy = torch.randn(2, *fine_s, ch, device=dev).to(dtype)
+    out = []
+    for fast in (1, 0):
+        lib.call("set_pool_fast", fast)
+        try:
+            f, c = fine.clone().requires_grad_(True), coarse.clone().requires_grad_(True)
+            y = ops.UpsampleAddFn.apply(f * 1.0, c)
+            y.backward(gy)
+            out.append((y.detach().clone(), c.grad.clone()))
+        finally:
+            lib.call("set_pool_fast", 1)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("sizes", [((10, 10, 10), (5, 5, 5)), ((9, 7, 5), (5, 4, 3)), ((33, 20, 7), (17, 10, 4))])
 def test_upsample_add(sizes, dev):
     from nerf_rpn_amd import ops
