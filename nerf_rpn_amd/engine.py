@@ -22,6 +22,7 @@ Design (MI355X-first, not the reference's DDP-wrapper pattern, run_rpn.py:235-23
 Scenes shard across ranks (DistributedSampler semantics); BatchNorm uses per-rank batch statistics like the reference.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -171,9 +172,9 @@ class FlatTrainer:
             # (AUTO_MODES: the fp32 exchanges; bench.py times the full table), a mode whose collectives the backend lacks drops out instead
             # of failing construction, and NRPN_GRAD_EXCHANGE / NRPN_GRAD_BUCKET_MIB pin the result: the winner of a wall-clock race can differ
             # between runs, and mode / bucket size fix the fp32 summation order (run-to-run bit-reproducibility needs them pinned).
-            pinned_mib = os.environ.get("NRPN_GRAD_BUCKET_MIB")
+            pinned_mib = self._pinned_bucket_mib()
             if self.exchanging:
-                sizes = (int(pinned_mib),) if pinned_mib else (16, 32, 64)
+                sizes = (pinned_mib,) if pinned_mib else (16, 32, 64)
                 self.exchange_table = self.measure_exchange(modes=AUTO_MODES, bucket_mib=sizes)
                 if self.exchange_table:
                     best = min(self.exchange_table, key=lambda k: self.exchange_table[k])
@@ -188,8 +189,8 @@ class FlatTrainer:
                           f"NRPN_GRAD_EXCHANGE={self.exchange} NRPN_GRAD_BUCKET_MIB={best[1]}", file=sys.stderr, flush=True)      # (stderr: bench.py's stdout is ONE JSON line)
             else:
                 self.exchange = "allreduce"
-        elif self.exchanging and os.environ.get("NRPN_GRAD_BUCKET_MIB"):
-            self._build_buckets(int(os.environ["NRPN_GRAD_BUCKET_MIB"]) << 20)
+        elif self.exchanging and self._pinned_bucket_mib():
+            self._build_buckets(self._pinned_bucket_mib() << 20)
 
     def _build_buckets(self, bucket_bytes):
         """Buckets of ~bucket_bytes in reverse parameter order (gradients arrive roughly back to front)."""
@@ -231,6 +232,52 @@ class FlatTrainer:
                     self._launch(b)
         return ready
 
+    @staticmethod
+    def _pinned_bucket_mib():
+        """NRPN_GRAD_BUCKET_MIB as a positive integer number of MiB, or None; anything else is a configuration error, said so."""
+        raw = os.environ.get("NRPN_GRAD_BUCKET_MIB")
+        if raw is None or raw == "":
+            return None
+        try:
+            mib = int(raw)
+        except ValueError:
+            mib = 0
+        if not 1 <= mib <= 4096:
+            raise ValueError(f"NRPN_GRAD_BUCKET_MIB={raw!r}: expected an integer number of MiB in 1..4096")
+        return mib
+
+    def _mode_available(self, mode):
+        """Does the backend run ``mode``'s collectives?  Probed with a few floats BEFORE anything is timed, and agreed on by every rank with a
+        plain all-reduce (a failure caught per rank inside the timing loop left the other ranks inside that mode's collectives
+        or the barrier, and the recovery all-reduce then paired with the wrong call).  A failure while TIMING is fatal."""
+        world, grp, dev = self.world, self.group, self.g_arena.device
+        ok, why = 1.0, ""
+        try:
+            g = torch.zeros(64 * world, dtype=torch.float32, device=dev)
+            if mode == "allreduce":
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=grp)
+            elif mode == "rs_ag":
+                mine = torch.empty(64, dtype=torch.float32, device=dev)
+                dist.reduce_scatter_tensor(mine, g, op=dist.ReduceOp.SUM, group=grp)
+                dist.all_gather_into_tensor(g, mine, group=grp)
+            else:
+                send = g.to(torch.bfloat16)
+                recv = torch.empty_like(send)
+                dist.all_to_all_single(recv, send, group=grp)
+                back = torch.empty_like(send)
+                dist.all_gather_into_tensor(back, recv[:64].contiguous(), group=grp)
+            if g.is_cuda:
+                torch.cuda.synchronize()
+        except (RuntimeError, NotImplementedError) as e:      # raised at call time on every rank alike (a backend without the collective)
+            ok, why = 0.0, str(e).splitlines()[0][:200]
+        flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=grp)
+        if flag.item() < 1.0:
+            self.unavailable = getattr(self, "unavailable", {})
+            self.unavailable[mode] = why or "unavailable on another rank"
+            return False
+        return True
+
     def measure_exchange(self, modes=EXCHANGE_MODES, bucket_mib=(16, 32, 64), iters=3):
         """Comm-only timing of every exchange mode x bucket size on the real gradient arena (no compute in flight): {(mode, MiB): ms}, the
         MAX over ranks of the best of ``iters`` passes, so every rank holds the same table.  Leaves arena, buckets and mode as they were."""
@@ -241,35 +288,26 @@ class FlatTrainer:
         for mode in modes:
             if mode != "allreduce" and 64 % self.world != 0:
                 continue
+            if not self._mode_available(mode):        # agreed on by every rank: the mode is not a candidate anywhere
+                continue
             for mib in bucket_mib:
                 self.exchange = mode
                 self._build_buckets(mib << 20)
                 best = float("inf")
-                try:
-                    for it in range(iters + 1):          # first pass = warm-up (communicator / buffer set-up)
-                        if cuda:
-                            torch.cuda.synchronize()
-                        dist.barrier(group=self.group)
-                        t0 = time.perf_counter()
-                        for b in range(len(self.buckets)):
-                            self._launch(b)
-                        self._finish_exchange()
-                        if cuda:
-                            torch.cuda.synchronize()
-                        if it:
-                            best = min(best, time.perf_counter() - t0)
-                except (RuntimeError, NotImplementedError) as e:      # the backend lacks this mode's collectives: it is not a candidate
-                    self.handles, self.finish = [], []
-                    self.launched = [False] * len(self.buckets)
-                    self.unavailable = getattr(self, "unavailable", {})
-                    self.unavailable[mode] = str(e).splitlines()[0][:200]
-                    best = float("inf")
-                t = torch.tensor([best * 1e3 if best != float("inf") else -1.0], dtype=torch.float64, device=self.g_arena.device)
-                lo = t.clone()
+                for it in range(iters + 1):          # first pass = warm-up (communicator / buffer set-up); an error in here is fatal
+                    if cuda:
+                        torch.cuda.synchronize()
+                    dist.barrier(group=self.group)
+                    t0 = time.perf_counter()
+                    for b in range(len(self.buckets)):
+                        self._launch(b)
+                    self._finish_exchange()
+                    if cuda:
+                        torch.cuda.synchronize()
+                    if it:
+                        best = min(best, time.perf_counter() - t0)
+                t = torch.tensor([best * 1e3], dtype=torch.float64, device=self.g_arena.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-                if lo.item() < 0:                    # failed on some rank: dropped on every rank (all ranks keep the same table)
-                    break
                 table[(mode, mib)] = round(t.item(), 4)
         self.g_arena.zero_()
         self.exchange = keep[0]

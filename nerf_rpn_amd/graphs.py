@@ -127,7 +127,9 @@ class GraphedBackbone:
             self._signature = sig
         if not self._sinks_everywhere():
             return bb(x)
-        key = (tuple(x.shape), x.dtype, bb.compute_dtype)
+        # fp32 and bf16x3 share compute_dtype == float32 but run different kernels (split operands, a captured weight split): a capture made
+        # in one arithmetic mode must not be replayed in the other
+        key = (tuple(x.shape), x.dtype, bb.compute_dtype, bool(ops.SPLIT3[0]))
         n = self.calls.get(key, 0)
         self.calls[key] = n + 1
         if n < self.warmup:

@@ -2139,6 +2139,11 @@ class RoiPoolFn(torch.autograd.Function):
     def forward(ctx, kind, meta, level_of, scales, output_size, *levels):
         o0, o1, o2 = (int(v) for v in output_size)
         R = int(meta.shape[0])
+        bad = [f for f in levels if not f.is_cuda or f.dtype not in (torch.float32, torch.bfloat16)]
+        if bad:       # say what is supported instead of a generic "not a CUDA tensor" from deeper down
+            raise lib.NrpnError(f"ROIPool runs on the HIP kernels only (csrc/roipool.hip): feature maps must be CUDA tensors in float32 or "
+                                f"bfloat16, got {bad[0].device} / {bad[0].dtype}; the torch restatement of the reference's pooling "
+                                "(oracle/roipool.py) is test infrastructure, not a fallback")
         cls = [as_channels_last(f[None])[0] for f in levels]          # [X, Y, Z, C]
         C = int(cls[0].shape[-1])
         dev = cls[0].device

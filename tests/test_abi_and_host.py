@@ -164,6 +164,17 @@ def test_rank_to_core_pinning_plan():
     assert all(len(cores) == 1 and cores[0] in (0, 1, 2) for cores, _ in shares)
     # a single rank is never pinned (bench.py's cpu_baseline leg uses every core)
     assert affinity.pin_rank(0, 1)["pinned"] is False
+    # two independent 2-rank jobs on one host (physical GPUs 0-1 and 2-3 of node 0, each job sees its own as devices 0, 1): the shares
+    # follow the GPU's place among the node's four GPUs, so the jobs do not start at the same core
+    phys = {"A": {0: 0, 1: 1}, "B": {0: 2, 1: 3}}
+    got = {}
+    for job, m in phys.items():
+        for r in range(2):
+            got[(job, r)] = affinity.plan(r, 2, allowed=allowed, numa_of=lambda d: 0, cpus_of=cpus.get, slot_of=lambda d, m=m: (m[d], 4))[0]
+    flat = [c for cores in got.values() for c in cores]
+    assert len(flat) == len(set(flat)) == 64 and got[("B", 0)][0] == 32 and all(len(c) == 16 for c in got.values())
+    # without the host-wide view (no sysfs): the job's own ranks divide the node, as before
+    assert affinity.plan(1, 2, allowed=allowed, numa_of=lambda d: 0, cpus_of=cpus.get, slot_of=lambda d: None)[0] == list(range(32, 64))
 
 
 def test_swin_b_of_the_reference_cli_is_rejected_like_the_reference_rejects_it():
