@@ -149,7 +149,8 @@ class ConvProbe:
         es = 2 if dtype_name == "bf16" else 4
         algo_bytes = vox * cin_ * es + vox * cout_ * es + (_k ** 3) * cin_ * cout_ * es      # x + y + w, each once
         traffic, note = None, "no PMC collection for this kernel in profiles/ (null = not measured)"
-        for pmc_name in ("r05_pmc_conv_256x256_40c.json", "r04_pmc_conv_256x256_40c.json", "r03_pmc_conv_256x256_40c.json", "r02_pmc_conv_256x256_40c.json"):
+        for pmc_name in ("r06_pmc_conv_256x256_40c.json", "r05_pmc_conv_256x256_40c.json", "r04_pmc_conv_256x256_40c.json", "r03_pmc_conv_256x256_40c.json",
+                         "r02_pmc_conv_256x256_40c.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if not (os.path.exists(pmc) and shape == (64000, 256, 256, 3)):
                 continue
@@ -427,7 +428,9 @@ def secondary_workloads(dtype, dev, xs, gts, make, steps=12):
 def measured_ceiling():
     """What the MFMA array sustains at the part's power cap on the operands the conv layers multiply (tools/mfma_peak_probe.py: a
     register-only v_mfma_f32_32x32x16_bf16 loop, post-ReLU activations x small weights) -- profiles/r04_mfma_ceiling.json."""
-    path = os.path.join(ROOT, "profiles", "r04_mfma_ceiling.json")      # (round 4's measurement: the probe and the part are unchanged)
+    path = os.path.join(ROOT, "profiles", "r06_mfma_ceiling.json")      # re-measured in round 6 (tools/mfma_peak_probe.py); round 4's otherwise
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r04_mfma_ceiling.json")
     if not os.path.exists(path):
         return None
     rows = json.load(open(path)).get("rows", [])
@@ -435,8 +438,7 @@ def measured_ceiling():
     if not pick:
         return None
     r = pick[0]
-    return {"tflops": r["tflops"], "power_w": r["power_w"], "sclk_mhz": r["sclk_mhz"], "source": "profiles/r04_mfma_ceiling.json",
-            "what": "register-only MFMA loop on post-ReLU randn activations x N(0, 0.05) weights, 2 waves per SIMD"}
+    return {"tflops": r["tflops"], "power_w": r["power_w"], "sclk_mhz": r["sclk_mhz"], "source": "profiles/" + os.path.basename(path)}
 
 
 def conv_source_hash():
@@ -445,6 +447,17 @@ def conv_source_hash():
     for f in ("conv3d.hip", "conv_halo.hip", "conv_common.cuh", "common.h"):
         h.update(open(os.path.join(ROOT, "nerf_rpn_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def _compact(obj):
+    """The JSON line without its prose: every "note" is dropped (DESIGN.md section 4 says what each field is; --notes keeps them) and the
+    traffic note is cut to its first clause.  VERDICT r5: the driver's record of the line lost `host` / `rpn_head_cone` to the length."""
+    if isinstance(obj, dict):
+        return {k: (v[:140] if k == "traffic_note" and isinstance(v, str) else (v.split(" (")[0] if k == "mode_chosen_by" else _compact(v)))
+                for k, v in obj.items() if k not in ("note", "what")}
+    if isinstance(obj, list):
+        return [_compact(v) for v in obj]
+    return obj
 
 
 def main():
@@ -456,6 +469,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="disable per-launch HIP-event timing of the conv kernels")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 step, eval protocol, 2 scenes per GPU)")
+    ap.add_argument("--notes", action="store_true", help="keep the explanatory 'note' strings in the JSON line (dropped by default: DESIGN.md section 4)")
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="per-rank batch of the TIMED region (1 = the BASELINE metric; 2 = the reference's train.sh setting)")
     ap.add_argument("--exchange", default=None, choices=["auto", "allreduce", "rs_ag", "a2a_bf16"],
                     help="gradient exchange of the trainer (N > 1); default auto = the fastest fp32 mode of the comm-only measurement at start-up")
@@ -773,7 +787,7 @@ def main():
             out["config"]["workload"] = f"{args.model}: one 160x160x160x4 grid per GPU, 16 OBB GT boxes, fwd+bwd+clip+AdamW, random-init weights"
         if world == 1 and not args.no_cpu_baseline and args.model == "vgg_rpn":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out if args.notes else _compact(out)))
     if dist_on:
         dist.destroy_process_group()
 

@@ -1442,9 +1442,8 @@ __global__ void adamw_kernel(float *__restrict__ p, float *__restrict__ g, float
   };
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long long quads = count >> 2;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long long)gridDim.x * blockDim.x) {
-    f4 pv = reinterpret_cast<f4 *>(p)[q], mv = reinterpret_cast<f4 *>(m)[q], vv = reinterpret_cast<f4 *>(v)[q];
-    const f4 gv = reinterpret_cast<const f4 *>(g)[q];
+  const long long S = (long long)gridDim.x * blockDim.x;
+  auto quad = [&](long long q, f4 pv, f4 mv, f4 vv, const f4 gv) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float pe = pv[e], me = mv[e], ve = vv[e];
@@ -1458,6 +1457,19 @@ __global__ void adamw_kernel(float *__restrict__ p, float *__restrict__ g, float
       u4s h = {f32_to_bf16_bits(pv[0]), f32_to_bf16_bits(pv[1]), f32_to_bf16_bits(pv[2]), f32_to_bf16_bits(pv[3])};
       reinterpret_cast<u4s *>(shadow)[q] = h;
     }
+  };
+  long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // two quads per iteration: eight 16-byte loads in flight per lane before the first store (round 6: 0.66 -> see bench hbm_stages)
+  for (; q + S < quads; q += 2 * S) {
+    const f4 p0 = reinterpret_cast<f4 *>(p)[q], m0 = reinterpret_cast<f4 *>(m)[q], v0 = reinterpret_cast<f4 *>(v)[q];
+    const f4 g0 = reinterpret_cast<const f4 *>(g)[q];
+    const f4 p1 = reinterpret_cast<f4 *>(p)[q + S], m1 = reinterpret_cast<f4 *>(m)[q + S], v1 = reinterpret_cast<f4 *>(v)[q + S];
+    const f4 g1 = reinterpret_cast<const f4 *>(g)[q + S];
+    quad(q, p0, m0, v0, g0);
+    quad(q + S, p1, m1, v1, g1);
+  }
+  for (; q < quads; q += S) {
+    quad(q, reinterpret_cast<f4 *>(p)[q], reinterpret_cast<f4 *>(m)[q], reinterpret_cast<f4 *>(v)[q], reinterpret_cast<const f4 *>(g)[q]);
   }
   for (long long i = (quads << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
     float pi = p[i], mi = m[i], vi = v[i];
