@@ -51,6 +51,8 @@ int nrpn_set_bn_fast(int on);
 int nrpn_set_bn_reduce_v8(int on);
 /* max-pool forward / backward: 1 (default) = multiply-shift index arithmetic + compile-time stride, 0 = the general kernels (A/B, same bits) */
 int nrpn_set_pool_fast(int on);
+/* GroupNorm apply / backward-apply (bf16, C / groups % 8 == 0): 1 (default) = hoisted-parameter kernels with 16-byte accesses, 0 = general (A/B, same bits) */
+int nrpn_set_gn_fast(int on);
 /* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
 int nrpn_set_window_attn_mfma(int on);
 

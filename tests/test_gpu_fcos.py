@@ -65,6 +65,33 @@ def test_groupnorm_matches_torch(dev):
         assert rel(y, yr) < 5e-6 and rel(gx, rx) < 2e-5 and rel(gw, rw) < 2e-5 and rel(gb, rb) < 2e-5, (shape, rel(y, yr), rel(gx, rx))
 
 
+def test_groupnorm_fast_elementwise_passes_are_bit_identical(dev):
+    """Round 6: the hoisted-parameter GroupNorm apply / backward-apply kernels (bf16, 8 channels per lane, C / groups % 8 == 0) against the
+    general kernels: outputs and input gradients must be the same bits (two samples, ragged row counts, with and without ReLU); and the bf16
+    result stays within bf16 rounding of torch's fp32 GroupNorm."""
+    from nerf_rpn_amd import lib, ops
+    g = torch.Generator().manual_seed(1)
+    for shape, groups, relu in [((2, 6, 5, 4, 256), 32, True), ((1, 21, 7, 3, 256), 32, False), ((2, 9, 4, 4, 128), 16, True)]:
+        x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dev).bfloat16()
+        w = (torch.rand(shape[-1], generator=g) + 0.5).to(dev)
+        b = (torch.randn(shape[-1], generator=g) * 0.3).to(dev)
+        dy = torch.randn(shape, generator=g).to(dev).bfloat16()
+        out = []
+        for fast in (1, 0):
+            lib.call("set_gn_fast", fast)
+            try:
+                xx = x.clone().requires_grad_()
+                y = ops.GroupNormFn.apply(xx, w, b, groups, 1e-5, relu)
+                (gx,) = torch.autograd.grad(y, (xx,), dy)
+                out.append((y.detach().clone(), gx.clone()))
+            finally:
+                lib.call("set_gn_fast", 1)
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), shape
+        yr = F.group_norm(x.float().permute(0, 4, 1, 2, 3), groups, w, b, 1e-5)
+        yr = (F.relu(yr) if relu else yr).permute(0, 2, 3, 4, 1)
+        assert rel(out[0][0].float(), yr) < 1e-2
+
+
 @pytest.mark.parametrize("rot,ctr_on_reg,training", [(False, True, True), (True, True, False), (True, False, True)])
 def test_head_matches_oracle_on_identical_features(rot, ctr_on_reg, training, dev):
     """FCOSHead forward + backward (towers, GroupNorm, fused final GEMMs, Scale / ReLU / stride epilogue) vs the oracle."""
