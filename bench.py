@@ -519,7 +519,8 @@ def main():
     knobs = {}
     for env, fn in (("NRPN_CONV_TILE_M", "set_conv_tile_m"), ("NRPN_CONV_BIG_SPLIT", "set_conv_big_split"), ("NRPN_WGRAD_BIG", "set_wgrad_big_tile"),
                     ("NRPN_CONV_STAGGER", "set_conv_stagger"), ("NRPN_ROWS_BIG", "set_rows_big_tile"), ("NRPN_ROWS_TAIL", "set_rows_tail_split"), ("NRPN_BN_FAST", "set_bn_fast"),
-                    ("NRPN_WGRAD_PACK2", "set_wgrad_pack2"), ("NRPN_POOL_FAST", "set_pool_fast"), ("NRPN_GN_FAST", "set_gn_fast")):      # tools-only process defaults (A/B runs); the measured configuration sets none
+                    ("NRPN_WGRAD_PACK2", "set_wgrad_pack2"), ("NRPN_POOL_FAST", "set_pool_fast"), ("NRPN_GN_FAST", "set_gn_fast"),
+                    ("NRPN_HALO_AUTO", "set_conv_halo_auto")):      # tools-only process defaults (A/B runs); the measured configuration sets none
         if env in os.environ:
             lib.call(fn, int(os.environ[env]))
             knobs[env] = int(os.environ[env])
