@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS tools/patches/r6_fused_splitk.patch applied (git apply) and the library rebuilt (the fused split-K experiment is not merged).
 # round 6, call 4: fused split-K (20^3-class launches on the 256x256 tile): parity + forward sequence + bench A/B against the two-launch form
 cd "$(dirname "$0")/.."
 O=gpurun_out/${OUT:-r6c4}

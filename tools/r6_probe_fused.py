@@ -1,4 +1,5 @@
-"""EXPERIMENT: time the K-sliced 20^3 launches in the fused / two-launch forms (and the fused form's debug variants)."""
+"""NEEDS tools/patches/r6_fused_splitk.patch applied (git apply) and the library rebuilt: ops.FUSED_SPLIT / NRPN_FUSED_DBG exist only there.
+EXPERIMENT: time the K-sliced 20^3 launches in the fused / two-launch forms (and the fused form's debug variants)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from nerf_rpn_amd import lib, ops
