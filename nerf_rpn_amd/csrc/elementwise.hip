@@ -70,6 +70,11 @@ static inline int slab_rows(long long rows) { const long long s = (rows + 1023) 
 // MODE 0: (sum x, sum x^2)           MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * (y > 0 if relu)
 // V channels per lane: 4, or 8 for bf16 with C % 8 == 0 (16-byte loads: half the load instructions and address arithmetic per byte; round 5 --
 // the 8-byte form ran at 0.27-0.39 of the HBM rate on the 64000-row maps).
+// rows in flight per lane.  Round 6 sweep (-DNRPN_CHAN_UNROLL, one MI355X; bn_backward on 64 ch x 512000 / 256 ch x 64000 rows, us; bench step, ms):
+// 2: 61.6 / 39.1, 8.70-8.75;  4: 60.4 / 39.1, 8.72-8.78;  8: 70.0 / 43.9, 8.82-8.86;  16: 97.5 / 59.4, 8.94 -- more loads in flight cost occupancy
+#ifndef NRPN_CHAN_UNROLL
+#define NRPN_CHAN_UNROLL 4
+#endif
 template <typename T, int MODE, int V>
 __global__ void __launch_bounds__(256)
 chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy, long long rows, int c,
@@ -99,7 +104,7 @@ chan_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, const T *_
         if (beta) { ga[k] = gamma[tx * V + k]; be[k] = beta[tx * V + k]; }
       }
     }
-#pragma unroll 4
+#pragma unroll NRPN_CHAN_UNROLL
     for (long long r = r0 + ty; r < r1; r += ty_n) {
       float xv[V];
       vecv<T, V>::ld(x + r * c + tx * V, xv);
