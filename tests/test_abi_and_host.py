@@ -177,6 +177,19 @@ def test_rank_to_core_pinning_plan():
     assert affinity.plan(1, 2, allowed=allowed, numa_of=lambda d: 0, cpus_of=cpus.get, slot_of=lambda d: None)[0] == list(range(32, 64))
 
 
+def test_pinned_bucket_size_is_validated(monkeypatch):
+    """NRPN_GRAD_BUCKET_MIB is a configuration input -- garbage raises a message that names it instead of an int() traceback."""
+    from nerf_rpn_amd.engine import FlatTrainer
+    monkeypatch.delenv("NRPN_GRAD_BUCKET_MIB", raising=False)
+    assert FlatTrainer._pinned_bucket_mib() is None
+    monkeypatch.setenv("NRPN_GRAD_BUCKET_MIB", "32")
+    assert FlatTrainer._pinned_bucket_mib() == 32
+    for bad in ("0", "-4", "64MiB", "1e3", "99999"):
+        monkeypatch.setenv("NRPN_GRAD_BUCKET_MIB", bad)
+        with pytest.raises(ValueError, match="NRPN_GRAD_BUCKET_MIB"):
+            FlatTrainer._pinned_bucket_mib()
+
+
 def test_swin_b_of_the_reference_cli_is_rejected_like_the_reference_rejects_it():
     """run_rpn.py:284 lists swin_b as embed_dim 128 with heads [3, 6, 12, 24]; 128 is not divisible by 3, and the reference's attention
     (feature_extractor.py:446, qkv.reshape(..., 3, heads, C // heads)) raises on the first forward.  Here construction fails with a message
