@@ -53,6 +53,8 @@ int nrpn_set_bn_reduce_v8(int on);
 int nrpn_set_pool_fast(int on);
 /* GroupNorm apply / backward-apply (bf16, C / groups % 8 == 0): 1 (default) = hoisted-parameter kernels with 16-byte accesses, 0 = general (A/B, same bits) */
 int nrpn_set_gn_fast(int on);
+/* host evaluation of the kernels' multiply-shift division (csrc/common.h FastDiv): n / d for 0 <= n < 2^31, 1 <= d < 2^31 (-1 outside); tests only */
+int64_t nrpn_fastdiv_host(int64_t n, int64_t d);
 /* bf16 window attention: 1 (default) = MFMA kernels, 0 = the VALU kernels (always used for fp32) */
 int nrpn_set_window_attn_mfma(int on);
 

@@ -36,6 +36,14 @@ int nrpn_ensure_dynamic_lds(const void *kernel, int bytes) {
   return NRPN_OK;
 }
 extern "C" int nrpn_abi_version(void) { return 3; }
+// tools / tests: the multiply-shift division of common.h (FastDiv) evaluated on the HOST with the same magic pair and the same arithmetic the
+// kernels use (mulhi, shift) -- lets the CPU suite check the construction against n / d without a GPU
+extern "C" int64_t nrpn_fastdiv_host(int64_t n, int64_t d) {
+  if (n < 0 || n >= (1ll << 31) || d < 1 || d >= (1ll << 31)) return -1;
+  const FastDiv f = make_fastdiv((unsigned)d);
+  if (f.d == 1) return n;
+  return (int64_t)((unsigned)(((unsigned long long)(unsigned)n * f.m) >> 32) >> f.sh);
+}
 
 extern "C" int nrpn_check_device(int ordinal) {
   hipDeviceProp_t p;

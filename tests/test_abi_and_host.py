@@ -45,7 +45,8 @@ def test_process_wide_switches_live_in_the_tools_header_only():
     everything = set(lib.declared_symbols())
     assert not [n for n in public if n.startswith("nrpn_set_")]
     setters = sorted(n for n in everything - public)
-    assert setters and all(n.startswith("nrpn_set_") for n in setters), setters
+    # (+ one stateless test helper: the host evaluation of the kernels' multiply-shift division)
+    assert setters and all(n.startswith("nrpn_set_") or n == "nrpn_fastdiv_host" for n in setters), setters
     src = open(os.path.join(os.path.dirname(lib.HEADER), "nerfrpn_tools.h")).read()
     assert '#include "nerfrpn.h"' in src
 
@@ -175,6 +176,25 @@ def test_rank_to_core_pinning_plan():
     assert len(flat) == len(set(flat)) == 64 and got[("B", 0)][0] == 32 and all(len(c) == 16 for c in got.values())
     # without the host-wide view (no sysfs): the job's own ranks divide the node, as before
     assert affinity.plan(1, 2, allowed=allowed, numa_of=lambda d: 0, cpus_of=cpus.get, slot_of=lambda d: None)[0] == list(range(32, 64))
+
+
+def test_multiply_shift_division_of_the_kernels_is_exact():
+    """Round 6: the implicit-GEMM loaders, the pools and the top-down add decompose voxel indices with a multiply-shift pair made on the host
+    (csrc/common.h: m = ceil(2^(31+l) / d), q = mulhi(n, m) >> (l - 1)).  The library's host evaluation of exactly that arithmetic must equal
+    n // d for every n < 2^31: small divisors, powers of two and their neighbours, random ones, and the n around multiples of d."""
+    import random
+    from nerf_rpn_amd import lib
+    L = lib.load()
+    rnd = random.Random(0)
+    ds = list(range(1, 200)) + [2 ** k + e for k in range(2, 31) for e in (-1, 0, 1)] + [rnd.randrange(1, 2 ** 31) for _ in range(300)]
+    for d in ds:
+        if not 1 <= d < 2 ** 31:
+            continue
+        ns = [0, 1, 2 ** 31 - 1, 2 ** 31 - 2, 2 ** 30] + [rnd.randrange(0, 2 ** 31) for _ in range(40)]
+        ns += [k * d + e for k in (1, 2, (2 ** 31 - 1) // d) for e in (-1, 0, 1) if 0 <= k * d + e < 2 ** 31]
+        for n in ns:
+            assert L.nrpn_fastdiv_host(n, d) == n // d, (n, d)
+    assert L.nrpn_fastdiv_host(2 ** 31, 3) == -1 and L.nrpn_fastdiv_host(5, 0) == -1
 
 
 def test_pinned_bucket_size_is_validated(monkeypatch):
